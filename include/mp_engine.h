@@ -1,0 +1,223 @@
+/* mp_engine.h -- C-ABI of the MI355X-native render-and-compare pose engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.
+ * The reference (megapose6d) is pure Python and has no FFI layer; the seam is three
+ * duck-typed Python objects.  Each entry point below names the reference interface it
+ * replaces (paths relative to /root/reference/src/megapose/).  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C, no torch types; every pointer named d_* is DEVICE memory (HBM), h_* is HOST.
+ *  - mp_stream is a hipStream_t; all work is enqueued on it, nothing synchronises.
+ *  - return value: 0 = ok, negative = error (message via mp_last_error()).
+ *  - handles are opaque, thread-compatible (one thread per handle at a time).
+ *  - outputs are caller-allocated.
+ *  - images/activations inside the engine are fp32 NHWC with a zero border ("padded NHWC"):
+ *    element (n, y, x, c) of a tensor with logical size H x W, border B, channels C lives at
+ *    ((n*(H+2B) + y+B)*(W+2B) + x+B)*C + c.  Borders are zero and never written.
+ */
+#ifndef MP_ENGINE_H
+#define MP_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mp_stream; /* hipStream_t */
+
+#define MP_OK 0
+#define MP_ERR_INVALID (-22)
+#define MP_ERR_NOMEM (-12)
+#define MP_ERR_HIP (-5)
+
+int mp_version(void);
+const char* mp_last_error(void);
+/* number of CUs etc. of the current device; fails loudly when no gfx950 device is usable */
+int mp_device_info(int* n_cus, int* lds_bytes, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------ */
+/* Mesh database: replaces the per-worker Panda3D model cache                            */
+/* (panda3d_renderer/panda3d_scene_renderer.py:192-207 get_object_node) and the          */
+/* BatchedMeshes point tensors (lib3d/rigid_mesh_database.py:90-130).                     */
+/* ------------------------------------------------------------------------------------ */
+typedef struct mp_mesh_db mp_mesh_db;
+
+typedef struct {
+  const float* h_vertices; /* [n_vertices,3] metres (RigidObject.scale and ypr offset applied) */
+  const float* h_normals;  /* [n_vertices,3] unit vertex normals (object frame)                */
+  const float* h_colors;   /* [n_vertices,3] albedo in [0,1] (uint8/255)                       */
+  const int32_t* h_faces;  /* [n_faces,3]                                                      */
+  int32_t n_vertices;
+  int32_t n_faces;
+} mp_mesh_desc;
+
+int mp_mesh_db_create(const mp_mesh_desc* h_meshes, int n_meshes, mp_mesh_db** out);
+int mp_mesh_db_destroy(mp_mesh_db* db);
+int mp_mesh_db_max_vertices(const mp_mesh_db* db);
+/* bounding-sphere radius (AABB centre) of mesh i, used for the point-light placement
+ * (panda3d_scene_renderer.py:121-125 pos_fn) */
+float mp_mesh_db_radius(const mp_mesh_db* db, int mesh_id);
+
+/* ------------------------------------------------------------------------------------ */
+/* Rasteriser: replaces Panda3dBatchRenderer.render                                       */
+/* (panda3d_renderer/panda3d_batch_renderer.py:217-282; worker_loop :89-150;              */
+/*  Panda3dSceneRenderer.render_scene panda3d_scene_renderer.py:298-358).                 */
+/* One object per view, pinhole K, near 0.1 m / far 10 m (types.py:63-64).                */
+/* ------------------------------------------------------------------------------------ */
+#define MP_RASTER_NORMALS 1u      /* render_normals=True: eye-normal LUT pass               */
+#define MP_RASTER_DEPTH 2u        /* render_depth=True: metric z, 0 = background            */
+#define MP_RASTER_NORMALS_GL 4u   /* eye space = GL (x right,y up,z back) instead of Panda  */
+#define MP_RASTER_NO_QUANT 8u     /* skip the uint8 round trip (not reference behaviour)    */
+
+typedef struct {
+  float ambient[3];        /* sum of ambient light colours                                  */
+  int32_t n_point;         /* number of point lights (<= 8)                                 */
+  float point_dir[8][3];   /* unit direction; position = dir * 10 * mesh radius             */
+  float point_color[8][3]; /* (panda3d_scene_renderer.py:104-136 make_scene_lights)         */
+} mp_lights;
+
+size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views);
+
+/* d_out addressing: element (view v, y, x, channel c) at d_out[v*stride_v + y*stride_y + x*stride_x + c].
+ * c_rgb / c_normals / c_depth are the first channel of each group (negative = not written).
+ * Values are uint8-quantised then /255 exactly as panda3d_batch_renderer.py:261-274
+ * (depth is not quantised).  Non-finite TCO/K rows produce zeros (:109-135).              */
+int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO /*[n,4,4]*/,
+                     const float* d_K /*[n,3,3]*/, int n_views, int h, int w, uint32_t flags,
+                     const mp_lights* h_lights, float* d_out, int64_t stride_v, int64_t stride_y,
+                     int64_t stride_x, int c_rgb, int c_normals, int c_depth, void* d_workspace,
+                     size_t workspace_bytes, mp_stream stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Crop: replaces lib3d/cropping.py:113-144 crop_images (torchvision.ops.roi_align,       */
+/* sampling_ratio=4, aligned=False) incl. the RGBD validity rule (:131-142), reading the  */
+/* observation by batch_im_id (no per-row gather, pose_estimator.py:389).                 */
+/* ------------------------------------------------------------------------------------ */
+int mp_crop_roi_align(const float* d_images /*[n_im,C,H,W] NCHW*/, int n_im, int C, int H, int W,
+                      const int32_t* d_im_ids /*[b]*/, const float* d_boxes /*[b,4] x1,y1,x2,y2*/, int b,
+                      int out_h, int out_w, float* d_out, int64_t stride_b, int64_t stride_y,
+                      int64_t stride_x, int c0, mp_stream stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Depth normalisation: models/pose_rigid.py:466-496 normalize_depth                      */
+/* mode: 0 none, 1 tCR_scale, 2 tCR_scale_clamp_center, 3 tCR_center_clamp                */
+/* applied in place to `n_ch` channels (list h_channels) of a padded-NHWC tensor.         */
+/* ------------------------------------------------------------------------------------ */
+int mp_normalize_depth(float* d_x, int b, int h, int w, int border, int C, const int32_t* h_channels,
+                       int n_ch, const float* d_tCR /*[b,3]*/, int mode, mp_stream stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Convolution stack: replaces `self.backbone(x)` (models/pose_rigid.py:323) for           */
+/* models/torchvision_resnet.py (vanilla_resnet34) and models/wide_resnet.py               */
+/* (WideResNet18/34).  fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out.             */
+/* ------------------------------------------------------------------------------------ */
+/* number of floats of the packed weight blob of one conv (Cin_p = padded input channels) */
+size_t mp_conv_packed_floats(int Cin_p, int Cout, int KH, int KW);
+/* host-side packing of OIHW weights with per-output-channel scale folded in (eval BN).    */
+int mp_conv_pack_weights(const float* h_w_oihw, int Cout, int Cin, int KH, int KW, int Cin_p,
+                         const float* h_scale /*[Cout] or NULL*/, float* h_packed);
+
+typedef struct {
+  const float* d_x;        /* padded NHWC input                                             */
+  int32_t N, H, W, C;      /* logical input size; C = padded channel count (multiple of 4)   */
+  int32_t in_border;
+  const float* d_w;        /* packed weights (mp_conv_pack_weights)                          */
+  const float* d_bias;     /* [Cout] or NULL                                                 */
+  int32_t Cout, KH, KW, stride, pad;
+  float* d_y;              /* padded NHWC output (may be NULL when only d_y_act is wanted)   */
+  int32_t out_border;
+  const float* d_residual; /* same geometry as d_y, or NULL                                  */
+  int32_t relu;            /* y = relu(conv + bias + residual)                               */
+  float* d_y_act;          /* optional second output relu(y*act_scale + act_shift)           */
+  const float* d_act_scale;
+  const float* d_act_shift;
+} mp_conv_desc;
+
+int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);
+/* the name of the kernel instantiation mp_conv2d_nhwc would launch (for profiling)        */
+const char* mp_conv2d_kernel_name(const mp_conv_desc* desc);
+
+/* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
+int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,
+                    int out_border, float* d_y_act, const float* d_act_scale, const float* d_act_shift,
+                    mp_stream stream);
+
+/* global average pool (+ optional fc) + heads: models/torchvision_resnet.py:311-314 and  */
+/* models/pose_rigid.py:326-333.  d_fc_w may be NULL (WideResNet: features = pooled).      */
+int mp_pool_fc_heads(const float* d_x, int N, int H, int W, int C, int in_border, const float* d_fc_w,
+                     const float* d_fc_b, int n_feat, const float* d_head_w, const float* d_head_b,
+                     int n_out, float* d_feat /*[N,n_feat] or NULL*/, float* d_out /*[N,n_out]*/,
+                     float* d_sigmoid /*[N,n_out] or NULL*/, mp_stream stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Backbone executor: whole network as one call (weights resident on the device).         */
+/* ------------------------------------------------------------------------------------ */
+typedef struct mp_backbone mp_backbone;
+#define MP_BACKBONE_VANILLA_RESNET34 0
+#define MP_BACKBONE_WIDE_RESNET34 1
+#define MP_BACKBONE_WIDE_RESNET18 2
+
+typedef struct {
+  const char* name;    /* state_dict key, e.g. "backbone.layer1.0.conv1.weight"             */
+  const float* h_data; /* host fp32, contiguous                                              */
+  int64_t numel;
+} mp_named_tensor;
+
+/* state_dict layout = the reference checkpoints' (SURVEY.md App. F): backbone.*, pose_fc.*, */
+/* views_logits_head.*.  head: 0 = pose_fc (9 outputs), 1 = views_logits_head (n_views).     */
+int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* h_state,
+                       int n_tensors, mp_backbone** out);
+int mp_backbone_destroy(mp_backbone* bb);
+int mp_backbone_input_channels_padded(const mp_backbone* bb);
+int mp_backbone_input_border(const mp_backbone* bb);
+size_t mp_backbone_workspace_bytes(const mp_backbone* bb, int batch, int h, int w);
+/* d_x: padded NHWC [batch, h, w, Cp] with border mp_backbone_input_border().                */
+int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out,
+                        float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
+                        mp_stream stream);
+/* algorithmic conv+fc FLOPs of one forward at this batch (2*MACs, real channels only)       */
+double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w);
+
+/* ------------------------------------------------------------------------------------ */
+/* Pose math (all fp32, one thread block per row)                                          */
+/* ------------------------------------------------------------------------------------ */
+/* lib3d/transform_ops.py:117-119 normalize_T (ortho6d Gram-Schmidt, rotations.py:25-40)    */
+int mp_normalize_T(const float* d_T, int b, float* d_T_out, mp_stream stream);
+
+/* per-(mesh, rotation) extents for TCO_init_from_boxes_autodepth_with_R                     */
+/* (lib3d/cosypose_ops.py:198-208): d_ext[(mesh*n_rot + r)*2 + {0,1}] = max-min of x,y of R p */
+int mp_init_extents(const float* d_points /*[n_mesh,n_pts,3]*/, int n_mesh, int n_pts,
+                    const float* d_R /*[n_rot,3,3]*/, int n_rot, float* d_ext, mp_stream stream);
+/* lib3d/cosypose_ops.py:169-218.  row i uses mesh d_mesh_ids[i], rotation d_rot_ids[i]      */
+int mp_init_poses_from_boxes(const float* d_boxes /*[b,4]*/, const float* d_K /*[b,3,3]*/,
+                             const int32_t* d_mesh_ids, const int32_t* d_rot_ids, const float* d_R,
+                             int n_rot, const float* d_ext, int b, float* d_TCO /*[b,4,4]*/,
+                             mp_stream stream);
+
+/* One refiner/coarse "prepare" step for b rows x V views:                                  */
+/*   TCO_n = normalize_T(TCO)                     (models/pose_rigid.py:524, :678)           */
+/*   tCR   = TCO_n[:3,3]                          (:527-529)                                 */
+/*   TCV_O = make_TCO_multiview(...)              (lib3d/multiview.py:165-246; App. A.5)     */
+/*   boxes_rend/boxes_crop/K_crop from 2000 pts   (pose_rigid.py:180-247 crop_inputs)        */
+/*   KV_crop from 200 pts for views >= 1          (:249-303; KV_crop[:,0] = K_crop :551-552) */
+/* multiview: 0 = single view (V must be 1), 1 = "TCO+front_3views" (V = 4)                  */
+int mp_pose_prepare(const float* d_TCO_in /*[b,4,4]*/, const float* d_K /*[b,3,3]*/,
+                    const int32_t* d_mesh_ids, const float* d_points /*[n_mesh,n_pts,3] sampled*/,
+                    int n_pts_stride, int n_pts_main, int n_pts_views, int b, int V, int multiview,
+                    int im_h, int im_w, int out_h, int out_w, float lamb,
+                    float* d_TCO_n /*[b,4,4]*/, float* d_tCR /*[b,3]*/, float* d_TCV_O /*[b,V,4,4]*/,
+                    float* d_KV_crop /*[b,V,3,3]*/, float* d_boxes_rend /*[b,4]*/,
+                    float* d_boxes_crop /*[b,4]*/, mp_stream stream);
+
+/* models/pose_rigid.py:305-312 update_pose + lib3d/cosypose_ops.py:33-58                    */
+int mp_pose_update(const float* d_TCO /*[b,4,4]*/, const float* d_K_crop /*[b,3,3] (stride 9*kstride)*/,
+                   int k_stride_floats, const float* d_out9 /*[b,9]*/, const float* d_tCR /*[b,3]*/, int b,
+                   float* d_TCO_out, mp_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP_ENGINE_H */

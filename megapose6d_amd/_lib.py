@@ -1,0 +1,131 @@
+"""ctypes binding of libmp_engine.so (the C-ABI in include/mp_engine.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails
+this module raises.  Build with ``python __graft_entry__.py`` (or ``make -C megapose6d_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libmp_engine.so"
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("h_vertices", C.c_void_p),
+        ("h_normals", C.c_void_p),
+        ("h_colors", C.c_void_p),
+        ("h_faces", C.c_void_p),
+        ("n_vertices", C.c_int32),
+        ("n_faces", C.c_int32),
+    ]
+
+
+class Lights(C.Structure):
+    _fields_ = [
+        ("ambient", C.c_float * 3),
+        ("n_point", C.c_int32),
+        ("point_dir", (C.c_float * 3) * 8),
+        ("point_color", (C.c_float * 3) * 8),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("in_border", C.c_int32),
+        ("d_w", C.c_void_p),
+        ("d_bias", C.c_void_p),
+        ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("d_y", C.c_void_p),
+        ("out_border", C.c_int32),
+        ("d_residual", C.c_void_p),
+        ("relu", C.c_int32),
+        ("d_y_act", C.c_void_p),
+        ("d_act_scale", C.c_void_p),
+        ("d_act_shift", C.c_void_p),
+    ]
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("h_data", C.c_void_p), ("numel", C.c_int64)]
+
+
+_vp, _i, _i64, _f, _sz, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint32
+
+# name -> (restype, argtypes); exactly the symbols declared in include/mp_engine.h
+SIGNATURES = {
+    "mp_version": (_i, []),
+    "mp_last_error": (C.c_char_p, []),
+    "mp_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "mp_mesh_db_create": (_i, [C.POINTER(MeshDesc), _i, C.POINTER(_vp)]),
+    "mp_mesh_db_destroy": (_i, [_vp]),
+    "mp_mesh_db_max_vertices": (_i, [_vp]),
+    "mp_mesh_db_radius": (_f, [_vp, _i]),
+    "mp_raster_workspace_bytes": (_sz, [_vp, _i]),
+    "mp_raster_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i64, _i64, _i, _i, _i,
+                              _vp, _sz, _vp]),
+    "mp_crop_roi_align": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _i, _vp]),
+    "mp_normalize_depth": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),
+    "mp_conv_packed_floats": (_sz, [_i, _i, _i, _i]),
+    "mp_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mp_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "mp_conv2d_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
+    "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
+    "mp_backbone_destroy": (_i, [_vp]),
+    "mp_backbone_input_channels_padded": (_i, [_vp]),
+    "mp_backbone_input_border": (_i, [_vp]),
+    "mp_backbone_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mp_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_backbone_flops": (C.c_double, [_vp, _i, _i, _i]),
+    "mp_normalize_T": (_i, [_vp, _i, _vp, _vp]),
+    "mp_init_extents": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "mp_init_poses_from_boxes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "mp_pose_prepare": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp]),
+    "mp_pose_update": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmp_engine.so and bind every symbol; raises EngineError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("MP_ENGINE_LIB", LIB_PATH))
+    if not path.is_file():
+        raise EngineError(
+            f"{path} not found: the HIP engine is not built. Run `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback."
+        )
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise EngineError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EngineError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().mp_last_error().decode("utf-8", "replace")
+        raise EngineError(f"mp_engine error {rc}: {msg}")

@@ -1,0 +1,334 @@
+// backbone.hip -- native executor for the CNN backbones + heads (host-side C++; kernels live in conv.hip / pool_fc.hip).
+//
+// Reference graph: src/megapose/models/torchvision_resnet.py:181-316 (vanilla_resnet34 = torchvision ResNet-34 with
+// n_input_channels and fc 512->512), src/megapose/models/wide_resnet.py:29-126 (pre-activation WideResNet18/34),
+// heads src/megapose/models/pose_rigid.py:122-130, selection src/megapose/training/pose_models_cfg.py:90-138.
+// Weights arrive as the reference checkpoint's state_dict (SURVEY.md App. F key layout); eval-mode BatchNorm is folded
+// into the preceding conv at load time (w' = w * g/sqrt(var+eps), b' = beta - mean * g/sqrt(var+eps)); the WideResNet
+// block-input BN (bn1) cannot fold and is emitted by the PRODUCER's epilogue as a second "activated" output.
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace mp {
+
+struct ConvLayer {
+  int Cin, Cin_p, Cout, K, stride, pad;
+  float* d_w = nullptr;
+  float* d_b = nullptr;  // folded BN shift (may be null)
+};
+
+struct BnAct {  // unfoldable pre-activation BN: relu(x*scale + shift)
+  float* d_scale = nullptr;
+  float* d_shift = nullptr;
+};
+
+struct Block {
+  ConvLayer conv1, conv2, down;
+  bool has_down = false;
+  BnAct pre;   // WideResNet: bn1 of THIS block (applied by the producer of its input)
+};
+
+}  // namespace mp
+
+using namespace mp;
+
+struct mp_backbone {
+  int kind, c_in, c_in_p, in_border, head_kind, n_out, n_feat;
+  bool wide;
+  ConvLayer stem;
+  std::vector<Block> blocks;
+  std::vector<int> stage_of_block;  // 0..3
+  float *d_fc_w = nullptr, *d_fc_b = nullptr, *d_head_w = nullptr, *d_head_b = nullptr;
+  std::vector<void*> allocs;
+  // workspace bookkeeping (borders are zeroed once per (pointer, batch, h, w))
+  void* ws_ptr = nullptr;
+  int ws_batch = 0, ws_h = 0, ws_w = 0;
+};
+
+namespace {
+
+typedef std::map<std::string, std::pair<const float*, int64_t>> StateMap;
+
+int upload(mp_backbone* bb, const std::vector<float>& h, float** d) {
+  MP_CHECK_HIP(hipMalloc(d, h.size() * sizeof(float)));
+  MP_CHECK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  bb->allocs.push_back(*d);
+  return MP_OK;
+}
+
+const float* find(const StateMap& sm, const std::string& k, int64_t numel) {
+  auto it = sm.find(k);
+  if (it == sm.end()) {
+    set_error("mp_backbone_create: missing state_dict key '%s'", k.c_str());
+    return nullptr;
+  }
+  if (it->second.second != numel) {
+    set_error("mp_backbone_create: key '%s' has %ld elements, expected %ld", k.c_str(), (long)it->second.second, (long)numel);
+    return nullptr;
+  }
+  return it->second.first;
+}
+
+// eval BatchNorm -> per-channel (scale, shift)
+int bn_affine(const StateMap& sm, const std::string& prefix, int C, std::vector<float>& scale, std::vector<float>& shift) {
+  const float* g = find(sm, prefix + ".weight", C);
+  const float* b = find(sm, prefix + ".bias", C);
+  const float* m = find(sm, prefix + ".running_mean", C);
+  const float* v = find(sm, prefix + ".running_var", C);
+  if (!g || !b || !m || !v) return MP_ERR_INVALID;
+  scale.resize(C);
+  shift.resize(C);
+  for (int c = 0; c < C; ++c) {
+    const float s = g[c] / sqrtf(v[c] + 1e-5f);
+    scale[c] = s;
+    shift[c] = b[c] - m[c] * s;
+  }
+  return MP_OK;
+}
+
+int make_conv(mp_backbone* bb, const StateMap& sm, const std::string& wkey, const std::string& bnkey /* "" = none */, int Cin,
+              int Cin_p, int Cout, int K, int stride, int pad, ConvLayer* L) {
+  L->Cin = Cin; L->Cin_p = Cin_p; L->Cout = Cout; L->K = K; L->stride = stride; L->pad = pad;
+  const float* w = find(sm, wkey, (int64_t)Cout * Cin * K * K);
+  if (!w) return MP_ERR_INVALID;
+  std::vector<float> scale, shift;
+  if (!bnkey.empty()) {
+    int rc = bn_affine(sm, bnkey, Cout, scale, shift);
+    if (rc) return rc;
+  }
+  std::vector<float> packed(mp_conv_packed_floats(Cin_p, Cout, K, K));
+  int rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
+  if (rc) return rc;
+  rc = upload(bb, packed, &L->d_w);
+  if (rc) return rc;
+  if (!bnkey.empty()) {
+    rc = upload(bb, shift, &L->d_b);
+    if (rc) return rc;
+  }
+  return MP_OK;
+}
+
+int make_bnact(mp_backbone* bb, const StateMap& sm, const std::string& bnkey, int C, BnAct* a) {
+  std::vector<float> scale, shift;
+  int rc = bn_affine(sm, bnkey, C, scale, shift);
+  if (rc) return rc;
+  rc = upload(bb, scale, &a->d_scale);
+  if (rc) return rc;
+  return upload(bb, shift, &a->d_shift);
+}
+
+int run_conv(const ConvLayer& L, const float* x, int N, int H, int W, int in_border, float* y, int out_border, const float* res,
+             int relu, float* y_act, const BnAct* act, hipStream_t s) {
+  mp_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.d_x = x; d.N = N; d.H = H; d.W = W; d.C = L.Cin_p; d.in_border = in_border;
+  d.d_w = L.d_w; d.d_bias = L.d_b; d.Cout = L.Cout; d.KH = L.K; d.KW = L.K; d.stride = L.stride; d.pad = L.pad;
+  d.d_y = y; d.out_border = out_border; d.d_residual = res; d.relu = relu;
+  d.d_y_act = y_act;
+  if (y_act) { d.d_act_scale = act->d_scale; d.d_act_shift = act->d_shift; }
+  return mp_conv2d_nhwc(&d, s);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline size_t buf_floats(int N, int H, int W, int C) { return (size_t)N * (H + 2) * (W + 2) * C + 64; }
+
+struct Geometry {
+  int h1, w1;       // stem output
+  int hs[4], ws[4]; // stage resolutions
+};
+
+Geometry geometry(const mp_backbone* bb, int h, int w) {
+  Geometry g;
+  g.h1 = (h + 2 * bb->stem.pad - bb->stem.K) / 2 + 1;
+  g.w1 = (w + 2 * bb->stem.pad - bb->stem.K) / 2 + 1;
+  g.hs[0] = (g.h1 + 2 - 3) / 2 + 1;
+  g.ws[0] = (g.w1 + 2 - 3) / 2 + 1;
+  for (int s = 1; s < 4; ++s) {
+    g.hs[s] = (g.hs[s - 1] + 2 - 3) / 2 + 1;
+    g.ws[s] = (g.ws[s - 1] + 2 - 3) / 2 + 1;
+  }
+  return g;
+}
+
+const int kStageC[4] = {64, 128, 256, 512};
+
+}  // namespace
+
+extern "C" int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
+                                  mp_backbone** out) {
+  MP_REQUIRE(out && st && n_tensors > 0, "mp_backbone_create: bad arguments");
+  MP_REQUIRE(kind >= 0 && kind <= 2, "mp_backbone_create: unknown backbone kind %d", kind);
+  MP_REQUIRE(c_in >= 1 && c_in <= 64, "mp_backbone_create: bad c_in %d", c_in);
+  StateMap sm;
+  for (int i = 0; i < n_tensors; ++i) sm[st[i].name] = std::make_pair(st[i].h_data, st[i].numel);
+  mp_backbone* bb = new mp_backbone();
+  bb->kind = kind;
+  bb->wide = kind != MP_BACKBONE_VANILLA_RESNET34;
+  bb->c_in = c_in;
+  bb->c_in_p = (c_in + 3) / 4 * 4;
+  bb->head_kind = head_kind;
+  bb->n_out = n_head_out;
+  bb->n_feat = 512;
+  int rc;
+#define MP_TRY(e) do { rc = (e); if (rc) { mp_backbone_destroy(bb); return rc; } } while (0)
+  const std::string B = "backbone.";
+  if (!bb->wide) {
+    bb->in_border = 3;
+    MP_TRY(make_conv(bb, sm, B + "conv1.weight", B + "bn1", c_in, bb->c_in_p, 64, 7, 2, 3, &bb->stem));
+  } else {
+    bb->in_border = 2;
+    MP_TRY(make_conv(bb, sm, B + "conv1.weight", B + "bn1", c_in, bb->c_in_p, 64, 5, 2, 2, &bb->stem));
+  }
+  static const int n34[4] = {3, 4, 6, 3}, n18[4] = {2, 2, 2, 2};
+  const int* nblocks = (kind == MP_BACKBONE_WIDE_RESNET18) ? n18 : n34;
+  int inplanes = 64;
+  for (int s = 0; s < 4; ++s) {
+    const int planes = kStageC[s];
+    for (int i = 0; i < nblocks[s]; ++i) {
+      Block blk;
+      const int stride = (i == 0 && s > 0) ? 2 : 1;
+      const std::string P = B + "layer" + std::to_string(s + 1) + "." + std::to_string(i) + ".";
+      blk.has_down = (i == 0) && (stride != 1 || inplanes != planes);
+      if (!bb->wide) {
+        MP_TRY(make_conv(bb, sm, P + "conv1.weight", P + "bn1", inplanes, inplanes, planes, 3, stride, 1, &blk.conv1));
+        MP_TRY(make_conv(bb, sm, P + "conv2.weight", P + "bn2", planes, planes, planes, 3, 1, 1, &blk.conv2));
+        if (blk.has_down)
+          MP_TRY(make_conv(bb, sm, P + "downsample.0.weight", P + "downsample.1", inplanes, inplanes, planes, 1, stride, 0, &blk.down));
+      } else {
+        // out = conv2(relu(bn2(conv1(a)))) + residual,  a = relu(bn1(x))   (wide_resnet.py:50-56)
+        MP_TRY(make_bnact(bb, sm, P + "bn1", inplanes, &blk.pre));
+        MP_TRY(make_conv(bb, sm, P + "conv1.weight", P + "bn2", inplanes, inplanes, planes, 3, stride, 1, &blk.conv1));
+        MP_TRY(make_conv(bb, sm, P + "conv2.weight", "", planes, planes, planes, 3, 1, 1, &blk.conv2));
+        if (blk.has_down) MP_TRY(make_conv(bb, sm, P + "downsample.weight", "", inplanes, inplanes, planes, 1, stride, 0, &blk.down));
+      }
+      bb->blocks.push_back(blk);
+      bb->stage_of_block.push_back(s);
+      inplanes = planes;
+    }
+  }
+  if (!bb->wide) {
+    const float* fw = find(sm, B + "fc.weight", 512 * 512);
+    const float* fb = find(sm, B + "fc.bias", 512);
+    if (!fw || !fb) { mp_backbone_destroy(bb); return MP_ERR_INVALID; }
+    MP_TRY(upload(bb, std::vector<float>(fw, fw + 512 * 512), &bb->d_fc_w));
+    MP_TRY(upload(bb, std::vector<float>(fb, fb + 512), &bb->d_fc_b));
+  }
+  const std::string H = head_kind == 0 ? "pose_fc" : "views_logits_head";
+  const float* hw = find(sm, H + ".weight", (int64_t)n_head_out * 512);
+  const float* hb = find(sm, H + ".bias", n_head_out);
+  if (!hw || !hb) { mp_backbone_destroy(bb); return MP_ERR_INVALID; }
+  MP_TRY(upload(bb, std::vector<float>(hw, hw + (size_t)n_head_out * 512), &bb->d_head_w));
+  MP_TRY(upload(bb, std::vector<float>(hb, hb + n_head_out), &bb->d_head_b));
+#undef MP_TRY
+  *out = bb;
+  return MP_OK;
+}
+
+extern "C" int mp_backbone_destroy(mp_backbone* bb) {
+  if (!bb) return MP_OK;
+  for (void* p : bb->allocs) (void)hipFree(p);
+  delete bb;
+  return MP_OK;
+}
+
+extern "C" int mp_backbone_input_channels_padded(const mp_backbone* bb) { return bb ? bb->c_in_p : 0; }
+extern "C" int mp_backbone_input_border(const mp_backbone* bb) { return bb ? bb->in_border : 0; }
+
+// workspace layout: [stem out][per stage: A, A_act (wide only), B, C]
+extern "C" size_t mp_backbone_workspace_bytes(const mp_backbone* bb, int batch, int h, int w) {
+  if (!bb || batch <= 0) return 0;
+  const Geometry g = geometry(bb, h, w);
+  size_t fl = align_up(buf_floats(batch, g.h1, g.w1, 64), 64);
+  const int per_stage = bb->wide ? 4 : 3;
+  for (int s = 0; s < 4; ++s) fl += per_stage * align_up(buf_floats(batch, g.hs[s], g.ws[s], kStageC[s]), 64);
+  return fl * sizeof(float);
+}
+
+extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out, float* d_sigmoid,
+                                   float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  MP_REQUIRE(bb && d_x && d_out && d_ws, "mp_backbone_forward: null pointer");
+  if (batch == 0) return MP_OK;
+  const size_t need = mp_backbone_workspace_bytes(bb, batch, h, w);
+  MP_REQUIRE(ws_bytes >= need, "mp_backbone_forward: workspace %zu < %zu bytes", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  const Geometry g = geometry(bb, h, w);
+  if (bb->ws_ptr != d_ws || bb->ws_batch != batch || bb->ws_h != h || bb->ws_w != w) {
+    MP_CHECK_HIP(hipMemsetAsync(d_ws, 0, need, s));  // zero borders once; interiors are always overwritten
+    bb->ws_ptr = d_ws; bb->ws_batch = batch; bb->ws_h = h; bb->ws_w = w;
+  }
+  float* p = (float*)d_ws;
+  float* S = p; p += align_up(buf_floats(batch, g.h1, g.w1, 64), 64);
+  float *A[4], *Aact[4], *Bf[4], *Cf[4];
+  for (int st = 0; st < 4; ++st) {
+    const size_t n = align_up(buf_floats(batch, g.hs[st], g.ws[st], kStageC[st]), 64);
+    A[st] = p; p += n;
+    Aact[st] = nullptr;
+    if (bb->wide) { Aact[st] = p; p += n; }
+    Bf[st] = p; p += n;
+    Cf[st] = p; p += n;
+  }
+  int rc;
+  // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
+  rc = run_conv(bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s);
+  if (rc) return rc;
+  const Block& b0 = bb->blocks[0];
+  rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, 64, 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
+                       bb->wide ? b0.pre.d_shift : nullptr, s);
+  if (rc) return rc;
+  const int nb = (int)bb->blocks.size();
+  for (int i = 0; i < nb; ++i) {
+    const Block& blk = bb->blocks[i];
+    const int so = bb->stage_of_block[i];                 // output stage
+    const int si = (blk.has_down && so > 0) ? so - 1 : so;  // input stage
+    const int Hi = g.hs[si], Wi = g.ws[si];
+    const bool last = (i + 1 == nb);
+    if (!bb->wide) {
+      // y1 = relu(bn1(conv1(x))); idn = bn(down(x)) | x; out = relu(bn2(conv2(y1)) + idn)
+      rc = run_conv(blk.conv1, A[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
+      if (rc) return rc;
+      const float* idn = A[si];
+      if (blk.has_down) {
+        rc = run_conv(blk.down, A[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
+        if (rc) return rc;
+        idn = Cf[so];
+      }
+      rc = run_conv(blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 1, nullptr, nullptr, s);
+      if (rc) return rc;
+    } else {
+      // a = relu(bn1(x)) was produced upstream into Aact[si]; residual = down(a) | x
+      rc = run_conv(blk.conv1, Aact[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
+      if (rc) return rc;
+      const float* idn = A[si];
+      if (blk.has_down) {
+        rc = run_conv(blk.down, Aact[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
+        if (rc) return rc;
+        idn = Cf[so];
+      }
+      const BnAct* next_pre = last ? nullptr : &bb->blocks[i + 1].pre;
+      rc = run_conv(blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 0, last ? nullptr : Aact[so], next_pre, s);
+      if (rc) return rc;
+    }
+  }
+  return mp_pool_fc_heads(A[3], batch, g.hs[3], g.ws[3], 512, 1, bb->d_fc_w, bb->d_fc_b, 512, bb->d_head_w, bb->d_head_b, bb->n_out,
+                          d_feat, d_out, d_sigmoid, s);
+}
+
+extern "C" double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w) {
+  if (!bb) return 0.0;
+  const Geometry g = geometry(bb, h, w);
+  auto conv_flops = [](const ConvLayer& L, int Ho, int Wo) { return 2.0 * L.Cout * L.Cin * L.K * L.K * (double)Ho * Wo; };
+  double f = conv_flops(bb->stem, g.h1, g.w1);
+  for (size_t i = 0; i < bb->blocks.size(); ++i) {
+    const Block& blk = bb->blocks[i];
+    const int so = bb->stage_of_block[i];
+    f += conv_flops(blk.conv1, g.hs[so], g.ws[so]) + conv_flops(blk.conv2, g.hs[so], g.ws[so]);
+    if (blk.has_down) f += conv_flops(blk.down, g.hs[so], g.ws[so]);
+  }
+  if (!bb->wide) f += 2.0 * 512 * 512;
+  f += 2.0 * 512 * bb->n_out;
+  return f * batch;
+}

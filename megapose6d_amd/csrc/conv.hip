@@ -1,0 +1,313 @@
+// conv.hip -- fp32 implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces the cuDNN convolutions behind `self.backbone(x)`
+// (reference: src/megapose/models/pose_rigid.py:323; layers in
+//  src/megapose/models/torchvision_resnet.py:74-120,181-316 and src/megapose/models/wide_resnet.py:29-111).
+//
+// Formulation ("row-run implicit GEMM"): activations are padded NHWC, so for a fixed kernel row kh the
+// (kw, c) taps of one output pixel are ONE contiguous run of KW*C floats in memory, and the zero border
+// makes bounds checks unnecessary.  GEMM view:  M = N*Ho*Wo output pixels, N = Cout, K = KH * (KW*C).
+// The K loop walks (kh, 32-float chunk of the run); A tiles are gathered row-by-row (128-B contiguous
+// pieces), B tiles come from a pre-packed weight blob laid out in exactly the loop order.  Both are
+// staged through LDS (double-buffered, register prefetch), read back as 16-B fragments, and fed to the
+// 32x32x2 fp32 MFMA, whose k-order within a 8-float group is permuted identically for A and B (free).
+// Epilogue fuses bias (folded eval-BN), residual add, ReLU and an optional second "pre-activated"
+// output relu(y*s+t) for pre-activation (WideResNet) blocks.
+//
+// Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s, MI355X_MICROARCH.md).
+#include "common.h"
+
+namespace mp {
+
+constexpr int BK = 32;        // floats of K per chunk
+constexpr int LDS_LD = BK + 4;  // padded LDS row (36 floats): conflict-free 16-B fragment reads
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+  const float* __restrict__ x;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  const float* __restrict__ residual;
+  const float* __restrict__ act_scale;
+  const float* __restrict__ act_shift;
+  float* __restrict__ y;
+  float* __restrict__ y_act;
+  int M;               // N*Ho*Wo
+  int Ho, Wo;
+  int Hp, Wp, C;       // padded input geometry
+  int in_off;          // in_border - pad
+  int stride;
+  int Cout;
+  int Hop, Wop, out_border;
+  int KH;
+  int chunks_per_row;  // ceil(KW*C / BK)
+  int n_chunks;        // KH * chunks_per_row
+  int relu;
+  int n_mblocks, n_nblocks;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_nhwc_f32_mfma(ConvParams p) {
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
+  constexpr int B_LD4 = BN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                          // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+  int* row_off = (int*)(Bs + 2 * BN * LDS_LD);  // [BM] output element offset of each tile row (-1: none)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / (BN / WN);
+  const int wn = wave % (BN / WN);
+
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int nblk = lb % p.n_nblocks;
+  const int mblk = lb / p.n_nblocks;
+  const int m0 = mblk * BM;
+  const int n0 = nblk * BN;
+
+  // ---- per-thread A row pointers (one output pixel per row) -------------------------------
+  const int a_c4 = tid & 7;   // which float4 of the 32-float chunk
+  const int a_r0 = tid >> 3;  // 0..31
+  const float* a_ptr[A_LD4];
+#pragma unroll
+  for (int i = 0; i < A_LD4; ++i) {
+    int m = m0 + a_r0 + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int wo = m % p.Wo;
+    const int t = m / p.Wo;
+    const int ho = t % p.Ho;
+    const int n = t / p.Ho;
+    const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
+    a_ptr[i] = p.x + pix * p.C + a_c4 * 4;
+  }
+  // output offsets of this tile's rows
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < p.M) {
+      const int wo = m % p.Wo;
+      const int t = m / p.Wo;
+      const int ho = t % p.Ho;
+      const int n = t / p.Ho;
+      off = (((n * p.Hop) + ho + p.out_border) * p.Wop + wo + p.out_border) * p.Cout;
+    }
+    row_off[r] = off;
+  }
+
+  const float* b_ptr = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + tid * 4;
+  const int row_stride = p.Wp * p.C;  // floats between successive kh rows
+
+  float4 a_reg[A_LD4], b_reg[B_LD4];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_chunk = [&](int chunk) {
+    const int kh = chunk / p.chunks_per_row;
+    const int kc = chunk - kh * p.chunks_per_row;
+    const int aoff = kh * row_stride + kc * BK;
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + aoff);
+    const float* bp = b_ptr + (size_t)chunk * (BN * BK);
+#pragma unroll
+    for (int i = 0; i < B_LD4; ++i) b_reg[i] = *reinterpret_cast<const float4*>(bp + i * 1024);
+  };
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * BM * LDS_LD;
+    float* bs = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i)
+      *reinterpret_cast<float4*>(as + (a_r0 + 32 * i) * LDS_LD + a_c4 * 4) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_LD4; ++i) {
+      const int idx = tid + 256 * i;  // float4 index inside the [BN][BK] tile
+      *reinterpret_cast<float4*>(bs + (idx >> 3) * LDS_LD + (idx & 7) * 4) = b_reg[i];
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+  for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+    const int buf = chunk & 1;
+    const bool has_next = chunk + 1 < p.n_chunks;
+    if (has_next) load_chunk(chunk + 1);
+    const float* as = As + buf * BM * LDS_LD + (wm * WM + frag_row) * LDS_LD + frag_k;
+    const float* bs = Bs + buf * BN * LDS_LD + (wn * WN + frag_row) * LDS_LD + frag_k;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (has_next) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 32 + col_l;
+    const bool n_ok = n < p.Cout;
+    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (p.y_act && n_ok) {
+      sc = p.act_scale[n];
+      sh = p.act_shift[n];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        const int off = row_off[row];
+        if (off >= 0 && n_ok) {
+          float v = acc[i][j][r] + bias;
+          if (p.residual) v += p.residual[off + n];
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.y) p.y[off + n] = v;
+          if (p.y_act) p.y_act[off + n] = fmaxf(fmaf(v, sc, sh), 0.f);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch(const ConvParams& p, hipStream_t s) {
+  ConvParams q = p;
+  q.n_mblocks = ceil_div(p.M, BM);
+  q.n_nblocks = ceil_div(p.Cout, BN);
+  const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD) * sizeof(float) + BM * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(q.n_mblocks * q.n_nblocks);
+  hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN>), grid, dim3(256), lds, s, q);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}
+
+// The packed weight blob is tiled for a fixed BN per layer: BN = 64 when Cout == 64, else 128.
+static inline int conv_bn_tile(int Cout) { return Cout <= 64 ? 64 : 128; }
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" size_t mp_conv_packed_floats(int Cin_p, int Cout, int KH, int KW) {
+  const int BN = conv_bn_tile(Cout);
+  const int nblk = ceil_div(Cout, BN);
+  const int cpr = ceil_div((long)KW * Cin_p, BK);
+  return (size_t)nblk * KH * cpr * BN * BK;
+}
+
+extern "C" int mp_conv_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int Cin_p,
+                                    const float* scale, float* packed) {
+  MP_REQUIRE(w && packed && Cin_p >= Cin && (Cin_p % 4) == 0, "mp_conv_pack_weights: bad arguments");
+  const int BN = conv_bn_tile(Cout);
+  const int nblk = ceil_div(Cout, BN);
+  const int run = KW * Cin_p;
+  const int cpr = ceil_div(run, BK);
+  const size_t total = mp_conv_packed_floats(Cin_p, Cout, KH, KW);
+  memset(packed, 0, total * sizeof(float));
+  for (int nb = 0; nb < nblk; ++nb)
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kc = 0; kc < cpr; ++kc) {
+        float* tile = packed + (((size_t)nb * KH + kh) * cpr + kc) * BN * BK;
+        for (int nl = 0; nl < BN; ++nl) {
+          const int n = nb * BN + nl;
+          if (n >= Cout) continue;
+          const float s = scale ? scale[n] : 1.f;
+          for (int k = 0; k < BK; ++k) {
+            const int j = kc * BK + k;
+            if (j >= run) continue;
+            const int kw = j / Cin_p, c = j % Cin_p;
+            if (c >= Cin) continue;
+            tile[nl * BK + k] = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw] * s;
+          }
+        }
+      }
+  return MP_OK;
+}
+
+static int make_params(const mp_conv_desc* d, ConvParams* p) {
+  MP_REQUIRE(d && d->d_x && d->d_w && (d->d_y || d->d_y_act), "mp_conv2d_nhwc: null pointer");
+  MP_REQUIRE(d->C % 4 == 0, "mp_conv2d_nhwc: C (%d) must be a multiple of 4", d->C);
+  MP_REQUIRE(d->in_border >= d->pad, "mp_conv2d_nhwc: in_border %d < pad %d", d->in_border, d->pad);
+  MP_REQUIRE(d->stride >= 1 && d->KH >= 1 && d->KW >= 1 && d->Cout >= 1, "mp_conv2d_nhwc: bad geometry");
+  MP_REQUIRE(!d->d_y_act || (d->d_act_scale && d->d_act_shift), "mp_conv2d_nhwc: y_act needs scale/shift");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  const int Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  const long M = (long)d->N * Ho * Wo;
+  MP_REQUIRE(M > 0 && M < (1L << 31), "mp_conv2d_nhwc: M out of range");
+  const long out_elems = (long)d->N * (Ho + 2 * d->out_border) * (Wo + 2 * d->out_border) * d->Cout;
+  MP_REQUIRE(out_elems < (1L << 31), "mp_conv2d_nhwc: output too large for 32-bit offsets (%ld)", out_elems);
+  p->x = d->d_x;
+  p->w = d->d_w;
+  p->bias = d->d_bias;
+  p->residual = d->d_residual;
+  p->act_scale = d->d_act_scale;
+  p->act_shift = d->d_act_shift;
+  p->y = d->d_y;
+  p->y_act = d->d_y_act;
+  p->M = (int)M;
+  p->Ho = Ho;
+  p->Wo = Wo;
+  p->Hp = d->H + 2 * d->in_border;
+  p->Wp = d->W + 2 * d->in_border;
+  p->C = d->C;
+  p->in_off = d->in_border - d->pad;
+  p->stride = d->stride;
+  p->Cout = d->Cout;
+  p->Hop = Ho + 2 * d->out_border;
+  p->Wop = Wo + 2 * d->out_border;
+  p->out_border = d->out_border;
+  p->KH = d->KH;
+  p->chunks_per_row = ceil_div((long)d->KW * d->C, BK);
+  p->n_chunks = d->KH * p->chunks_per_row;
+  p->relu = d->relu;
+  return MP_OK;
+}
+
+extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
+  ConvParams p;
+  int rc = make_params(d, &p);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (conv_bn_tile(d->Cout) == 64) return launch<128, 64, 64, 32>(p, s);
+  return launch<128, 128, 64, 64>(p, s);
+}
+
+extern "C" const char* mp_conv2d_kernel_name(const mp_conv_desc* d) {
+  return conv_bn_tile(d->Cout) == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>";
+}

@@ -1,0 +1,441 @@
+// raster.hip -- on-device triangle rasteriser for gfx950 (replaces the Panda3D/OpenGL render loop).
+//
+// Reference contract: Panda3dBatchRenderer.render
+//   (/root/reference/src/megapose/panda3d_renderer/panda3d_batch_renderer.py:217-282, worker_loop :89-150,
+//    Panda3dSceneRenderer.render_scene panda3d_scene_renderer.py:298-358, camera model types.py:75-101,
+//    eye-normal LUT utils.py:58-68 + panda3d_scene_renderer.py:210-216, depth utils.py:44-55,
+//    lights panda3d_scene_renderer.py:104-136).
+//
+// Pixel contract (identical, operation for operation, to oracle/raster.c -- see DESIGN.md "Rasteriser"):
+//   * camera-space vertex  Pc = R p + t  as an fmaf chain; screen  sx = fmaf(fx, x/z.., cx)
+//   * screen coords snapped to 1/256 px fixed point; coverage by exact int64 edge functions sampled at
+//     pixel centres (x+.5, y+.5) with the top-left fill rule; two-sided (no back-face culling)
+//   * depth test on wsum = sum b_i/z_i (perspective-correct 1/z), nearest wins, ties -> lowest triangle id;
+//     fragments outside [near, far] = [0.1, 10] m are discarded
+//   * attributes interpolated perspective-correctly; RGB = albedo * light; normals through the 32^3 LUT
+//     (separable, linear filter, repeat wrap); uint8 quantisation then /255.
+//
+// Structure: (1) raster_transform: one thread per (view, vertex) -> {X, Y (fixed point), 1/z, valid}
+//            (2) raster_bands: one workgroup per (view, band of BAND_H rows): 64-bit {depth,tri} z-buffer in
+//                LDS, triangle-parallel scan with LDS atomicMin, block-cooperative path for large triangles,
+//                then a pixel-parallel resolve/shade that writes straight into the CNN input tensor slice.
+// Roofline: HBM-bound on the output writes ((3+3[+1])*4*h*w bytes per view).
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace mp {
+
+constexpr int SUBPIX = 256;
+constexpr float GUARD = 16384.f;  // |screen coord| limit (pixels) for the fixed-point path
+constexpr float Z_EPS = 1e-6f;
+constexpr float Z_NEAR = 0.1f, Z_FAR = 10.0f;
+constexpr int BAND_H = 30;
+constexpr int BAND_THREADS = 512;
+constexpr int BIG_TRI_AREA = 512;   // clipped-bbox pixels above which a triangle is rasterised by the whole block
+constexpr int BIG_QUEUE = 2048;
+
+struct MeshDev {
+  const float* verts;
+  const float* normals;
+  const float* colors;
+  const int32_t* faces;
+  int n_verts, n_faces;
+  float radius;
+  float center[3];
+};
+
+struct VtxRec {
+  int X, Y;     // fixed-point screen coordinates (1/256 px)
+  float invz;   // 1 / camera z
+  int valid;
+};
+
+struct LightsDev {
+  float ambient[3];
+  int n_point;
+  float dir[8][3];
+  float color[8][3];
+};
+
+__device__ __forceinline__ float dot3p(float a0, float a1, float a2, float x, float y, float z, float t) {
+  return fmaf(a2, z, fmaf(a1, y, fmaf(a0, x, t)));
+}
+
+__device__ __forceinline__ bool view_finite(const float* T, const float* K) {
+  bool ok = true;
+  for (int i = 0; i < 16; ++i) ok = ok && isfinite(T[i]);
+  for (int i = 0; i < 9; ++i) ok = ok && isfinite(K[i]);
+  return ok;
+}
+
+__global__ void raster_transform(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
+                                 const float* __restrict__ TCO, const float* __restrict__ K, int max_verts,
+                                 VtxRec* __restrict__ out) {
+  const int view = blockIdx.y;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const MeshDev m = meshes[mesh_ids[view]];
+  if (v >= m.n_verts) return;
+  const float* T = TCO + (size_t)view * 16;
+  const float* Kv = K + (size_t)view * 9;
+  VtxRec rec;
+  rec.X = 0; rec.Y = 0; rec.invz = 0.f; rec.valid = 0;
+  if (view_finite(T, Kv)) {
+    const float px = m.verts[3 * v + 0], py = m.verts[3 * v + 1], pz = m.verts[3 * v + 2];
+    const float x = dot3p(T[0], T[1], T[2], px, py, pz, T[3]);
+    const float y = dot3p(T[4], T[5], T[6], px, py, pz, T[7]);
+    const float z = dot3p(T[8], T[9], T[10], px, py, pz, T[11]);
+    if (z > Z_EPS) {
+      const float iz = 1.0f / z;
+      const float sx = fmaf(Kv[0], x * iz, Kv[2]);
+      const float sy = fmaf(Kv[4], y * iz, Kv[5]);
+      if (fabsf(sx) < GUARD && fabsf(sy) < GUARD) {
+        rec.X = (int)rintf(sx * (float)SUBPIX);
+        rec.Y = (int)rintf(sy * (float)SUBPIX);
+        rec.invz = iz;
+        rec.valid = 1;
+      }
+    }
+  }
+  out[(size_t)view * max_verts + v] = rec;
+}
+
+struct TriSetup {
+  long long A0, B0, C0, A1, B1, C1, A2, B2, C2;  // E_i(sx,sy) = A_i*sx + B_i*sy + C_i (fixed-point sample coords, exact)
+  int t0, t1, t2;                                // fill-rule thresholds: sample is inside iff E_i >= t_i (0 or 1)
+  double inv_area;
+  float iz0, iz1, iz2;
+  int xmin, xmax, ymin, ymax;  // pixel bbox (inclusive), clipped to the band
+  bool ok;
+};
+
+// Edge a->b: E(p) = (bx-ax)*(py-ay) - (by-ay)*(px-ax).  With y pointing down and a positively oriented
+// triangle the interior is E >= 0; an edge is "left" if it goes up (dy < 0) and "top" if dy == 0 && dx > 0.
+// Top-left edges own their boundary samples (threshold 0); the others exclude E == 0 (threshold 1).
+__device__ __forceinline__ void edge_setup(int ax, int ay, int bx, int by, long long& A, long long& B, long long& C, int& thr) {
+  const long long dx = (long long)bx - ax, dy = (long long)by - ay;
+  A = -dy;
+  B = dx;
+  C = dy * ax - dx * ay;
+  thr = ((dy < 0) || (dy == 0 && dx > 0)) ? 0 : 1;
+}
+
+// v1/v2 (and i1/i2) are swapped in place when the screen-space orientation is negative (two-sided rendering).
+__device__ __forceinline__ TriSetup tri_setup(const VtxRec& v0, VtxRec& v1, VtxRec& v2, int& i1, int& i2, int w, int y_lo,
+                                              int y_hi) {
+  TriSetup s;
+  s.ok = false;
+  if (!(v0.valid && v1.valid && v2.valid)) return s;
+  long long area = ((long long)v1.X - v0.X) * ((long long)v2.Y - v0.Y) - ((long long)v1.Y - v0.Y) * ((long long)v2.X - v0.X);
+  if (area == 0) return s;
+  if (area < 0) {
+    const VtxRec t = v1; v1 = v2; v2 = t;
+    const int ti = i1; i1 = i2; i2 = ti;
+    area = -area;
+  }
+  const int Xmin = min(v0.X, min(v1.X, v2.X)), Xmax = max(v0.X, max(v1.X, v2.X));
+  const int Ymin = min(v0.Y, min(v1.Y, v2.Y)), Ymax = max(v0.Y, max(v1.Y, v2.Y));
+  // samples sit at x*256+128: ceil((Xmin-128)/256) .. floor((Xmax-128)/256)
+  s.xmin = max(0, (Xmin - 128 + 255) >> 8);
+  s.xmax = min(w - 1, (Xmax - 128) >> 8);
+  s.ymin = max(y_lo, (Ymin - 128 + 255) >> 8);
+  s.ymax = min(y_hi, (Ymax - 128) >> 8);
+  if (s.xmin > s.xmax || s.ymin > s.ymax) return s;
+  edge_setup(v1.X, v1.Y, v2.X, v2.Y, s.A0, s.B0, s.C0, s.t0);  // edge opposite vertex 0
+  edge_setup(v2.X, v2.Y, v0.X, v0.Y, s.A1, s.B1, s.C1, s.t1);
+  edge_setup(v0.X, v0.Y, v1.X, v1.Y, s.A2, s.B2, s.C2, s.t2);
+  s.inv_area = 1.0 / (double)area;
+  s.iz0 = v0.invz;
+  s.iz1 = v1.invz;
+  s.iz2 = v2.invz;
+  s.ok = true;
+  return s;
+}
+
+__device__ __forceinline__ bool sample_tri(const TriSetup& s, int px, int py, float& b0, float& b1, float& b2, float& wsum) {
+  const long long sx = (long long)px * SUBPIX + 128, sy = (long long)py * SUBPIX + 128;
+  const long long e0 = s.A0 * sx + s.B0 * sy + s.C0;
+  const long long e1 = s.A1 * sx + s.B1 * sy + s.C1;
+  const long long e2 = s.A2 * sx + s.B2 * sy + s.C2;
+  if (e0 < s.t0 || e1 < s.t1 || e2 < s.t2) return false;
+  b0 = (float)((double)e0 * s.inv_area);
+  b1 = (float)((double)e1 * s.inv_area);
+  b2 = (float)((double)e2 * s.inv_area);
+  wsum = fmaf(b2, s.iz2, fmaf(b1, s.iz1, b0 * s.iz0));
+  return true;
+}
+
+__device__ __forceinline__ void raster_pixel(const TriSetup& s, int px, int py, int tri, int band_y0, int w,
+                                             unsigned long long* zbuf) {
+  float b0, b1, b2, wsum;
+  if (!sample_tri(s, px, py, b0, b1, b2, wsum)) return;
+  if (!(wsum >= 1.0f / Z_FAR && wsum <= 1.0f / Z_NEAR)) return;
+  const unsigned long long key = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(wsum)) << 32) | (unsigned)tri;
+  atomicMin(&zbuf[(py - band_y0) * w + px], key);
+}
+
+__device__ __forceinline__ float lut_val(int i) { return (float)((i * 255) >> 5); }  // floor(i*255/32), utils.py:65
+
+// Eye-normal LUT lookup: 32-texel separable ramp, GL_LINEAR filter, repeat wrap; returns the value on the 0..255 scale
+__device__ __forceinline__ float normal_lut(float n) {
+  const float u = n - floorf(n);
+  const float t = fmaf(u, 32.0f, -0.5f);
+  const float fl = floorf(t);
+  const float f = t - fl;
+  const int i0 = ((int)fl + 32) & 31;
+  const int i1 = (i0 + 1) & 31;
+  const float a = lut_val(i0), b = lut_val(i1);
+  return fmaf(b - a, f, a);
+}
+
+__device__ __forceinline__ float quant8(float v255) {
+  const float q = floorf(fminf(fmaxf(v255, 0.f), 255.f) + 0.5f);
+  return q / 255.0f;
+}
+
+template <bool kUnused = false>
+__global__ __launch_bounds__(BAND_THREADS) void raster_bands(
+    const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
+    const VtxRec* __restrict__ vtx, int max_verts, int h, int w, uint32_t flags, LightsDev lights,
+    float* __restrict__ out, long long stride_v, long long stride_y, long long stride_x, int c_rgb, int c_normals,
+    int c_depth) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];  // [BAND_H*w] + big-triangle queue
+  int* big_queue = (int*)(zbuf + (size_t)BAND_H * w);
+  __shared__ int big_count;
+
+  const int view = blockIdx.y;
+  const int band = blockIdx.x;
+  const int y0 = band * BAND_H;
+  const int y1 = min(h, y0 + BAND_H) - 1;
+  const int npix = (y1 - y0 + 1) * w;
+  const MeshDev m = meshes[mesh_ids[view]];
+  const VtxRec* vv = vtx + (size_t)view * max_verts;
+
+  for (int i = threadIdx.x; i < npix; i += BAND_THREADS) zbuf[i] = ~0ull;
+  if (threadIdx.x == 0) big_count = 0;
+  __syncthreads();
+
+  // ---- pass 1: triangle-parallel coverage + depth ------------------------------------------------
+  for (int t = threadIdx.x; t < m.n_faces; t += BAND_THREADS) {
+    int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
+    const VtxRec v0 = vv[i0];
+    VtxRec v1 = vv[i1], v2 = vv[i2];
+    const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
+    if (!s.ok) continue;
+    const int area = (s.xmax - s.xmin + 1) * (s.ymax - s.ymin + 1);
+    if (area > BIG_TRI_AREA) {
+      const int slot = atomicAdd(&big_count, 1);
+      if (slot < BIG_QUEUE) {
+        big_queue[slot] = t;
+        continue;
+      }
+    }
+    for (int py = s.ymin; py <= s.ymax; ++py)
+      for (int px = s.xmin; px <= s.xmax; ++px) raster_pixel(s, px, py, t, y0, w, zbuf);
+  }
+  __syncthreads();
+  // ---- pass 1b: large triangles, whole block per triangle ----------------------------------------
+  const int nbig = min(big_count, BIG_QUEUE);
+  for (int q = 0; q < nbig; ++q) {
+    const int t = big_queue[q];
+    int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
+    const VtxRec v0 = vv[i0];
+    VtxRec v1 = vv[i1], v2 = vv[i2];
+    const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
+    const int bw = s.xmax - s.xmin + 1, bh = s.ymax - s.ymin + 1;
+    for (int i = threadIdx.x; i < bw * bh; i += BAND_THREADS)
+      raster_pixel(s, s.xmin + i % bw, s.ymin + i / bw, t, y0, w, zbuf);
+  }
+  __syncthreads();
+
+  // ---- pass 2: resolve + shade, pixel-parallel ----------------------------------------------------
+  const float* T = TCO + (size_t)view * 16;
+  const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0;
+  const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
+  const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
+  const bool no_quant = flags & MP_RASTER_NO_QUANT;
+  float* out_v = out + (size_t)view * stride_v;
+  for (int i = threadIdx.x; i < npix; i += BAND_THREADS) {
+    const int py = y0 + i / w, px = i % w;
+    float* o = out_v + (size_t)py * stride_y + (size_t)px * stride_x;
+    const unsigned long long key = zbuf[i];
+    float r = 0.f, g = 0.f, b = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, depth = 0.f;
+    if (key != ~0ull) {
+      const int t = (int)(key & 0xFFFFFFFFu);
+      int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
+      const VtxRec v0 = vv[i0];
+      VtxRec v1 = vv[i1], v2 = vv[i2];
+      const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, py, py);
+      float b0, b1, b2, wsum;
+      (void)sample_tri(s, px, py, b0, b1, b2, wsum);
+      const float w0 = b0 * s.iz0, w1 = b1 * s.iz1, w2 = b2 * s.iz2;
+      const float z = 1.0f / wsum;
+      depth = z;
+      const float* c0 = m.colors + 3 * i0; const float* c1 = m.colors + 3 * i1; const float* c2 = m.colors + 3 * i2;
+      float ar = fmaf(w2, c2[0], fmaf(w1, c1[0], w0 * c0[0])) * z;
+      float ag = fmaf(w2, c2[1], fmaf(w1, c1[1], w0 * c0[1])) * z;
+      float ab = fmaf(w2, c2[2], fmaf(w1, c1[2], w0 * c0[2])) * z;
+      const float* n0 = m.normals + 3 * i0; const float* n1 = m.normals + 3 * i1; const float* n2 = m.normals + 3 * i2;
+      // interpolated object-frame normal (perspective-correct, NOT renormalised: texcoord semantics)
+      const float onx = fmaf(w2, n2[0], fmaf(w1, n1[0], w0 * n0[0])) * z;
+      const float ony = fmaf(w2, n2[1], fmaf(w1, n1[1], w0 * n0[1])) * z;
+      const float onz = fmaf(w2, n2[2], fmaf(w1, n1[2], w0 * n0[2])) * z;
+      float lr = lights.ambient[0], lg = lights.ambient[1], lb = lights.ambient[2];
+      if (lights.n_point > 0) {
+        const float* p0 = m.verts + 3 * i0; const float* p1 = m.verts + 3 * i1; const float* p2 = m.verts + 3 * i2;
+        const float ox = fmaf(w2, p2[0], fmaf(w1, p1[0], w0 * p0[0])) * z;
+        const float oy = fmaf(w2, p2[1], fmaf(w1, p1[1], w0 * p0[1])) * z;
+        const float oz = fmaf(w2, p2[2], fmaf(w1, p1[2], w0 * p0[2])) * z;
+        const float nn = sqrtf(fmaf(onz, onz, fmaf(ony, ony, onx * onx)));
+        const float inn = nn > 0.f ? 1.0f / nn : 0.f;
+        const float R10 = 10.0f * m.radius;
+        for (int l = 0; l < lights.n_point; ++l) {
+          const float lx = fmaf(lights.dir[l][0], R10, -ox);
+          const float ly = fmaf(lights.dir[l][1], R10, -oy);
+          const float lz = fmaf(lights.dir[l][2], R10, -oz);
+          const float ln = sqrtf(fmaf(lz, lz, fmaf(ly, ly, lx * lx)));
+          const float d = fmaf(lz, onz, fmaf(ly, ony, lx * onx)) * inn / ln;
+          const float dd = fmaxf(d, 0.f);
+          lr = fmaf(lights.color[l][0], dd, lr);
+          lg = fmaf(lights.color[l][1], dd, lg);
+          lb = fmaf(lights.color[l][2], dd, lb);
+        }
+      }
+      ar *= lr; ag *= lg; ab *= lb;
+      if (no_quant) { r = ar; g = ag; b = ab; }
+      else { r = quant8(ar * 255.0f); g = quant8(ag * 255.0f); b = quant8(ab * 255.0f); }
+      if (do_norm) {
+        // eye-space normal: camera (OpenCV) frame first, then the eye-axis convention
+        const float cx = fmaf(T[2], onz, fmaf(T[1], ony, T[0] * onx));
+        const float cy = fmaf(T[6], onz, fmaf(T[5], ony, T[4] * onx));
+        const float cz = fmaf(T[10], onz, fmaf(T[9], ony, T[8] * onx));
+        float ex, ey, ez;
+        if (gl_eye) { ex = cx; ey = -cy; ez = -cz; }   // GL eye: x right, y up, z back
+        else { ex = cx; ey = cz; ez = -cy; }           // Panda view: x right, y forward, z up (TCCGL, types.py:40)
+        if (no_quant) { nx = normal_lut(ex) / 255.0f; ny = normal_lut(ey) / 255.0f; nz = normal_lut(ez) / 255.0f; }
+        else { nx = quant8(normal_lut(ex)); ny = quant8(normal_lut(ey)); nz = quant8(normal_lut(ez)); }
+      }
+    }
+    if (c_rgb >= 0) { o[c_rgb] = r; o[c_rgb + 1] = g; o[c_rgb + 2] = b; }
+    if (do_norm) { o[c_normals] = nx; o[c_normals + 1] = ny; o[c_normals + 2] = nz; }
+    if (do_depth) o[c_depth] = depth;
+  }
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+struct mp_mesh_db {
+  int n;
+  int max_verts, max_faces;
+  MeshDev* d_meshes;
+  std::vector<MeshDev> h_meshes;
+  std::vector<void*> allocs;
+};
+
+extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out) {
+  MP_REQUIRE(hm && out && n > 0, "mp_mesh_db_create: bad arguments");
+  mp_mesh_db* db = new mp_mesh_db();
+  db->n = n;
+  db->max_verts = db->max_faces = 0;
+  db->d_meshes = nullptr;
+  for (int i = 0; i < n; ++i) {
+    const mp_mesh_desc& d = hm[i];
+    MP_REQUIRE(d.h_vertices && d.h_normals && d.h_colors && d.h_faces && d.n_vertices > 0 && d.n_faces > 0,
+               "mp_mesh_db_create: mesh %d incomplete", i);
+    for (int f = 0; f < 3 * d.n_faces; ++f)
+      MP_REQUIRE(d.h_faces[f] >= 0 && d.h_faces[f] < d.n_vertices, "mp_mesh_db_create: mesh %d face index out of range", i);
+    MeshDev m;
+    float *dv, *dn, *dc;
+    int32_t* df;
+    const size_t vb = (size_t)d.n_vertices * 3 * sizeof(float);
+    MP_CHECK_HIP(hipMalloc(&dv, vb));
+    MP_CHECK_HIP(hipMalloc(&dn, vb));
+    MP_CHECK_HIP(hipMalloc(&dc, vb));
+    MP_CHECK_HIP(hipMalloc(&df, (size_t)d.n_faces * 3 * sizeof(int32_t)));
+    MP_CHECK_HIP(hipMemcpy(dv, d.h_vertices, vb, hipMemcpyHostToDevice));
+    MP_CHECK_HIP(hipMemcpy(dn, d.h_normals, vb, hipMemcpyHostToDevice));
+    MP_CHECK_HIP(hipMemcpy(dc, d.h_colors, vb, hipMemcpyHostToDevice));
+    MP_CHECK_HIP(hipMemcpy(df, d.h_faces, (size_t)d.n_faces * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+    db->allocs.push_back(dv); db->allocs.push_back(dn); db->allocs.push_back(dc); db->allocs.push_back(df);
+    m.verts = dv; m.normals = dn; m.colors = dc; m.faces = df;
+    m.n_verts = d.n_vertices; m.n_faces = d.n_faces;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int v = 0; v < d.n_vertices; ++v)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(lo[k], d.h_vertices[3 * v + k]);
+        hi[k] = fmaxf(hi[k], d.h_vertices[3 * v + k]);
+      }
+    for (int k = 0; k < 3; ++k) m.center[k] = 0.5f * (lo[k] + hi[k]);
+    float r2 = 0.f;
+    for (int v = 0; v < d.n_vertices; ++v) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) {
+        const float dd = d.h_vertices[3 * v + k] - m.center[k];
+        s += dd * dd;
+      }
+      r2 = fmaxf(r2, s);
+    }
+    m.radius = sqrtf(r2);
+    db->h_meshes.push_back(m);
+    db->max_verts = std::max(db->max_verts, d.n_vertices);
+    db->max_faces = std::max(db->max_faces, d.n_faces);
+  }
+  MP_CHECK_HIP(hipMalloc(&db->d_meshes, n * sizeof(MeshDev)));
+  MP_CHECK_HIP(hipMemcpy(db->d_meshes, db->h_meshes.data(), n * sizeof(MeshDev), hipMemcpyHostToDevice));
+  *out = db;
+  return MP_OK;
+}
+
+extern "C" int mp_mesh_db_destroy(mp_mesh_db* db) {
+  if (!db) return MP_OK;
+  for (void* p : db->allocs) (void)hipFree(p);
+  if (db->d_meshes) (void)hipFree(db->d_meshes);
+  delete db;
+  return MP_OK;
+}
+
+extern "C" int mp_mesh_db_max_vertices(const mp_mesh_db* db) { return db ? db->max_verts : 0; }
+extern "C" float mp_mesh_db_radius(const mp_mesh_db* db, int i) {
+  return (db && i >= 0 && i < db->n) ? db->h_meshes[i].radius : 0.f;
+}
+
+extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views) {
+  return db ? (size_t)n_views * db->max_verts * sizeof(VtxRec) : 0;
+}
+
+extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
+                                int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
+                                int64_t stride_v, int64_t stride_y, int64_t stride_x, int c_rgb, int c_normals, int c_depth,
+                                void* d_ws, size_t ws_bytes, mp_stream stream) {
+  MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
+  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024, "mp_raster_render: bad size");
+  MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
+  if (n_views == 0) return MP_OK;
+  MP_REQUIRE(ws_bytes >= mp_raster_workspace_bytes(db, n_views), "mp_raster_render: workspace too small");
+  MP_REQUIRE(n_views <= 65535, "mp_raster_render: at most 65535 views per call");
+  hipStream_t s = (hipStream_t)stream;
+  LightsDev L;
+  memcpy(L.ambient, lights->ambient, sizeof(L.ambient));
+  L.n_point = lights->n_point;
+  memcpy(L.dir, lights->point_dir, sizeof(L.dir));
+  memcpy(L.color, lights->point_color, sizeof(L.color));
+  VtxRec* vtx = (VtxRec*)d_ws;
+  dim3 g1(ceil_div(db->max_verts, 256), n_views);
+  hipLaunchKernelGGL(raster_transform, g1, dim3(256), 0, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, db->max_verts, vtx);
+  const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + BIG_QUEUE * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bands<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    attr_set = true;
+  }
+  MP_REQUIRE(lds <= 160 * 1024 - 64, "mp_raster_render: image too wide for the LDS z-buffer");
+  dim3 g2(ceil_div(h, BAND_H), n_views);
+  hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, vtx, db->max_verts,
+                     h, w, flags, L, d_out, (long long)stride_v, (long long)stride_y, (long long)stride_x, c_rgb, c_normals,
+                     c_depth);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}

@@ -1,0 +1,302 @@
+"""Thin torch-tensor front-end over the C-ABI (include/mp_engine.h).
+
+PyTorch is used for device memory and streams only; every computation below is a
+call into libmp_engine.so.  All functions enqueue on torch's current HIP stream and
+never synchronise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, EngineError, Lights, MeshDesc, NamedTensor, check
+
+RASTER_NORMALS = 1
+RASTER_DEPTH = 2
+RASTER_NORMALS_GL = 4
+RASTER_NO_QUANT = 8
+
+BACKBONE_KINDS = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise EngineError("engine tensors must live on the GPU")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+def _dev_i32(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise EngineError("engine tensors must live on the GPU")
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        t = t.to(torch.int32).contiguous()
+    return t
+
+
+def device_info() -> Tuple[int, int, str]:
+    lib = _lib.load()
+    n_cu, lds = C.c_int(0), C.c_int(0)
+    name = C.create_string_buffer(64)
+    check(lib.mp_device_info(C.byref(n_cu), C.byref(lds), name, 64))
+    return n_cu.value, lds.value, name.value.decode()
+
+
+# --------------------------------------------------------------------------- #
+class MeshDB:
+    """Device-resident meshes (mp_mesh_db).  `meshes`: list of dicts with float32 arrays
+    vertices [V,3] (metres), normals [V,3], colors [V,3] in [0,1], int32 faces [T,3]."""
+
+    def __init__(self, meshes: Sequence[Dict[str, np.ndarray]]):
+        lib = _lib.load()
+        self._keep = []
+        descs = (MeshDesc * len(meshes))()
+        for i, m in enumerate(meshes):
+            v = np.ascontiguousarray(m["vertices"], dtype=np.float32)
+            n = np.ascontiguousarray(m["normals"], dtype=np.float32)
+            c = np.ascontiguousarray(m["colors"], dtype=np.float32)
+            f = np.ascontiguousarray(m["faces"], dtype=np.int32)
+            assert v.shape == n.shape == c.shape and v.shape[1] == 3 and f.shape[1] == 3
+            self._keep += [v, n, c, f]
+            descs[i] = MeshDesc(v.ctypes.data, n.ctypes.data, c.ctypes.data, f.ctypes.data, v.shape[0], f.shape[0])
+        h = C.c_void_p()
+        check(lib.mp_mesh_db_create(descs, len(meshes), C.byref(h)))
+        self.handle = h
+        self.n = len(meshes)
+        self.max_vertices = lib.mp_mesh_db_max_vertices(h)
+        self._keep = []
+        self._ws: Optional[torch.Tensor] = None
+
+    def radius(self, i: int) -> float:
+        return _lib.load().mp_mesh_db_radius(self.handle, i)
+
+    def workspace(self, n_views: int, device) -> torch.Tensor:
+        need = _lib.load().mp_raster_workspace_bytes(self.handle, n_views)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(device):
+            self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().mp_mesh_db_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()) -> Lights:
+    L = Lights()
+    L.ambient[:] = ambient
+    L.n_point = len(point_dirs)
+    for i, (d, c) in enumerate(zip(point_dirs, point_colors)):
+        L.point_dir[i][:] = d
+        L.point_color[i][:] = c
+    return L
+
+
+def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, h: int, w: int, flags: int,
+                  lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
+                  c_depth: int, out_offset_floats: int = 0) -> None:
+    """Render n views into `out` (float32 device tensor) at the given element strides."""
+    lib = _lib.load()
+    n = int(TCO.shape[0])
+    mesh_ids = _dev_i32(mesh_ids)
+    TCO = _dev_f32(TCO)
+    K = _dev_f32(K)
+    assert out.dtype == torch.float32 and out.is_cuda
+    ws = db.workspace(n, out.device)
+    check(lib.mp_raster_render(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
+                               out.data_ptr() + 4 * out_offset_floats, stride_v, stride_y, stride_x, c_rgb, c_normals, c_depth,
+                               ws.data_ptr(), ws.numel(), _stream()))
+
+
+def crop_roi_align(images: torch.Tensor, im_ids: torch.Tensor, boxes: torch.Tensor, out_h: int, out_w: int, out: torch.Tensor,
+                   stride_b: int, stride_y: int, stride_x: int, c0: int, out_offset_floats: int = 0) -> None:
+    lib = _lib.load()
+    images = _dev_f32(images)
+    n_im, Cc, H, W = images.shape
+    check(lib.mp_crop_roi_align(images.data_ptr(), n_im, Cc, H, W, _dev_i32(im_ids).data_ptr(), _dev_f32(boxes).data_ptr(),
+                                int(boxes.shape[0]), out_h, out_w, out.data_ptr() + 4 * out_offset_floats, stride_b, stride_y,
+                                stride_x, c0, _stream()))
+
+
+def normalize_depth(x: torch.Tensor, b: int, h: int, w: int, border: int, Cp: int, channels: Sequence[int], tCR: torch.Tensor,
+                    mode: int) -> None:
+    lib = _lib.load()
+    ch = (C.c_int32 * len(channels))(*channels)
+    check(lib.mp_normalize_depth(x.data_ptr(), b, h, w, border, Cp, ch, len(channels), _dev_f32(tCR).data_ptr(), mode, _stream()))
+
+
+DEPTH_NORM_MODES = {None: 0, "none": 0, "tCR_scale": 1, "tCR_scale_clamp_center": 2, "tCR_center_clamp": 3}
+
+
+# --------------------------------------------------------------------------- #
+def padded_nhwc(n: int, h: int, w: int, c: int, border: int, device, slack: int = 64) -> torch.Tensor:
+    """Zero-initialised flat buffer holding a padded-NHWC tensor (+ read slack for the conv's chunked loads)."""
+    return torch.zeros(n * (h + 2 * border) * (w + 2 * border) * c + slack, dtype=torch.float32, device=device)
+
+
+def padded_view(buf: torch.Tensor, n: int, h: int, w: int, c: int, border: int) -> torch.Tensor:
+    """[n, h, w, c] view of the interior of a padded-NHWC buffer."""
+    full = buf[: n * (h + 2 * border) * (w + 2 * border) * c].view(n, h + 2 * border, w + 2 * border, c)
+    return full[:, border : border + h, border : border + w, :]
+
+
+def conv_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin, KH, KW = w.shape
+    n = lib.mp_conv_packed_floats(cin_p, Cout, KH, KW)
+    out = np.empty(n, dtype=np.float32)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    check(lib.mp_conv_pack_weights(w.ctypes.data, Cout, Cin, KH, KW, cin_p, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int, w_packed: torch.Tensor,
+                bias: Optional[torch.Tensor], Cout: int, K: int, stride: int, pad: int, y: Optional[torch.Tensor], out_border: int,
+                residual: Optional[torch.Tensor] = None, relu: bool = False, y_act: Optional[torch.Tensor] = None,
+                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None) -> None:
+    lib = _lib.load()
+    d = ConvDesc()
+    d.d_x, d.N, d.H, d.W, d.C, d.in_border = x.data_ptr(), N, H, W, Cp, in_border
+    d.d_w, d.d_bias = w_packed.data_ptr(), _ptr(bias)
+    d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, stride, pad
+    d.d_y, d.out_border, d.d_residual, d.relu = _ptr(y), out_border, _ptr(residual), int(relu)
+    d.d_y_act, d.d_act_scale, d.d_act_shift = _ptr(y_act), _ptr(act_scale), _ptr(act_shift)
+    check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
+
+
+def maxpool3x3s2(x, N, H, W, Cc, in_border, y, out_border, y_act=None, sc=None, sh=None) -> None:
+    check(_lib.load().mp_maxpool3x3s2(x.data_ptr(), N, H, W, Cc, in_border, _ptr(y), out_border, _ptr(y_act), _ptr(sc), _ptr(sh),
+                                      _stream()))
+
+
+def pool_fc_heads(x, N, H, W, Cc, in_border, fc_w, fc_b, n_feat, head_w, head_b, n_out, feat, out, sigmoid) -> None:
+    check(_lib.load().mp_pool_fc_heads(x.data_ptr(), N, H, W, Cc, in_border, _ptr(fc_w), _ptr(fc_b), n_feat, head_w.data_ptr(),
+                                       head_b.data_ptr(), n_out, _ptr(feat), out.data_ptr(), _ptr(sigmoid), _stream()))
+
+
+class Backbone:
+    """mp_backbone: whole CNN + head resident on the device, one call per forward."""
+
+    def __init__(self, kind: str, c_in: int, head: str, n_out: int, state_dict: Dict[str, torch.Tensor]):
+        lib = _lib.load()
+        if kind not in BACKBONE_KINDS:
+            raise EngineError(f"unknown backbone '{kind}' (pose_models_cfg.py:106-118 supports {list(BACKBONE_KINDS)})")
+        keep = []
+        items = []
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            a = np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32)
+            keep.append(a)
+            items.append((k.encode(), a))
+        arr = (NamedTensor * len(items))()
+        for i, (k, a) in enumerate(items):
+            arr[i] = NamedTensor(k, a.ctypes.data, a.size)
+        h = C.c_void_p()
+        check(lib.mp_backbone_create(BACKBONE_KINDS[kind], c_in, 0 if head == "pose" else 1, n_out, arr, len(items), C.byref(h)))
+        self.handle = h
+        self.kind, self.c_in, self.n_out = kind, c_in, n_out
+        self.c_in_p = lib.mp_backbone_input_channels_padded(h)
+        self.in_border = lib.mp_backbone_input_border(h)
+        self._ws: Optional[torch.Tensor] = None
+
+    def workspace(self, batch: int, h: int, w: int, device) -> torch.Tensor:
+        need = _lib.load().mp_backbone_workspace_bytes(self.handle, batch, h, w)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(device):
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def flops(self, batch: int, h: int, w: int) -> float:
+        return _lib.load().mp_backbone_flops(self.handle, batch, h, w)
+
+    def forward(self, x: torch.Tensor, batch: int, h: int, w: int, out: torch.Tensor, sigmoid: Optional[torch.Tensor] = None,
+                feat: Optional[torch.Tensor] = None) -> None:
+        ws = self.workspace(batch, h, w, x.device)
+        check(_lib.load().mp_backbone_forward(self.handle, x.data_ptr(), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat),
+                                              ws.data_ptr(), ws.numel(), _stream()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().mp_backbone_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------- #
+def normalize_T(T: torch.Tensor) -> torch.Tensor:
+    T = _dev_f32(T)
+    out = torch.empty_like(T)
+    check(_lib.load().mp_normalize_T(T.data_ptr(), T.shape[0], out.data_ptr(), _stream()))
+    return out
+
+
+def init_extents(points: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
+    points, R = _dev_f32(points), _dev_f32(R)
+    n_mesh, n_pts, _ = points.shape
+    ext = torch.empty(n_mesh, R.shape[0], 2, dtype=torch.float32, device=points.device)
+    check(_lib.load().mp_init_extents(points.data_ptr(), n_mesh, n_pts, R.data_ptr(), R.shape[0], ext.data_ptr(), _stream()))
+    return ext
+
+
+def init_poses_from_boxes(boxes, K, mesh_ids, rot_ids, R, ext) -> torch.Tensor:
+    boxes, K, R, ext = _dev_f32(boxes), _dev_f32(K), _dev_f32(R), _dev_f32(ext)
+    b = boxes.shape[0]
+    TCO = torch.empty(b, 4, 4, dtype=torch.float32, device=boxes.device)
+    check(_lib.load().mp_init_poses_from_boxes(boxes.data_ptr(), K.data_ptr(), _dev_i32(mesh_ids).data_ptr(),
+                                               _dev_i32(rot_ids).data_ptr(), R.data_ptr(), R.shape[0], ext.data_ptr(), b,
+                                               TCO.data_ptr(), _stream()))
+    return TCO
+
+
+def pose_prepare(TCO_in, K, mesh_ids, points, n_pts_main: int, n_pts_views: int, V: int, multiview: int, im_hw, out_hw,
+                 lamb: float = 1.4):
+    TCO_in, K, points = _dev_f32(TCO_in), _dev_f32(K), _dev_f32(points)
+    b = TCO_in.shape[0]
+    dev = TCO_in.device
+    f = dict(dtype=torch.float32, device=dev)
+    TCO_n = torch.empty(b, 4, 4, **f)
+    tCR = torch.empty(b, 3, **f)
+    TCV_O = torch.empty(b, V, 4, 4, **f)
+    KV = torch.empty(b, V, 3, 3, **f)
+    boxes_rend = torch.empty(b, 4, **f)
+    boxes_crop = torch.empty(b, 4, **f)
+    check(_lib.load().mp_pose_prepare(TCO_in.data_ptr(), K.data_ptr(), _dev_i32(mesh_ids).data_ptr(), points.data_ptr(),
+                                      points.shape[1], n_pts_main, n_pts_views, b, V, multiview, im_hw[0], im_hw[1], out_hw[0],
+                                      out_hw[1], lamb, TCO_n.data_ptr(), tCR.data_ptr(), TCV_O.data_ptr(), KV.data_ptr(),
+                                      boxes_rend.data_ptr(), boxes_crop.data_ptr(), _stream()))
+    return TCO_n, tCR, TCV_O, KV, boxes_rend, boxes_crop
+
+
+def pose_update(TCO, K_crop, out9, tCR, k_stride_floats: int = 9) -> torch.Tensor:
+    TCO, out9, tCR = _dev_f32(TCO), _dev_f32(out9), _dev_f32(tCR)
+    assert K_crop.dtype == torch.float32 and K_crop.is_cuda
+    out = torch.empty_like(TCO)
+    check(_lib.load().mp_pose_update(TCO.data_ptr(), K_crop.data_ptr(), k_stride_floats, out9.data_ptr(), tCR.data_ptr(),
+                                     TCO.shape[0], out.data_ptr(), _stream()))
+    return out

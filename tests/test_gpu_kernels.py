@@ -1,0 +1,295 @@
+"""-m gpu: kernel-level parity of libmp_engine.so (called through the C-ABI) against the CPU oracle.
+
+Tolerances (stated per test): rasteriser bit-exact (integer coverage + explicit fmaf contract);
+roi_align / pose math <= 1e-5 abs (same fp32 formulas, different contraction); conv / backbone <= 2e-4
+relative to the activation scale (fp32 MFMA k-ordered fmaf chain vs MKL-DNN's blocked summation).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from megapose6d_amd import engine
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    n_cu, lds, arch = engine.device_info()
+    assert arch.startswith("gfx950")
+    return engine
+
+
+def _to_padded(eng, x_nchw, cp, border):
+    n, c, h, w = x_nchw.shape
+    buf = eng.padded_nhwc(n, h, w, cp, border, "cuda")
+    v = eng.padded_view(buf, n, h, w, cp, border)
+    v[..., :c] = x_nchw.permute(0, 2, 3, 1).cuda()
+    return buf
+
+
+def _from_padded(eng, buf, n, h, w, c, border):
+    return eng.padded_view(buf, n, h, w, c, border).permute(0, 3, 1, 2).contiguous().cpu()
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, K, stride, pad, in_border
+    (2, 9, 48, 64, 64, 7, 2, 3, 3),     # coarse stem (C padded 9 -> 12, run 84 -> 96)
+    (1, 27, 30, 40, 64, 7, 2, 3, 3),    # refiner stem (27 -> 28)
+    (1, 32, 30, 40, 64, 5, 2, 2, 2),    # wide-resnet RGBD stem
+    (3, 64, 15, 20, 64, 3, 1, 1, 1),    # layer1
+    (2, 64, 15, 21, 128, 3, 2, 1, 1),   # layer2.0.conv1 (odd width)
+    (2, 64, 15, 21, 128, 1, 2, 0, 1),   # downsample
+    (2, 128, 8, 10, 256, 3, 2, 1, 1),
+    (5, 256, 4, 5, 512, 3, 1, 1, 1),    # M = 100: partial tile
+    (1, 512, 8, 10, 512, 3, 1, 1, 2),   # border larger than pad
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "res_relu", "dual"])
+def test_conv_matches_torch_fp32(eng, case, epi):
+    N, Cin, H, W, Cout, K, s, p, ib = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    res = torch.randn(N, Cout, Ho, Wo, generator=g)
+    cp = (Cin + 3) // 4 * 4
+    xb = _to_padded(eng, x, cp, ib)
+    use_scale = epi != "plain"
+    wp = torch.from_numpy(eng.conv_pack_weights(w.numpy(), cp, scale.numpy() if use_scale else None)).cuda()
+    ob = 1
+    yb = eng.padded_nhwc(N, Ho, Wo, Cout, ob, "cuda")
+    yb += 7.0  # poison: interior must be fully overwritten
+    ya = eng.padded_nhwc(N, Ho, Wo, Cout, ob, "cuda") if epi == "dual" else None
+    sc2, sh2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    rb = _to_padded(eng, res, Cout, ob) if epi in ("res_relu", "dual") else None
+    eng.conv2d_nhwc(xb, N, H, W, cp, ib, wp, bias.cuda() if use_scale else None, Cout, K, s, p, yb, ob,
+                    residual=rb, relu=epi in ("bias_relu", "res_relu"), y_act=ya,
+                    act_scale=sc2.cuda() if ya is not None else None, act_shift=sh2.cuda() if ya is not None else None)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w * (scale.view(-1, 1, 1, 1) if use_scale else 1.0), bias if use_scale else None, stride=s, padding=p)
+    if epi in ("res_relu", "dual"):
+        ref = ref + res
+    if epi in ("bias_relu", "res_relu"):
+        ref = F.relu(ref)
+    got = _from_padded(eng, yb, N, Ho, Wo, Cout, ob)
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < tol
+    # border untouched (still the poison value)
+    full = yb[: N * (Ho + 2) * (Wo + 2) * Cout].view(N, Ho + 2, Wo + 2, Cout)
+    assert torch.all(full[:, 0] == 7.0) and torch.all(full[:, :, 0] == 7.0)
+    if epi == "dual":
+        ref_a = F.relu(ref * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1))
+        got_a = _from_padded(eng, ya, N, Ho, Wo, Cout, ob)
+        assert (got_a - ref_a).abs().max().item() < tol * 2
+
+
+def test_maxpool_and_tail(eng):
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = 3, 64, 30, 41
+    x = torch.rand(N, C, H, W, generator=g)
+    xb = _to_padded(eng, x, C, 1)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    yb = eng.padded_nhwc(N, Ho, Wo, C, 1, "cuda")
+    eng.maxpool3x3s2(xb, N, H, W, C, 1, yb, 1)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    assert torch.equal(_from_padded(eng, yb, N, Ho, Wo, C, 1), ref)
+    # tail: avgpool + fc + head + sigmoid
+    C2 = 512
+    x2 = torch.randn(4, C2, 8, 10, generator=g)
+    fcw, fcb = torch.randn(512, 512, generator=g) * 0.05, torch.randn(512, generator=g)
+    hw, hb = torch.randn(9, 512, generator=g) * 0.05, torch.randn(9, generator=g)
+    out = torch.empty(4, 9, device="cuda")
+    sig = torch.empty(4, 9, device="cuda")
+    feat = torch.empty(4, 512, device="cuda")
+    eng.pool_fc_heads(_to_padded(eng, x2, C2, 1), 4, 8, 10, C2, 1, fcw.cuda(), fcb.cuda(), 512, hw.cuda(), hb.cuda(), 9, feat, out, sig)
+    f_ref = F.linear(x2.mean(dim=(2, 3)), fcw, fcb)
+    o_ref = F.linear(f_ref, hw, hb)
+    assert (feat.cpu() - f_ref).abs().max() < 1e-4
+    assert (out.cpu() - o_ref).abs().max() < 1e-4
+    assert (sig.cpu() - torch.sigmoid(o_ref)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("kind,c_in,head,n_out", [("vanilla_resnet34", 9, "logits", 1), ("vanilla_resnet34", 27, "pose", 9),
+                                                  ("resnet34", 27, "pose", 9), ("resnet18", 9, "logits", 1),
+                                                  ("vanilla_resnet34", 32, "pose", 9)])
+def test_backbone_matches_oracle(eng, kind, c_in, head, n_out):
+    from megapose6d_amd import synthetic as syn
+    from oracle import backbones as ob
+
+    sd = syn.make_state_dict(kind, c_in, head, n_out, seed=1)
+    bb = eng.Backbone(kind, c_in, head, n_out, sd)
+    b, h, w = 3, 240, 320
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(b, c_in, h, w, generator=g)
+    xb = _to_padded(eng, x, bb.c_in_p, bb.in_border)
+    out = torch.empty(b, n_out, device="cuda")
+    feat = torch.empty(b, 512, device="cuda")
+    bb.forward(xb, b, h, w, out, None, feat)
+    # run twice: the second call must reuse the workspace (no re-zeroing) and give identical results
+    out2 = torch.empty_like(out)
+    bb.forward(xb, b, h, w, out2, None, None)
+    torch.cuda.synchronize()
+    ref = ob.net_forward(sd, kind, x)
+    key = "pose" if head == "pose" else "renderings_logits"
+    fscale = ref["features"].abs().max().item()
+    assert (feat.cpu() - ref["features"]).abs().max().item() < 2e-4 * max(1.0, fscale)
+    assert (out.cpu() - ref[key]).abs().max().item() < 2e-4 * max(1.0, ref[key].abs().max().item())
+    assert torch.equal(out, out2)
+    assert abs(bb.flops(1, 240, 320) / 1e9 - {9: 12.068, 27: 14.236, 32: 14.838}[c_in]) < 0.01 or kind != "vanilla_resnet34"
+
+
+def _mesh_db(eng, engine_meshes):
+    return eng.MeshDB(engine_meshes)
+
+
+@pytest.mark.parametrize("flags", [1, 3, 1 | 4, 0])
+def test_raster_bit_exact_vs_oracle(eng, engine_meshes, flags):
+    from megapose6d_amd import synthetic as syn
+    from oracle import raster as orr
+
+    db = _mesh_db(eng, engine_meshes)
+    rng = np.random.RandomState(5)
+    n = 6
+    mesh_ids = np.array([0, 1, 2, 0, 1, 2], np.int32)
+    T = np.stack([syn.random_pose(rng, z_range=(0.25, 0.6)) for _ in range(n)])
+    K = np.repeat(syn.K_EXAMPLE[None].astype(np.float32), n, 0)
+    K[:, 0, 0] *= 0.5; K[:, 1, 1] *= 0.5; K[:, 0, 2] = 160; K[:, 1, 2] = 120
+    T[3, 0, 3] = np.nan  # invalid pose -> zeros (panda3d_batch_renderer.py:109-135)
+    h, w = 240, 320
+    out = torch.full((n, h, w, 8), -1.0, device="cuda")
+    if flags == 0:
+        dirs = orr.POINT_DIRS
+        cols = [(0.4, 0.4, 0.4)] * 6
+        L = eng.make_lights((0.1, 0.1, 0.1), dirs, cols)
+        Lo = orr.lights_struct((0.1, 0.1, 0.1), dirs, cols)
+    else:
+        L, Lo = eng.make_lights(), orr.lights_struct()
+    eng.raster_render(db, torch.from_numpy(mesh_ids).cuda(), torch.from_numpy(T).cuda(), torch.from_numpy(K).cuda(), h, w, flags,
+                      L, out, h * w * 8, w * 8, 8, 0, 3, 6)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(n):
+        rgb, nrm, dep = orr.render(engine_meshes[mesh_ids[i]], T[i : i + 1], K[i : i + 1], h, w, flags, Lo)
+        if i != 3:
+            assert (dep[0] > 0).mean() > 0.02, "object should be visible"
+        if flags == 0:  # point lights use sqrt/div chains: allow 1 LSB of the uint8 quantisation on a few pixels
+            d = np.abs(got[i, :, :, 0:3] - rgb[0])
+            assert d.max() <= 1.0 / 255 + 1e-7 and (d > 0).mean() < 1e-3
+        else:
+            assert np.array_equal(got[i, :, :, 0:3], rgb[0])
+        if flags & 1:
+            assert np.array_equal(got[i, :, :, 3:6], nrm[0])
+        if flags & 2:
+            assert np.array_equal(got[i, :, :, 6], dep[0])
+
+
+def test_raster_large_triangles_and_close_camera(eng):
+    """low-poly mesh (huge triangles -> block-cooperative path) and a camera inside the guard band."""
+    from oracle import raster as orr
+
+    v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [0, 0, 0.5]], np.float32) * 0.1
+    f = np.array([[0, 1, 2], [0, 2, 3], [0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], np.int32)
+    nrm = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6)
+    col = np.random.RandomState(0).rand(5, 3).astype(np.float32)
+    mesh = {"vertices": v, "normals": nrm.astype(np.float32), "colors": col, "faces": f}
+    db = eng.MeshDB([mesh])
+    T = np.tile(np.eye(4, dtype=np.float32), (3, 1, 1))
+    T[:, 2, 3] = [0.3, 0.15, 0.11]
+    T[1, :3, :3] = np.array([[0.8, 0, 0.6], [0, 1, 0], [-0.6, 0, 0.8]], np.float32)
+    K = np.tile(np.array([[300, 0, 160], [0, 300, 120], [0, 0, 1]], np.float32), (3, 1, 1))
+    out = torch.zeros(3, 240, 320, 8, device="cuda")
+    eng.raster_render(db, torch.zeros(3, dtype=torch.int32, device="cuda"), torch.from_numpy(T).cuda(), torch.from_numpy(K).cuda(),
+                      240, 320, 3, eng.make_lights(), out, 240 * 320 * 8, 320 * 8, 8, 0, 3, 6)
+    got = out.cpu().numpy()
+    rgb, nr, dep = orr.render(mesh, T, K, 240, 320, 3)
+    assert np.array_equal(got[..., 0:3], rgb) and np.array_equal(got[..., 3:6], nr) and np.array_equal(got[..., 6], dep)
+    assert (dep[0] > 0).mean() > 0.1
+
+
+@pytest.mark.parametrize("C", [3, 4])
+def test_crop_roi_align_vs_oracle(eng, C):
+    from oracle import thirdparty as tp
+
+    g = torch.Generator().manual_seed(C)
+    imgs = torch.rand(2, C, 120, 160, generator=g)
+    if C == 4:
+        imgs[:, 3] = imgs[:, 3] * 2
+        imgs[:, 3][torch.rand(2, 120, 160, generator=g) < 0.05] = 0.0
+    boxes = torch.tensor([[10.3, 5.2, 90.7, 65.5], [-20.0, -10.0, 100.0, 80.0], [100.0, 60.0, 200.0, 135.0], [50.0, 50.0, 50.5, 50.2]])
+    im_ids = torch.tensor([0, 1, 1, 0], dtype=torch.int32)
+    oh, ow = 60, 80
+    out = torch.zeros(4, oh, ow, 8, device="cuda")
+    eng.crop_roi_align(imgs.cuda(), im_ids.cuda(), boxes.cuda(), oh, ow, out, oh * ow * 8, ow * 8, 8, 1)
+    torch.cuda.synchronize()
+    rois = torch.cat([im_ids.float()[:, None], boxes], 1)
+    ref = tp.roi_align(imgs, rois, (oh, ow), sampling_ratio=4)
+    if C == 4:  # cropping.py:131-142
+        valid = (imgs[:, 3:4] > 0).float()
+        vc = tp.roi_align(valid, rois, (oh, ow), sampling_ratio=4)
+        ref[:, 3:4] = ref[:, 3:4] * (vc >= 0.99).float()
+    got = out[..., 1 : 1 + C].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 1e-5
+    assert torch.all(out[..., 0] == 0)
+
+
+def test_pose_ops_vs_oracle(eng, engine_meshes):
+    from megapose6d_amd import synthetic as syn
+    from oracle import geometry as og
+
+    rng = np.random.RandomState(11)
+    b = 7
+    pts_list = [torch.from_numpy(m["points"]) for m in engine_meshes]
+    pts = og.pad_stack_points(pts_list)  # [3, Nmax, 3]
+    ids2000 = og.sample_point_ids(pts.shape[1], 2000)
+    pts_s = pts[:, ids2000]
+    mesh_ids = torch.tensor(rng.randint(0, 3, size=b), dtype=torch.int32)
+    T = torch.from_numpy(np.stack([syn.random_pose(rng) for _ in range(b)]))
+    T[:, :3, :3] += 0.01 * torch.randn(b, 3, 3)  # not orthonormal on purpose
+    K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None], b, 0)).float()
+    # normalize_T
+    got = eng.normalize_T(T.cuda()).cpu()
+    assert (got - og.normalize_T(T)).abs().max() < 1e-6
+    # prepare, single view
+    for V, mv, mvt in ((1, 0, "TCO"), (4, 1, "TCO+front_3views")):
+        TCO_n, tCR, TCV, KV, brend, bcrop = [t.cpu() for t in eng.pose_prepare(T.cuda(), K.cuda(), mesh_ids.cuda(), pts_s.cuda(), 2000, 200, V, mv, (480, 640), (240, 320))]
+        Tn = og.normalize_T(T)
+        tcr = Tn[:, :3, 3]
+        P = pts_s[mesh_ids.long()]
+        uv = og.project_points_robust(P, K, Tn)
+        br = og.boxes_from_uv(uv)
+        bc = og.crop_boxes_robust(br, K, Tn, tcr, P, (480, 640))
+        Kc = og.get_K_crop_resize(K, bc, (240, 320))
+        assert (TCO_n - Tn).abs().max() < 1e-6 and (tCR - tcr).abs().max() < 1e-6
+        assert (brend - br).abs().max() < 2e-3 and (bcrop - bc).abs().max() < 2e-3  # pixels, values ~ 1e2..1e3
+        assert ((KV[:, 0] - Kc).abs() / Kc.abs().clamp(min=1.0)).max() < 1e-5
+        TV = og.make_TCO_multiview(Tn, tcr, mvt, V)
+        assert (TCV - TV).abs().max() < 2e-6
+        if V == 4:
+            Pv = P[:, :200].unsqueeze(1).repeat(1, V, 1, 1).flatten(0, 1)
+            TVf, Kf = TV.flatten(0, 1), K.unsqueeze(1).repeat(1, V, 1, 1).flatten(0, 1)
+            brv = og.boxes_from_uv(og.project_points_robust(Pv, Kf, TVf))
+            bcv = og.crop_boxes_robust(brv, Kf, TVf, TVf[:, :3, 3], Pv, (480, 640))
+            Kcv = og.get_K_crop_resize(Kf, bcv, (240, 320)).view(b, V, 3, 3)
+            Kcv[:, 0] = Kc
+            assert ((KV - Kcv).abs() / Kcv.abs().clamp(min=1.0)).max() < 2e-5
+    # pose update
+    out9 = torch.randn(b, 9) * 0.05 + torch.tensor([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0])
+    Tn = og.normalize_T(T)
+    got = eng.pose_update(Tn.cuda(), Kc.cuda().contiguous(), out9.cuda(), Tn[:, :3, 3].contiguous().cuda()).cpu()
+    assert (got - og.update_pose(Tn, Kc, out9, Tn[:, :3, 3])).abs().max() < 1e-6
+    # SO(3)-grid init
+    quats = torch.randn(16, 4); quats = quats / quats.norm(dim=1, keepdim=True)
+    R = og.load_SO3_grid_from_quats(quats)
+    ext = eng.init_extents(pts.cuda(), R.cuda())
+    rot_ids = torch.tensor(rng.randint(0, 16, size=b), dtype=torch.int32)
+    boxes = torch.tensor([[200.0, 150, 330, 300]]).repeat(b, 1) + torch.rand(b, 4) * 20
+    got = eng.init_poses_from_boxes(boxes.cuda(), K.cuda(), mesh_ids.cuda(), rot_ids.cuda(), R.cuda(), ext).cpu()
+    ref = og.TCO_init_from_boxes_autodepth_with_R(boxes, pts[mesh_ids.long()], K, R[rot_ids.long()])
+    assert (got - ref).abs().max() < 1e-5
