@@ -81,15 +81,18 @@ typedef struct {
 
 size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views);
 
-/* d_out addressing: element (view v, y, x, channel c) at d_out[v*stride_v + y*stride_y + x*stride_x + c].
+/* d_out addressing: element (view v, y, x, channel c) at
+ *   d_out[(v / views_per_item)*stride_v + (v % views_per_item)*stride_view + y*stride_y + x*stride_x + c]
+ * (views_per_item = 1, stride_view = 0 for a plain batch; = n_rendered_views / channels-per-view when the views of
+ * one hypothesis are folded into the channels of one CNN input row, models/pose_rigid.py:405-408).
  * c_rgb / c_normals / c_depth are the first channel of each group (negative = not written).
  * Values are uint8-quantised then /255 exactly as panda3d_batch_renderer.py:261-274
  * (depth is not quantised).  Non-finite TCO/K rows produce zeros (:109-135).              */
 int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO /*[n,4,4]*/,
                      const float* d_K /*[n,3,3]*/, int n_views, int h, int w, uint32_t flags,
-                     const mp_lights* h_lights, float* d_out, int64_t stride_v, int64_t stride_y,
-                     int64_t stride_x, int c_rgb, int c_normals, int c_depth, void* d_workspace,
-                     size_t workspace_bytes, mp_stream stream);
+                     const mp_lights* h_lights, float* d_out, int64_t stride_v, int views_per_item,
+                     int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb, int c_normals,
+                     int c_depth, void* d_workspace, size_t workspace_bytes, mp_stream stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Crop: replaces lib3d/cropping.py:113-144 crop_images (torchvision.ops.roi_align,       */

@@ -71,7 +71,7 @@ SIGNATURES = {
     "mp_mesh_db_max_vertices": (_i, [_vp]),
     "mp_mesh_db_radius": (_f, [_vp, _i]),
     "mp_raster_workspace_bytes": (_sz, [_vp, _i]),
-    "mp_raster_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i64, _i64, _i, _i, _i,
+    "mp_raster_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
                               _vp, _sz, _vp]),
     "mp_crop_roi_align": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _i, _vp]),
     "mp_normalize_depth": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),

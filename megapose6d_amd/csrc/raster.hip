@@ -198,8 +198,8 @@ template <bool kUnused = false>
 __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const VtxRec* __restrict__ vtx, int max_verts, int h, int w, uint32_t flags, LightsDev lights,
-    float* __restrict__ out, long long stride_v, long long stride_y, long long stride_x, int c_rgb, int c_normals,
-    int c_depth) {
+    float* __restrict__ out, long long stride_v, int views_per_item, long long stride_view, long long stride_y,
+    long long stride_x, int c_rgb, int c_normals, int c_depth) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];  // [BAND_H*w] + big-triangle queue
   int* big_queue = (int*)(zbuf + (size_t)BAND_H * w);
   __shared__ int big_count;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
   const bool no_quant = flags & MP_RASTER_NO_QUANT;
-  float* out_v = out + (size_t)view * stride_v;
+  float* out_v = out + (size_t)(view / views_per_item) * stride_v + (size_t)(view % views_per_item) * stride_view;
   for (int i = threadIdx.x; i < npix; i += BAND_THREADS) {
     const int py = y0 + i / w, px = i % w;
     float* o = out_v + (size_t)py * stride_y + (size_t)px * stride_x;
@@ -408,10 +408,10 @@ extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views) {
 
 extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
                                 int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
-                                int64_t stride_v, int64_t stride_y, int64_t stride_x, int c_rgb, int c_normals, int c_depth,
-                                void* d_ws, size_t ws_bytes, mp_stream stream) {
+                                int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
+                                int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream) {
   MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
-  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024, "mp_raster_render: bad size");
+  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && views_per_item >= 1, "mp_raster_render: bad size");
   MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
   if (n_views == 0) return MP_OK;
   MP_REQUIRE(ws_bytes >= mp_raster_workspace_bytes(db, n_views), "mp_raster_render: workspace too small");
@@ -434,8 +434,8 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   MP_REQUIRE(lds <= 160 * 1024 - 64, "mp_raster_render: image too wide for the LDS z-buffer");
   dim3 g2(ceil_div(h, BAND_H), n_views);
   hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, vtx, db->max_verts,
-                     h, w, flags, L, d_out, (long long)stride_v, (long long)stride_y, (long long)stride_x, c_rgb, c_normals,
-                     c_depth);
+                     h, w, flags, L, d_out, (long long)stride_v, views_per_item, (long long)stride_view, (long long)stride_y,
+                     (long long)stride_x, c_rgb, c_normals, c_depth);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

@@ -1,0 +1,72 @@
+"""Row sharding + gathers for the multi-GPU path (one process per GPU, torch.distributed; backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).
+
+The hot path shards naturally: every (object, hypothesis) row is independent through coarse
+scoring, each refiner chain and re-scoring; the only coupling is the per-detection top-K / arg-max.  So: rank r owns
+rows r, r+W, r+2W, ... (interleaved: every rank touches every object, meshes stay balanced), results are exchanged with
+ONE all-gather per stage of a packed [rows, k] fp32 tensor (<= 2.5 MB at 64 x 576 x 17 floats -- latency-bound, far below
+the per-link xGMI budget, so no bucketing or ring tuning is warranted), and every rank then holds the full table.
+The reference has no in-pipeline collective at all (its eval gathers through the filesystem,
+src/megapose/utils/tensor_collection.py:165-186).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def is_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def rank() -> int:
+    return dist.get_rank() if is_initialized() else 0
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def init_from_env(backend: Optional[str] = None) -> None:
+    """Initialise the default process group from torchrun's environment (RANK / WORLD_SIZE / MASTER_*)."""
+    if is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, init_method="env://")
+
+
+def shard_indices(n: int, r: int, world: int) -> np.ndarray:
+    """Rows owned by rank r: r, r+world, ..."""
+    return np.arange(r, n, world)
+
+
+def shard_size(n: int, r: int, world: int) -> int:
+    return len(range(r, n, world))
+
+
+def gather_rows(local: torch.Tensor, n: int, r: int, world: int, group=None) -> torch.Tensor:
+    """Inverse of shard_indices: every rank passes its [shard_size, k] rows and receives the full [n, k] table in
+    original row order.  One all_gather of equally sized (padded) blocks."""
+    assert local.dim() == 2 and local.shape[0] == shard_size(n, r, world)
+    per = (n + world - 1) // world
+    k = local.shape[1]
+    block = torch.zeros(per, k, dtype=local.dtype, device=local.device)
+    block[: local.shape[0]] = local
+    out = torch.empty(world * per, k, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, block, group=group) if local.is_cuda else _all_gather_cpu(out, block, world, group)
+    # out[q*per + j] is row q + j*world
+    full = out.view(world, per, k).transpose(0, 1).reshape(per * world, k)
+    return full[:n].contiguous()
+
+
+def _all_gather_cpu(out: torch.Tensor, block: torch.Tensor, world: int, group=None) -> None:
+    parts = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(parts, block, group=group)
+    out.copy_(torch.cat(parts, dim=0))

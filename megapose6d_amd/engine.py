@@ -113,7 +113,7 @@ def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()) -> Ligh
 
 def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, h: int, w: int, flags: int,
                   lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
-                  c_depth: int, out_offset_floats: int = 0) -> None:
+                  c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0) -> None:
     """Render n views into `out` (float32 device tensor) at the given element strides."""
     lib = _lib.load()
     n = int(TCO.shape[0])
@@ -123,8 +123,8 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     assert out.dtype == torch.float32 and out.is_cuda
     ws = db.workspace(n, out.device)
     check(lib.mp_raster_render(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
-                               out.data_ptr() + 4 * out_offset_floats, stride_v, stride_y, stride_x, c_rgb, c_normals, c_depth,
-                               ws.data_ptr(), ws.numel(), _stream()))
+                               out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x, c_rgb,
+                               c_normals, c_depth, ws.data_ptr(), ws.numel(), _stream()))
 
 
 def crop_roi_align(images: torch.Tensor, im_ids: torch.Tensor, boxes: torch.Tensor, out_h: int, out_w: int, out: torch.Tensor,

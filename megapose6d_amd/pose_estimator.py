@@ -1,0 +1,387 @@
+"""PoseEstimator: SO(3)-grid hypotheses -> coarse scores -> top-K -> iterative refinement -> re-scoring -> arg-max.
+
+Same public API, return types, DataFrame columns and `extra_data` keys as the reference
+src/megapose/inference/pose_estimator.py:52-667, so it drops into
+src/megapose/scripts/run_inference_on_example.py:126-148 unchanged.  What differs is the schedule: the reference walks
+three Python loops of tiny batches (bsz_images / bsz_objects are 2022-era memory workarounds), gathers one full frame
+per hypothesis row and syncs to the host in every batch; here every stage runs as a few large launches over rows that
+share the single observation frame by index, and the host is touched once per stage (to fill the DataFrame).
+`bsz_images` / `bsz_objects` are accepted and kept as attributes; the engine batches by `max_rows_per_launch`
+(set `strict_batching=True` to honour the reference batch sizes exactly).
+
+Multi-GPU: with torch.distributed initialised and `distributed=True`, rows are sharded `rank::world`,
+coarse logits are all-gathered (RCCL), every rank computes the same top-K, refine+score runs on the local shard, and
+`[rows,17]` (pose + logit) is all-gathered so that every rank returns the full result.
+"""
+from __future__ import annotations
+
+import time
+from collections import defaultdict
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import distributed as mpdist
+from . import engine as eng
+from . import tcoll as tc
+from .tcoll import PandasTensorCollection
+from .types import DetectionsType, ObservationTensor, PoseEstimatesType, assert_detections_valid
+
+_DATA_DIR = Path(__file__).resolve().parent / "data"
+
+
+def load_SO3_grid(resolution: int) -> torch.Tensor:
+    """xyzw unit quaternions -> [N,3,3] (reference utils/transform_utils.py:27-50; roma.unitquat_to_rotmat formula,
+    SURVEY.md App. A.1).  fp32 like the reference (torch.tensor of python floats)."""
+    path = _DATA_DIR / f"so3_grid_{resolution}_xyzw.npy"
+    assert path.is_file(), f"File {path} not found"
+    q = torch.tensor(np.load(path).tolist())  # float32, same rounding as torch.tensor(list of python floats)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1)
+    return R.reshape(-1, 3, 3)
+
+
+def add_instance_id(inputs):
+    """reference inference/utils.py:151-171"""
+    if "instance_id" in inputs.infos:
+        return inputs
+    df = inputs.infos.copy()
+    df["instance_id"] = df.groupby(["batch_im_id", "label"]).cumcount()
+    inputs.infos = df
+    return inputs
+
+
+def filter_detections(detections, labels: Optional[List[str]] = None, one_instance_per_class: bool = False):
+    """reference inference/utils.py:174-194"""
+    if labels is not None:
+        df = detections.infos
+        detections = detections[df[df.label.isin(labels)].index.tolist()]
+    if one_instance_per_class:
+        df = detections.infos.sort_values("score", ascending=False).groupby(["batch_im_id", "label"]).head(1)
+        detections = detections[df.index.tolist()]
+    return detections
+
+
+class _Timer:
+    def __init__(self):
+        self.t0 = time.time()
+
+    def elapsed(self) -> float:
+        return time.time() - self.t0
+
+
+class PoseEstimator(torch.nn.Module):
+    """Performs inference for pose estimation."""
+
+    def __init__(self, refiner_model: Optional[torch.nn.Module] = None, coarse_model: Optional[torch.nn.Module] = None,
+                 detector_model: Optional[torch.nn.Module] = None, depth_refiner=None, bsz_objects: int = 8, bsz_images: int = 256,
+                 SO3_grid_size: int = 576, max_rows_per_launch: int = 576, strict_batching: bool = False,
+                 distributed: bool = False) -> None:
+        super().__init__()
+        self.coarse_model = coarse_model
+        self.refiner_model = refiner_model
+        self.detector_model = detector_model
+        self.depth_refiner = depth_refiner
+        self.bsz_objects = bsz_objects
+        self.bsz_images = bsz_images
+        self.max_rows_per_launch = max_rows_per_launch
+        self.strict_batching = strict_batching
+        self.distributed = distributed
+        if self.refiner_model is not None:
+            self.cfg = self.refiner_model.cfg
+            self.mesh_db = self.refiner_model.mesh_db
+        elif self.coarse_model is not None:
+            self.cfg = self.coarse_model.cfg
+            self.mesh_db = self.coarse_model.mesh_db
+        else:
+            raise ValueError("At least one of refiner_model or coarse_model must be specified.")
+        self._extents: Optional[torch.Tensor] = None
+        if SO3_grid_size is not None:
+            self.load_SO3_grid(SO3_grid_size)
+        self.eval()
+        self.keep_all_outputs = False
+        self.keep_all_coarse_outputs = False
+        self.refiner_outputs = None
+        self.coarse_outputs = None
+        self.debug_dict: dict = dict()
+
+    def load_SO3_grid(self, grid_size: int) -> None:
+        self._SO3_grid = load_SO3_grid(grid_size).cuda()
+        self._extents = None
+
+    # -- helpers -------------------------------------------------------------------------------------------------
+    def _chunk(self, reference_bsz: int) -> int:
+        return reference_bsz if self.strict_batching else max(self.max_rows_per_launch, 1)
+
+    def _grid_extents(self) -> torch.Tensor:
+        if self._extents is None:  # [n_obj, M, 2]: depends only on (mesh, rotation) -- cosypose_ops.py:198-208
+            self._extents = eng.init_extents(self.mesh_db.points, self._SO3_grid)
+        return self._extents
+
+    def _shard(self, n: int) -> np.ndarray:
+        if self.distributed and mpdist.world_size() > 1:
+            return mpdist.shard_indices(n, mpdist.rank(), mpdist.world_size())
+        return np.arange(n)
+
+    def _gather(self, local: torch.Tensor, n: int) -> torch.Tensor:
+        if self.distributed and mpdist.world_size() > 1:
+            return mpdist.gather_rows(local, n, mpdist.rank(), mpdist.world_size())
+        return local
+
+    # -- coarse ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_coarse_model(self, observation: ObservationTensor, detections: DetectionsType, cuda_timer: bool = False,
+                             return_debug_data: bool = False) -> Tuple[PoseEstimatesType, dict]:
+        start = time.time()
+        assert_detections_valid(detections)
+        coarse = self.coarse_model
+        device = observation.images.device
+        B, M = len(detections), self._SO3_grid.shape[0]
+        df = detections.infos
+        # one row per (detection, grid rotation); detection-major, hypothesis-minor (pose_estimator.py:350-360)
+        df_h = df.loc[df.index.repeat(M)].copy()
+        df_h["hypothesis_id"] = np.tile(np.arange(M), B)
+        df_h["bbox_id"] = np.repeat(df.index.values, M)
+        n = B * M
+        labels_det = df["label"].tolist()
+        det_mesh = torch.tensor(self.mesh_db.ids(labels_det), dtype=torch.int32, device=device)
+        det_im = torch.as_tensor(df["batch_im_id"].values.astype(np.int32), device=device)
+        rows = torch.as_tensor(self._shard(n), device=device, dtype=torch.long)
+        det_of_row = torch.div(rows, M, rounding_mode="floor")
+        rot_of_row = (rows % M).to(torch.int32)
+        bboxes_all = detections.bboxes.to(device=device, dtype=torch.float32)
+        K_rows = observation.K[det_im[det_of_row].long()].float()
+        TCO_local = eng.init_poses_from_boxes(bboxes_all[det_of_row], K_rows, det_mesh[det_of_row], rot_of_row, self._SO3_grid,
+                                              self._grid_extents())
+        logits_l, scores_l = [], []
+        crops, renders = [], []
+        render_time = model_time = 0.0
+        chunk = self._chunk(self.bsz_images)
+        n_batches = 0
+        for s in range(0, rows.numel(), chunk):
+            sl = slice(s, min(s + chunk, rows.numel()))
+            d = det_of_row[sl]
+            labels_ = [labels_det[i] for i in d.tolist()]
+            out_ = coarse.forward_coarse(images=observation.images, K=K_rows[sl], labels=labels_, TCO_input=TCO_local[sl],
+                                         cuda_timer=cuda_timer, return_debug_data=return_debug_data, im_ids=det_im[d])
+            render_time += out_["render_time"]
+            model_time += out_["model_time"]
+            logits_l.append(out_["logits"])
+            scores_l.append(out_["scores"])
+            if return_debug_data:
+                crops.append(out_["images_crop"])
+                renders.append(out_["renders"])
+            n_batches += 1
+        packed = torch.cat([TCO_local.flatten(1), torch.cat(logits_l), torch.cat(scores_l)], dim=1)  # [rows, 18]
+        packed = self._gather(packed, n)
+        TCO = packed[:, :16].reshape(n, 4, 4).contiguous()
+        logits = packed[:, 16].reshape(B, M)
+        scores = packed[:, 17].reshape(B, M)
+        bboxes = bboxes_all[torch.arange(n, device=device) // M]
+        debug_data = dict()
+        if return_debug_data:
+            ic, rr = torch.cat(crops), torch.cat(renders)
+            debug_data = {"images_crop": ic.reshape([B, M, -1, *ic.shape[-2:]]), "renders": rr.reshape([B, M, -1, *rr.shape[-2:]])}
+        host = torch.stack([logits.flatten(), scores.flatten()]).cpu().numpy()  # the stage's single D2H sync
+        df_h["coarse_logit"] = host[0]
+        df_h["coarse_score"] = host[1]
+        elapsed = time.time() - start
+        timing_str = f"time: {elapsed:.2f}, model_time: {model_time:.2f}, render_time: {render_time:.2f}"
+        extra_data = {"render_time": render_time, "model_time": model_time, "time": elapsed, "logits": logits, "scores": scores,
+                      "TCO": TCO.reshape([B, M, 4, 4]), "debug": debug_data, "n_batches": n_batches, "timing_str": timing_str}
+        return PandasTensorCollection(df_h, poses=TCO, bboxes=bboxes), extra_data
+
+    # -- refiner --------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_refiner(self, observation: ObservationTensor, data_TCO_input: PoseEstimatesType, n_iterations: int = 5,
+                        keep_all_outputs: bool = False, cuda_timer: bool = False, **refiner_kwargs) -> Tuple[dict, dict]:
+        start = time.time()
+        assert self.refiner_model is not None
+        device = observation.images.device
+        R = data_TCO_input.poses.shape[0]
+        chunk = self._chunk(self.bsz_objects)
+        df = data_TCO_input.infos.copy()  # the reference adds these two columns to its per-batch copies (:155-156)
+        df["refiner_batch_idx"] = np.arange(R) // chunk
+        df["refiner_instance_idx"] = np.arange(R) % chunk
+        labels_all = df["label"].tolist()
+        im_all = torch.as_tensor(df["batch_im_id"].values.astype(np.int32), device=device)
+        rows = torch.as_tensor(self._shard(R), device=device, dtype=torch.long)
+        poses_in = data_TCO_input.poses.to(device=device, dtype=torch.float32)
+        K_all = observation.K[im_all.long()].float()
+        keys = ("poses", "poses_input", "K_crop", "boxes_rend", "boxes_crop")
+        acc: Dict[int, Dict[str, list]] = {n: {k: [] for k in keys} for n in range(1, n_iterations + 1)}
+        all_outputs = []
+        model_time = 0.0
+        ev = None
+        if cuda_timer:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for s in range(0, rows.numel(), chunk):
+            r = rows[s : s + chunk]
+            labels_ = [labels_all[i] for i in r.tolist()]
+            outputs_ = self.refiner_model(images=observation.images, K=K_all[r], TCO=poses_in[r], n_iterations=n_iterations,
+                                          labels=labels_, im_ids=im_all[r], materialize=keep_all_outputs, **refiner_kwargs)
+            if keep_all_outputs:
+                all_outputs.append(outputs_)
+            for n in range(1, n_iterations + 1):
+                o = outputs_[f"iteration={n}"]
+                a = acc[n]
+                a["poses"].append(o.TCO_output)
+                a["poses_input"].append(o.TCO_input)
+                a["K_crop"].append(o.K_crop)
+                a["boxes_rend"].append(o.boxes_rend)
+                a["boxes_crop"].append(o.boxes_crop)
+        if cuda_timer:
+            ev[1].record()
+            torch.cuda.synchronize()
+            model_time = ev[0].elapsed_time(ev[1]) / 1000.0
+        preds = dict()
+        for n in range(1, n_iterations + 1):
+            a = acc[n]
+            packed = torch.cat([torch.cat(a["poses"]).flatten(1), torch.cat(a["poses_input"]).flatten(1), torch.cat(a["K_crop"]).flatten(1),
+                                torch.cat(a["boxes_rend"]), torch.cat(a["boxes_crop"])], dim=1) if rows.numel() else torch.zeros(0, 49, device=device)
+            packed = self._gather(packed, R)
+            preds[f"iteration={n}"] = PandasTensorCollection(
+                df, poses=packed[:, 0:16].reshape(R, 4, 4).contiguous(), poses_input=packed[:, 16:32].reshape(R, 4, 4).contiguous(),
+                K_crop=packed[:, 32:41].reshape(R, 3, 3).contiguous(), K=K_all, boxes_rend=packed[:, 41:45].contiguous(),
+                boxes_crop=packed[:, 45:49].contiguous())
+        elapsed = time.time() - start
+        extra_data = {"n_iterations": n_iterations, "outputs": all_outputs, "model_time": model_time, "time": elapsed}
+        return preds, extra_data
+
+    # -- scoring --------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_scoring_model(self, observation: ObservationTensor, data_TCO: PoseEstimatesType, cuda_timer: bool = False,
+                              return_debug_data: bool = False) -> Tuple[PoseEstimatesType, dict]:
+        """Adds 'pose_logit' / 'pose_score' to data_TCO.infos (modifies the collection in place, :217-322)."""
+        start = time.time()
+        assert self.coarse_model is not None
+        device = observation.images.device
+        df = data_TCO.infos
+        R = len(df)
+        labels_all = df["label"].tolist()
+        im_all = torch.as_tensor(df["batch_im_id"].values.astype(np.int32), device=device)
+        rows = torch.as_tensor(self._shard(R), device=device, dtype=torch.long)
+        poses = data_TCO.poses.to(device=device, dtype=torch.float32)
+        K_all = observation.K[im_all.long()].float()
+        chunk = self._chunk(self.bsz_images)
+        logits_l, scores_l, crops, renders = [], [], [], []
+        render_time = model_time = 0.0
+        n_batches = 0
+        for s in range(0, rows.numel(), chunk):
+            r = rows[s : s + chunk]
+            out_ = self.coarse_model.forward_coarse(images=observation.images, K=K_all[r], labels=[labels_all[i] for i in r.tolist()],
+                                                    TCO_input=poses[r], cuda_timer=cuda_timer, return_debug_data=return_debug_data,
+                                                    im_ids=im_all[r])
+            render_time += out_["render_time"]
+            model_time += out_["model_time"]
+            logits_l.append(out_["logits"])
+            scores_l.append(out_["scores"])
+            if return_debug_data:
+                crops.append(out_["images_crop"])
+                renders.append(out_["renders"])
+            n_batches += 1
+        packed = torch.cat([torch.cat(logits_l), torch.cat(scores_l)], dim=1) if rows.numel() else torch.zeros(0, 2, device=device)
+        packed = self._gather(packed, R)
+        logits, scores = packed[:, 0:1].contiguous(), packed[:, 1:2].contiguous()
+        debug_data = dict()
+        if return_debug_data:
+            debug_data = {"images_crop": torch.cat(crops), "renders": torch.cat(renders)}
+        host = packed.cpu().numpy()
+        df["pose_logit"] = host[:, 0]
+        df["pose_score"] = host[:, 1]
+        elapsed = time.time() - start
+        timing_str = f"time: {elapsed:.2f}, model_time: {model_time:.2f}, render_time: {render_time:.2f}"
+        extra_data = {"render_time": render_time, "model_time": model_time, "time": elapsed, "logits": logits, "scores": scores,
+                      "debug": debug_data, "n_batches": n_batches, "timing_str": timing_str}
+        data_TCO.infos = df
+        return data_TCO, extra_data
+
+    @torch.no_grad()
+    def forward_detection_model(self, observation: ObservationTensor, *args: Any, **kwargs: Any) -> DetectionsType:
+        if self.detector_model is None:
+            raise ValueError("no detector model: pass `detections` (the 2D detector is out of the hot-path scope)")
+        return self.detector_model.get_detections(observation, *args, **kwargs)
+
+    def run_depth_refiner(self, observation: ObservationTensor, predictions: PoseEstimatesType) -> Tuple[PoseEstimatesType, dict]:
+        assert self.depth_refiner is not None, "You must specify a depth refiner"
+        return self.depth_refiner.refine_poses(predictions, depth=observation.depth, K=observation.K)
+
+    # -- pipeline -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def run_inference_pipeline(self, observation: ObservationTensor, detections: Optional[DetectionsType] = None,
+                               run_detector: Optional[bool] = None, n_refiner_iterations: int = 5, n_pose_hypotheses: int = 1,
+                               keep_all_refiner_outputs: bool = False, detection_filter_kwargs: Optional[dict] = None,
+                               run_depth_refiner: bool = False, bsz_images: Optional[int] = None, bsz_objects: Optional[int] = None,
+                               cuda_timer: bool = False, coarse_estimates: Optional[PoseEstimatesType] = None
+                               ) -> Tuple[PoseEstimatesType, dict]:
+        timing_str = ""
+        timer = _Timer()
+        if bsz_images is not None:
+            self.bsz_images = bsz_images
+        if bsz_objects is not None:
+            self.bsz_objects = bsz_objects
+        if coarse_estimates is None:
+            assert detections is not None or run_detector, "You must either pass in `detections` or set run_detector=True"
+            if detections is None and run_detector:
+                t = time.time()
+                detections = self.forward_detection_model(observation).cuda()
+                timing_str += f"detection={time.time() - t:.2f}, "
+            assert detections is not None
+            detections = add_instance_id(detections)
+            if detection_filter_kwargs is not None:
+                detections = filter_detections(detections, **detection_filter_kwargs)
+            data_TCO_coarse, coarse_extra_data = self.forward_coarse_model(observation=observation, detections=detections,
+                                                                           cuda_timer=cuda_timer)
+            timing_str += f"coarse={coarse_extra_data['time']:.2f}, "
+            data_TCO_filtered = self.filter_pose_estimates(data_TCO_coarse, top_K=n_pose_hypotheses, filter_field="coarse_logit")
+        else:
+            data_TCO_coarse = coarse_estimates
+            coarse_extra_data = None
+            data_TCO_filtered = coarse_estimates
+        preds, refiner_extra_data = self.forward_refiner(observation, data_TCO_filtered, n_iterations=n_refiner_iterations,
+                                                         keep_all_outputs=keep_all_refiner_outputs, cuda_timer=cuda_timer)
+        data_TCO_refined = preds[f"iteration={n_refiner_iterations}"]
+        timing_str += f"refiner={refiner_extra_data['time']:.2f}, "
+        data_TCO_scored, scoring_extra_data = self.forward_scoring_model(observation, data_TCO_refined, cuda_timer=cuda_timer)
+        timing_str += f"scoring={scoring_extra_data['time']:.2f}, "
+        data_TCO_final_scored = self.filter_pose_estimates(data_TCO_scored, top_K=1, filter_field="pose_logit")
+        if run_depth_refiner:
+            t = time.time()
+            data_TCO_depth_refiner, _ = self.run_depth_refiner(observation, data_TCO_final_scored)
+            data_TCO_final = data_TCO_depth_refiner
+            timing_str += f"depth refiner={time.time() - t:.2f}"
+        else:
+            data_TCO_depth_refiner = None
+            data_TCO_final = data_TCO_final_scored
+        total = timer.elapsed()
+        timing_str = f"total={total:.2f}, {timing_str}"
+        extra_data: dict = dict()
+        extra_data["coarse"] = {"preds": data_TCO_coarse, "data": coarse_extra_data}
+        extra_data["coarse_filter"] = {"preds": data_TCO_filtered}
+        extra_data["refiner_all_hypotheses"] = {"preds": preds, "data": refiner_extra_data}
+        extra_data["scoring"] = {"preds": data_TCO_scored, "data": scoring_extra_data}
+        extra_data["refiner"] = {"preds": data_TCO_final_scored, "data": refiner_extra_data}
+        extra_data["timing_str"] = timing_str
+        extra_data["time"] = total
+        if run_depth_refiner:
+            extra_data["depth_refiner"] = {"preds": data_TCO_depth_refiner}
+        return data_TCO_final, extra_data
+
+    def filter_pose_estimates(self, data_TCO: PoseEstimatesType, top_K: int, filter_field: str, ascending: bool = False) -> PoseEstimatesType:
+        """Keep the top_K rows per (batch_im_id, label, instance_id) by `filter_field` (:643-667).  The sort is made
+        stable so that exact ties resolve deterministically (lowest row first); the reference's default quicksort leaves
+        tie order unspecified."""
+        df = data_TCO.infos
+        group_cols = ["batch_im_id", "label", "instance_id"]
+        df = df.sort_values(filter_field, ascending=ascending, kind="stable").groupby(group_cols).head(top_K)
+        return data_TCO[df.index.tolist()]
+
+
+# name used by BASELINE.json's north_star; the reference snapshot only has PoseEstimator
+CoarseRefinePoseEstimator = PoseEstimator

@@ -1,0 +1,363 @@
+"""PosePredictor: one render-and-compare step (crop -> multiview cameras -> render -> CNN -> pose update).
+
+Public surface = the reference's src/megapose/models/pose_rigid.py:81-708 (`forward`, `forward_coarse`,
+`forward_coarse_tensor`, `crop_inputs`, `compute_crops_multiview`, `update_pose`, `net_forward`,
+`render_images_multiview`, `normalize_images`, attributes cfg-driven).  The module only HOSTS the parameter graph
+(state_dict keys identical to the reference checkpoints); every computation is a call into
+libmp_engine.so: the crop, the rasteriser and the depth normalisation write straight into one padded-NHWC CNN input
+tensor, the backbone executor consumes it, and the pose math runs as fused device kernels -- nothing leaves the GPU and
+nothing synchronises.
+"""
+from __future__ import annotations
+
+import time
+from collections import defaultdict
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import engine as eng
+from .mesh_db import BatchedMeshes
+from .renderer import Panda3dBatchRenderer
+from .types import Panda3dLightData, PosePredictorOutput, Resolution, make_scene_lights
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Parameter containers: module trees whose state_dict keys equal the reference backbones'.  They are never called.
+# ----------------------------------------------------------------------------------------------------------------
+class _PlainBlock(nn.Module):  # torchvision BasicBlock parameter layout
+    def __init__(self, inplanes: int, planes: int, downsample: bool):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, bias=False), nn.BatchNorm2d(planes))
+
+
+class _PreActBlock(nn.Module):  # wide_resnet BasicBlockV2 parameter layout
+    def __init__(self, inplanes: int, planes: int, downsample: bool):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(inplanes)
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, bias=False)
+        if downsample:
+            self.downsample = nn.Conv2d(inplanes, planes, 1, bias=False)
+
+
+class HipBackbone(nn.Module):
+    """Hosts the weights of vanilla_resnet34 / WideResNet34 / WideResNet18 (pose_models_cfg.py:106-118)."""
+
+    def __init__(self, backbone_str: str, n_inputs: int):
+        super().__init__()
+        if backbone_str not in eng.BACKBONE_KINDS:
+            raise ValueError("Unknown backbone", backbone_str)
+        self.backbone_str = backbone_str
+        self.n_inputs = n_inputs
+        self.n_features = 512
+        wide = backbone_str != "vanilla_resnet34"
+        self.conv1 = nn.Conv2d(n_inputs, 64, 5 if wide else 7, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        counts = [2, 2, 2, 2] if backbone_str == "resnet18" else [3, 4, 6, 3]
+        inplanes = 64
+        for s, (planes, n) in enumerate(zip([64, 128, 256, 512], counts)):
+            blocks = []
+            for i in range(n):
+                down = i == 0 and (s > 0 or inplanes != planes)
+                blocks.append((_PreActBlock if wide else _PlainBlock)(inplanes, planes, down))
+                inplanes = planes
+            setattr(self, f"layer{s + 1}", nn.Sequential(*blocks))
+        if not wide:
+            self.fc = nn.Linear(512, 512)
+
+    def forward(self, x):  # pragma: no cover - the graph is executed by the HIP engine through PosePredictor
+        raise RuntimeError("HipBackbone only hosts parameters; use PosePredictor.net_forward (HIP engine)")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class PosePredictor(nn.Module):
+    def __init__(
+        self,
+        backbone: HipBackbone,
+        renderer: Panda3dBatchRenderer,
+        mesh_db: BatchedMeshes,
+        render_size: Resolution = (240, 320),
+        multiview_type: str = "front_3views",
+        views_inplane_rotations: bool = False,
+        remove_TCO_rendering: bool = False,
+        predict_pose_update: bool = True,
+        predict_rendered_views_logits: bool = False,
+        render_normals: bool = True,
+        n_rendered_views: int = 1,
+        input_depth: bool = False,
+        render_depth: bool = False,
+        depth_normalization_type: Optional[str] = None,
+    ):
+        super().__init__()
+        if views_inplane_rotations or remove_TCO_rendering:
+            raise NotImplementedError("views_inplane_rotations / remove_TCO_rendering are not used by the released models")
+        if multiview_type in ("front_3views",):
+            multiview_type = "TCO+front_3views"  # pose_models_cfg.py:51-52
+        if n_rendered_views == 1:
+            self._mv_mode = 0
+        elif multiview_type == "TCO+front_3views" and n_rendered_views == 4:
+            self._mv_mode = 1
+        else:
+            raise NotImplementedError(f"multiview_type={multiview_type} with {n_rendered_views} views")
+        self.backbone = backbone
+        self.renderer = renderer
+        self.mesh_db = mesh_db
+        self.render_size = render_size
+        self.n_rendered_views = n_rendered_views
+        self.input_depth = input_depth
+        self.multiview_type = multiview_type
+        self.views_inplane_rotations = views_inplane_rotations
+        self.render_normals = render_normals
+        self.render_depth = render_depth
+        self.depth_normalization_type = depth_normalization_type
+        self.predict_rendered_views_logits = predict_rendered_views_logits
+        self.remove_TCO_rendering = remove_TCO_rendering
+        self.predict_pose_update = predict_pose_update
+
+        n_features = backbone.n_features
+        self.heads: Dict[str, nn.Linear] = dict()
+        if self.predict_pose_update:
+            self._pose_dim = 9
+            self.pose_fc = nn.Linear(n_features, self._pose_dim, bias=True)
+            self.heads["pose"] = self.pose_fc
+        if self.predict_rendered_views_logits:
+            self.views_logits_head = nn.Linear(n_features, self.n_rendered_views, bias=True)
+            self.heads["renderings_logits"] = self.views_logits_head
+        if len(self.heads) != 1:
+            raise NotImplementedError("exactly one head (pose update or view logits) is supported, as in the released models")
+
+        self._n_input_channels = 3 + (1 if input_depth else 0)
+        self._n_single_render_channels = 3 + (3 if render_normals else 0) + (1 if render_depth else 0)
+        n_in = self._n_input_channels + self._n_single_render_channels * n_rendered_views
+        if n_in != backbone.n_inputs:
+            raise ValueError(f"backbone has {backbone.n_inputs} input channels, configuration needs {n_in}")
+        self.debug = False
+        self.timing_dict: Dict[str, float] = defaultdict(float)
+        self._engine_bb: Optional[eng.Backbone] = None
+        self._x: Optional[torch.Tensor] = None
+        self._x_rows = 0
+        self._label_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    # -- engine plumbing -----------------------------------------------------------------------------------------
+    def load_state_dict(self, *args, **kwargs):
+        self._engine_bb = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _backbone_engine(self) -> eng.Backbone:
+        if self._engine_bb is None:
+            head, n_out = ("pose", 9) if self.predict_pose_update else ("logits", self.n_rendered_views)
+            self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict())
+        return self._engine_bb
+
+    def _x_buffer(self, rows: int, device) -> torch.Tensor:
+        bb = self._backbone_engine()
+        h, w = self.render_size
+        if self._x is None or self._x_rows < rows or self._x.device != device:
+            self._x = None
+            self._x = eng.padded_nhwc(rows, h, w, bb.c_in_p, bb.in_border, device)
+            self._x_rows = rows
+        return self._x
+
+    def _x_geometry(self):
+        bb = self._backbone_engine()
+        h, w = self.render_size
+        Wp, Hp, Cp, B = w + 2 * bb.in_border, h + 2 * bb.in_border, bb.c_in_p, bb.in_border
+        return Hp * Wp * Cp, Wp * Cp, Cp, (B * Wp + B) * Cp  # stride_row, stride_y, stride_x, interior offset
+
+    def _ids(self, labels: Sequence[str], device) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = (tuple(labels), str(device))
+        hit = self._label_cache.get(key)
+        if hit is None:
+            pts_ids = torch.tensor(self.mesh_db.ids(labels), dtype=torch.int32, device=device)
+            ren_ids = self.renderer.label_ids(labels, device)
+            if len(self._label_cache) > 64:
+                self._label_cache.clear()
+            self._label_cache[key] = hit = (pts_ids, ren_ids)
+        return hit
+
+    def _lights(self) -> List[Panda3dLightData]:
+        if self.render_normals:
+            return [Panda3dLightData(light_type="ambient", color=(1.0, 1.0, 1.0, 1.0))]  # pose_rigid.py:374-376
+        return make_scene_lights()
+
+    def _nchw_view(self, rows: int, c0: int, c1: int) -> torch.Tensor:
+        bb = self._backbone_engine()
+        h, w = self.render_size
+        return eng.padded_view(self._x, self._x_rows, h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
+
+    # -- the fused step ------------------------------------------------------------------------------------------
+    def _step(self, images: torch.Tensor, im_ids: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO_in: torch.Tensor,
+              want_sigmoid: bool):
+        """images [n_im,C,H,W] (C already trimmed to the model's input channels), im_ids [b] row -> image.
+        Returns dict of device tensors; the CNN input stays in self._x."""
+        device = TCO_in.device
+        b = TCO_in.shape[0]
+        V = self.n_rendered_views
+        h, w = self.render_size
+        H, W = images.shape[-2:]
+        pts_ids, ren_ids = self._ids(labels, device)
+        points = self.mesh_db.sampled_points(2000)
+        TCO_n, tCR, TCV_O, KV_crop, boxes_rend, boxes_crop = eng.pose_prepare(
+            TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode, (H, W), (h, w), 1.4)
+        x = self._x_buffer(b, device)
+        s_row, s_y, s_x, off = self._x_geometry()
+        eng.crop_roi_align(images, im_ids, boxes_crop, h, w, x, s_row, s_y, s_x, 0, off)
+        nin, nper = self._n_input_channels, self._n_single_render_channels
+        t0 = time.time()
+        view_ids = ren_ids.repeat_interleave(V) if V > 1 else ren_ids
+        self.renderer.render_into(view_ids, TCV_O.view(b * V, 4, 4), KV_crop.view(b * V, 3, 3), self._lights(), (h, w), x, s_row,
+                                  s_y, s_x, nin, nin + 3 if self.render_normals else -1,
+                                  nin + (6 if self.render_normals else 3) if self.render_depth else -1, off,
+                                  views_per_item=V, stride_view=nper)
+        render_time = time.time() - t0
+        mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
+        bb = self._backbone_engine()
+        depth_ch = []
+        if self.input_depth:
+            depth_ch.append(3)
+        if self.render_depth:
+            d0 = nin + (6 if self.render_normals else 3)
+            depth_ch += [d0 + nper * v for v in range(V)]
+        if depth_ch and mode:
+            eng.normalize_depth(x, b, h, w, bb.in_border, bb.c_in_p, depth_ch, tCR, mode)
+        n_out = bb.n_out
+        out = torch.empty(b, n_out, dtype=torch.float32, device=device)
+        sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
+        bb.forward(x, b, h, w, out, sig)
+        return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,
+                    sigmoid=sig, render_time=render_time)
+
+    def _prep_images(self, images: torch.Tensor) -> torch.Tensor:
+        if not self.input_depth:
+            images = images[:, :3]  # pose_rigid.py:511-513, :669-671
+        return images
+
+    # -- reference API -----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, K: torch.Tensor, labels: List[str], TCO: torch.Tensor, n_iterations: int = 1,
+                random_ambient_light: bool = False, im_ids: Optional[torch.Tensor] = None,
+                materialize: bool = True) -> Dict[str, PosePredictorOutput]:
+        """Same contract as the reference forward (pose_rigid.py:498-604).  Engine extensions: `im_ids` lets several rows
+        share one observation frame (images is then [n_im,C,H,W] and K stays per-row); `materialize=False` skips the
+        clones of the crops/renders (they stay valid only until the next step)."""
+        if random_ambient_light:
+            raise NotImplementedError("random_ambient_light is a training-time augmentation")
+        images = self._prep_images(images)
+        bsz = TCO.shape[0]
+        assert TCO.shape == (bsz, 4, 4) and K.shape == (bsz, 3, 3) and len(labels) == bsz
+        device = TCO.device
+        if im_ids is None:
+            assert images.shape[0] == bsz
+            im_ids = torch.arange(bsz, dtype=torch.int32, device=device)
+        outputs: Dict[str, PosePredictorOutput] = dict()
+        TCO_input = TCO
+        nin = self._n_input_channels
+        for n in range(n_iterations):
+            st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=False)
+            K_crop = st["KV_crop"][:, 0]
+            if self.predict_pose_update:
+                TCO_output = eng.pose_update(st["TCO_n"], st["KV_crop"], st["out"], st["tCR"], 9 * self.n_rendered_views)
+                network_outputs = {"pose": st["out"]}
+                renderings_logits = torch.empty(bsz, self.n_rendered_views, dtype=TCO.dtype, device=device)
+            else:
+                TCO_output = st["TCO_n"].clone()
+                network_outputs = {"renderings_logits": st["out"]}
+                renderings_logits = st["out"]
+            renders = images_crop = None
+            if materialize:
+                images_crop = self._nchw_view(bsz, 0, nin).clone()
+                renders = self._nchw_view(bsz, nin, self.backbone.n_inputs).clone()
+            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
+                renders=renders, images_crop=images_crop, TCO_input=st["TCO_n"], TCO_output=TCO_output, TCV_O_input=st["TCV_O"],
+                tCR=st["tCR"], labels=labels, K=K, K_crop=K_crop, KV_crop=st["KV_crop"], network_outputs=network_outputs,
+                boxes_rend=st["boxes_rend"], boxes_crop=st["boxes_crop"], renderings_logits=renderings_logits,
+                timing_dict={"render": st["render_time"]})
+            TCO_input = TCO_output
+        return outputs
+
+    @torch.no_grad()
+    def forward_coarse(self, images: torch.Tensor, K: torch.Tensor, labels: List[str], TCO_input: torch.Tensor,
+                       cuda_timer: bool = False, return_debug_data: bool = False,
+                       im_ids: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        """pose_rigid.py:634-708: logits/scores [b,1] of each hypothesis."""
+        assert self.predict_rendered_views_logits, "Method only valid if coarse classification model"
+        images = self._prep_images(images)
+        bsz = TCO_input.shape[0]
+        assert TCO_input.shape == (bsz, 4, 4) and K.shape == (bsz, 3, 3) and len(labels) == bsz
+        if im_ids is None:
+            assert images.shape[0] == bsz
+            im_ids = torch.arange(bsz, dtype=torch.int32, device=TCO_input.device)
+        ev0 = ev1 = None
+        if cuda_timer:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True)
+        elapsed = 0.0
+        if cuda_timer:
+            ev1.record()
+            torch.cuda.synchronize()
+            elapsed = ev0.elapsed_time(ev1) / 1000.0
+        out = {"logits": st["out"], "scores": st["sigmoid"], "time": elapsed, "render_time": st["render_time"], "model_time": elapsed,
+               "TCO_n": st["TCO_n"], "K_crop": st["KV_crop"][:, 0], "boxes_rend": st["boxes_rend"], "boxes_crop": st["boxes_crop"]}
+        if return_debug_data:
+            nin = self._n_input_channels
+            out["images_crop"] = self._nchw_view(bsz, 0, nin).clone()
+            out["renders"] = self._nchw_view(bsz, nin, self.backbone.n_inputs).clone()
+        return out
+
+    @torch.no_grad()
+    def net_forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """pose_rigid.py:314-334 on an already assembled NCHW input [b, n_inputs, h, w] (API-compat path: one layout copy)."""
+        bb = self._backbone_engine()
+        b, c, h, w = x.shape
+        assert c == self.backbone.n_inputs
+        buf = eng.padded_nhwc(b, h, w, bb.c_in_p, bb.in_border, x.device)
+        eng.padded_view(buf, b, h, w, bb.c_in_p, bb.in_border)[..., :c] = x.permute(0, 2, 3, 1)
+        out = torch.empty(b, bb.n_out, dtype=torch.float32, device=x.device)
+        bb.forward(buf, b, h, w, out)
+        return {"pose" if self.predict_pose_update else "renderings_logits": out}
+
+    @torch.no_grad()
+    def forward_coarse_tensor(self, x: torch.Tensor, cuda_timer: bool = False) -> Dict[str, Union[torch.Tensor, float]]:
+        assert self.predict_rendered_views_logits, "Method only valid if coarse classification model"
+        logits = self.net_forward(x)["renderings_logits"]
+        return {"logits": logits, "scores": torch.sigmoid(logits), "time": 0.0}
+
+    @torch.no_grad()
+    def crop_inputs(self, images: torch.Tensor, K: torch.Tensor, TCO: torch.Tensor, tCR: torch.Tensor, labels: List[str]):
+        """pose_rigid.py:180-247 -> (images_cropped, K_crop, boxes_rend, boxes_crop).  tCR must be TCO's translation
+        (the only way the hot path calls it)."""
+        bsz = TCO.shape[0]
+        pts_ids, _ = self._ids(labels, TCO.device)
+        h, w = self.render_size
+        _, _, _, KV, brend, bcrop = eng.pose_prepare(TCO, K, pts_ids, self.mesh_db.sampled_points(2000), 2000, 200, 1, 0,
+                                                     tuple(images.shape[-2:]), (h, w), 1.4)
+        C = images.shape[1]
+        out = torch.empty(bsz, h, w, C, dtype=torch.float32, device=TCO.device)
+        eng.crop_roi_align(images, torch.arange(bsz, dtype=torch.int32, device=TCO.device), bcrop, h, w, out, h * w * C, w * C, C, 0)
+        return out.permute(0, 3, 1, 2), KV[:, 0], brend, bcrop
+
+    @torch.no_grad()
+    def update_pose(self, TCO: torch.Tensor, K_crop: torch.Tensor, pose_outputs: torch.Tensor, tCR: torch.Tensor) -> torch.Tensor:
+        assert pose_outputs.shape[-1] == 9
+        return eng.pose_update(TCO, K_crop.contiguous(), pose_outputs, tCR, 9)
+
+    @torch.no_grad()
+    def render_images_multiview(self, labels: List[str], TCV_O: torch.Tensor, KV: torch.Tensor, random_ambient_light: bool = False):
+        """pose_rigid.py:336-408: [bsz, n_views*n_channels, H, W]"""
+        bsz, n_views = TCV_O.shape[:2]
+        labels_mv = [l for l in labels for _ in range(n_views)]
+        data = self.renderer.render(labels=labels_mv, TCO=TCV_O.flatten(0, 1), K=KV.flatten(0, 1), render_mask=False,
+                                    resolution=self.render_size, render_normals=self.render_normals, render_depth=self.render_depth,
+                                    light_datas=[self._lights() for _ in labels_mv])
+        cat = [data.rgbs] + ([data.normals] if self.render_normals else []) + ([data.depths] if self.render_depth else [])
+        renders = torch.cat(cat, dim=1)
+        return renders.view(bsz, n_views, renders.shape[1], *renders.shape[-2:]).flatten(1, 2)

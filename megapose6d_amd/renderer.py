@@ -1,0 +1,126 @@
+"""Panda3dBatchRenderer: drop-in for the reference's batch renderer, backed by the on-device HIP rasteriser.
+
+Same constructor and `render(...)`/`stop()` signatures as
+/root/reference/src/megapose/panda3d_renderer/panda3d_batch_renderer.py:153-340.  Differences by design: no worker
+processes, no OpenGL, no queues, no host round trip -- inputs are read on the device and the outputs are device
+tensors.  `render_into` is the zero-copy path the pose models use: it rasterises straight into a slice of the CNN
+input tensor.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import engine as eng
+from . import mesh_io
+from .types import BatchRenderOutput, Panda3dLightData, Resolution
+
+
+def _lights_key(lights: Sequence[Panda3dLightData]):
+    return tuple((l.light_type, tuple(float(c) for c in l.color[:3]), tuple(l.direction) if l.direction else None) for l in lights)
+
+
+def _to_engine_lights(lights: Sequence[Panda3dLightData]):
+    amb = np.zeros(3, np.float64)
+    dirs, cols = [], []
+    axis = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    for l in lights:
+        if l.light_type == "ambient":
+            amb += np.asarray(l.color[:3], np.float64)
+        elif l.light_type == "point":
+            d = l.direction if l.direction is not None else axis[len(dirs) % 6]  # make_scene_lights order
+            dirs.append(tuple(float(x) for x in d))
+            cols.append(tuple(float(c) for c in l.color[:3]))
+        else:
+            raise NotImplementedError(l.light_type)
+    return eng.make_lights(tuple(float(a) for a in amb), dirs, cols)
+
+
+class Panda3dBatchRenderer:
+    def __init__(self, object_dataset, n_workers: int = 8, preload_cache: bool = True, split_objects: bool = False,
+                 normals_eye_convention: str = "panda"):
+        assert n_workers >= 1
+        self._object_dataset = object_dataset
+        self._n_workers = n_workers          # accepted for API compatibility; there are no workers
+        self._split_objects = split_objects
+        self._labels = [obj.label for obj in object_dataset.list_objects]
+        self._label_to_id: Dict[str, int] = {l: i for i, l in enumerate(self._labels)}
+        self._gl_eye = normals_eye_convention == "gl"
+        self._mesh_db: Optional[eng.MeshDB] = None
+        self._is_closed = False
+        if preload_cache:
+            self._ensure_db()
+
+    # -- internals -----------------------------------------------------------------------------------
+    def _ensure_db(self) -> eng.MeshDB:
+        if self._is_closed:
+            raise RuntimeError("renderer is stopped")
+        if self._mesh_db is None:
+            meshes = [mesh_io.load_rigid_object(o) for o in self._object_dataset.list_objects]
+            self._mesh_db = eng.MeshDB(meshes)
+        return self._mesh_db
+
+    def label_ids(self, labels: Sequence[str], device) -> torch.Tensor:
+        return torch.tensor([self._label_to_id[l] for l in labels], dtype=torch.int32, device=device)  # KeyError like :243
+
+    def render_into(self, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, lights: Sequence[Panda3dLightData],
+                    resolution: Resolution, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int,
+                    c_normals: int, c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0) -> None:
+        db = self._ensure_db()
+        flags = (eng.RASTER_NORMALS if c_normals >= 0 else 0) | (eng.RASTER_DEPTH if c_depth >= 0 else 0)
+        if self._gl_eye:
+            flags |= eng.RASTER_NORMALS_GL
+        h, w = resolution
+        eng.raster_render(db, mesh_ids, TCO, K, h, w, flags, _to_engine_lights(lights), out, stride_v, stride_y, stride_x, c_rgb,
+                          c_normals, c_depth, out_offset_floats, views_per_item, stride_view)
+
+    # -- reference API -----------------------------------------------------------------------------------
+    def render(self, labels: List[str], TCO: torch.Tensor, K: torch.Tensor, light_datas: List[List[Panda3dLightData]],
+               resolution: Resolution, render_depth: bool = False, render_mask: bool = False,
+               render_normals: bool = False) -> BatchRenderOutput:
+        if render_mask:
+            raise NotImplementedError
+        bsz = TCO.shape[0]
+        assert TCO.shape == (bsz, 4, 4)
+        assert K.shape == (bsz, 3, 3)
+        assert len(labels) == bsz and len(light_datas) == bsz
+        device = TCO.device if TCO.is_cuda else torch.device("cuda")
+        TCO = TCO.detach().to(device=device, dtype=torch.float32)
+        K = K.detach().to(device=device, dtype=torch.float32)
+        h, w = resolution
+        C = 8  # rgb 0..2, normals 3..5, depth 6
+        out = torch.empty(bsz, h, w, C, dtype=torch.float32, device=device)
+        mesh_ids = self.label_ids(labels, device)
+        # one launch per distinct light set (the hot path always passes identical lights for the whole batch)
+        groups: Dict[tuple, List[int]] = {}
+        for i, ld in enumerate(light_datas):
+            groups.setdefault(_lights_key(ld), []).append(i)
+        c_n = 3 if render_normals else -1
+        c_d = 6 if render_depth else -1
+        if len(groups) == 1:
+            self.render_into(mesh_ids, TCO, K, light_datas[0], resolution, out, h * w * C, w * C, C, 0, c_n, c_d)
+        else:
+            for idx in groups.values():
+                sel = torch.as_tensor(idx, device=device)
+                tmp = torch.empty(len(idx), h, w, C, dtype=torch.float32, device=device)
+                self.render_into(mesh_ids[sel], TCO[sel], K[sel], light_datas[idx[0]], resolution, tmp, h * w * C, w * C, C, 0, c_n, c_d)
+                out[sel] = tmp
+        nchw = out.permute(0, 3, 1, 2)  # views with NCHW shape; memory stays NHWC
+        return BatchRenderOutput(rgbs=nchw[:, 0:3], normals=nchw[:, 3:6] if render_normals else None,
+                                 depths=nchw[:, 6:7] if render_depth else None)
+
+    def stop(self) -> None:
+        if self._is_closed:
+            return
+        if self._mesh_db is not None:
+            self._mesh_db.close()
+            self._mesh_db = None
+        self._is_closed = True
+
+    def __del__(self) -> None:
+        try:
+            self.stop()
+        except Exception:
+            pass

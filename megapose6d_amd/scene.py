@@ -1,0 +1,79 @@
+"""Synthetic scenes + model assembly shared by bench.py, smoke() and the tests (product side: no oracle imports).
+The observation is rendered by the engine's own rasteriser over a uniform-noise background."""
+from __future__ import annotations
+
+import tempfile
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import synthetic as syn
+from .load_model import build_pose_model, make_detections
+from .mesh_db import MeshDataBase
+from .pose_estimator import PoseEstimator
+from .renderer import Panda3dBatchRenderer
+from .types import ObservationTensor, Panda3dLightData
+
+
+def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
+                    seeds=(11, 12), **est_kwargs) -> PoseEstimator:
+    """Seeded random-weight coarse + refiner models in the released recipes' structure, on the HIP engine."""
+    renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
+    mesh_db = MeshDataBase.from_object_ds(object_dataset).batched().cuda()
+    models = {}
+    for role, seed in zip(("coarse", "refiner"), seeds):
+        cfg = syn.make_cfg(role, backbone, rgbd=(rgbd and role == "refiner"))
+        head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
+        sd = syn.make_state_dict(backbone, syn.n_inputs_for(cfg), head, n_out, seed=seed)
+        models[role] = build_pose_model(cfg, sd, renderer, mesh_db)
+    return PoseEstimator(refiner_model=models["refiner"], coarse_model=models["coarse"], SO3_grid_size=SO3_grid_size, **est_kwargs)
+
+
+def render_observation(renderer: Panda3dBatchRenderer, labels: List[str], poses: np.ndarray, K: np.ndarray, seed: int = 0,
+                       with_depth: bool = False, hw=(480, 640)) -> Tuple[torch.Tensor, np.ndarray]:
+    """One 640x480 frame containing all objects (painter's order by depth buffer) -> images [1,C,H,W] on the GPU, bboxes."""
+    h, w = hw
+    dev = torch.device("cuda")
+    n = len(labels)
+    Kt = torch.from_numpy(np.repeat(K[None].astype(np.float32), n, 0)).to(dev)
+    out = renderer.render(labels, torch.from_numpy(poses.astype(np.float32)).to(dev), Kt,
+                          [[Panda3dLightData("ambient", (1.0, 1.0, 1.0, 1.0))]] * n, (h, w), render_depth=True, render_normals=False)
+    rgb, dep = out.rgbs, out.depths[:, 0]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = (torch.rand(3, h, w, generator=g) * 0.3).to(dev)
+    zbuf = torch.zeros(h, w, device=dev)
+    bboxes = []
+    for i in range(n):
+        m = dep[i] > 0
+        closer = m & ((zbuf == 0) | (dep[i] < zbuf))
+        img = torch.where(closer[None], rgb[i], img)
+        zbuf = torch.where(closer, dep[i], zbuf)
+        ys, xs = torch.nonzero(m, as_tuple=True)
+        bboxes.append([xs.min().item(), ys.min().item(), xs.max().item(), ys.max().item()])
+    img = torch.round(img * 255) / 255
+    if with_depth:
+        gd = torch.Generator(device="cpu").manual_seed(seed + 1)
+        noise = (torch.randn(h, w, generator=gd) * 0.002).to(dev)
+        d = torch.where(zbuf > 0, zbuf + noise, zbuf)
+        drop = (torch.rand(h, w, generator=gd) < 0.05).to(dev)
+        d = torch.where(drop, torch.zeros_like(d), d)
+        img = torch.cat([img, d[None]], 0)
+    return img[None].contiguous(), np.asarray(bboxes, np.float32)
+
+
+def make_scene(n_objects: int = 1, seed: int = 0, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
+               tmp_dir: Optional[str] = None, **est_kwargs):
+    """-> (estimator, observation, detections, gt_poses)"""
+    tmp = Path(tmp_dir or tempfile.mkdtemp(prefix="mp_scene_"))
+    ds = syn.make_object_dataset(tmp, n_objects=n_objects, seed=seed)
+    est = build_estimator(ds, backbone, rgbd, SO3_grid_size, **est_kwargs)
+    rng = np.random.RandomState(seed + 100)
+    labels = [o.label for o in ds.list_objects]
+    poses = np.stack([syn.random_pose(rng, z_range=(0.45, 0.7), xy_frac=0.12 if n_objects == 1 else 0.3) for _ in labels])
+    K = syn.K_EXAMPLE.astype(np.float32)
+    images, bboxes = render_observation(est.coarse_model.renderer, labels, poses, K, seed=seed, with_depth=rgbd)
+    obs = ObservationTensor(images, torch.from_numpy(K)[None].cuda())
+    det = make_detections(labels, bboxes).cuda()
+    return est, obs, det, poses

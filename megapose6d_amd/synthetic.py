@@ -210,7 +210,7 @@ def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: i
     else:
         raise ValueError(backbone_str)
     if head == "pose":
-        _linear(sd, g, "pose_fc", 9, 512, scale=0.02)
+        _linear(sd, g, "pose_fc", 9, 512, scale=0.001)
         sd["pose_fc.bias"] = sd["pose_fc.bias"] + torch.tensor([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0])
     else:
         _linear(sd, g, "views_logits_head", n_out, 512)
@@ -225,11 +225,11 @@ def make_cfg(role: str, backbone_str: str = "vanilla_resnet34", rgbd: bool = Fal
         return SimpleNamespace(backbone_str=backbone_str, n_rendered_views=1, multiview_type="TCO", views_inplane_rotations=False,
                                render_normals=True, render_depth=False, input_depth=False, predict_rendered_views_logits=True,
                                remove_TCO_rendering=False, predict_pose_update=False, depth_normalization_type="tCR_scale_clamp_center",
-                               renderer="panda3d")
+                               depth_augmentation=False, renderer="panda3d")
     return SimpleNamespace(backbone_str=backbone_str, n_rendered_views=4, multiview_type="TCO+front_3views", views_inplane_rotations=False,
                            render_normals=True, render_depth=rgbd, input_depth=rgbd, predict_rendered_views_logits=False,
                            remove_TCO_rendering=False, predict_pose_update=True, depth_normalization_type="tCR_scale_clamp_center",
-                           renderer="panda3d")
+                           depth_augmentation=False, renderer="panda3d")
 
 
 def n_inputs_for(cfg) -> int:

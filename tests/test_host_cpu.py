@@ -1,0 +1,180 @@
+"""CPU: host logic, the C-ABI surface (load + symbols, no compute), the rasteriser oracle's analytic properties,
+and the world_size-2 gloo path of the row sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from megapose6d_amd import _lib
+
+    header = (ROOT / "include" / "mp_engine.h").read_text()
+    declared = set(re.findall(r"\b(mp_[A-Za-z0-9_]+)\s*\(", header))
+    declared -= {"mp_stream"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()  # raises if the .so is missing or a symbol does not resolve
+    assert lib.mp_version() >= 100
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mp_[A-Za-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from megapose6d_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("MP_ENGINE_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EngineError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+def test_conv_weight_packing_layout():
+    """host-side packing: [nblk][kh][chunk][BN][32] with (kw,c) runs, zero padded"""
+    from megapose6d_amd import _lib
+
+    lib = _lib.load()
+    Cout, Cin, K, Cp = 64, 9, 7, 12
+    w = np.random.RandomState(0).randn(Cout, Cin, K, K).astype(np.float32)
+    scale = np.random.RandomState(1).rand(Cout).astype(np.float32) + 0.5
+    n = lib.mp_conv_packed_floats(Cp, Cout, K, K)
+    cpr = -(-K * Cp // 32)
+    assert n == 1 * K * cpr * 64 * 32
+    out = np.empty(n, np.float32)
+    _lib.check(lib.mp_conv_pack_weights(w.ctypes.data, Cout, Cin, K, K, Cp, scale.ctypes.data, out.ctypes.data))
+    p = out.reshape(1, K, cpr, 64, 32)
+    for (co, ci, kh, kw) in [(0, 0, 0, 0), (63, 8, 6, 6), (17, 3, 2, 5)]:
+        j = kw * Cp + ci
+        assert p[0, kh, j // 32, co, j % 32] == np.float32(w[co, ci, kh, kw] * scale[co])
+    assert p[0, 0, 0, 0, 9] == 0 and p[0, 0, cpr - 1, 0, 31] == 0  # padded channel / run tail
+
+
+def test_tensor_collection_semantics():
+    from megapose6d_amd.tcoll import PandasTensorCollection, concatenate
+
+    c = PandasTensorCollection(pd.DataFrame({"label": ["a", "b", "c"], "s": [1.0, 3.0, 2.0]}, index=[5, 6, 7]), poses=torch.arange(3.0))
+    assert c.infos.index.tolist() == [0, 1, 2]
+    d = c[torch.tensor([2, 0])]
+    assert d.poses.tolist() == [2.0, 0.0] and d.infos["label"].tolist() == ["c", "a"]
+    assert len(concatenate([c, d])) == 5 and len(concatenate([])) == 0
+    with pytest.raises(AttributeError):
+        _ = c.nope
+
+
+def test_filter_pose_estimates_topk_and_ties():
+    from megapose6d_amd.pose_estimator import PoseEstimator
+    from megapose6d_amd.tcoll import PandasTensorCollection
+
+    df = pd.DataFrame(dict(batch_im_id=[0] * 6, label=["a"] * 3 + ["b"] * 3, instance_id=[0] * 6, s=[0.1, 0.9, 0.9, 0.3, 0.2, 0.5]))
+    data = PandasTensorCollection(df, poses=torch.arange(6.0))
+    out = PoseEstimator.filter_pose_estimates(None, data, top_K=2, filter_field="s")
+    assert sorted(out.poses.tolist()) == [1.0, 2.0, 3.0, 5.0]
+    top1 = PoseEstimator.filter_pose_estimates(None, data, top_K=1, filter_field="s")
+    assert sorted(top1.poses.tolist()) == [1.0, 5.0]  # exact tie -> lowest row wins (stable sort)
+
+
+def test_config_back_compat_and_named_models():
+    from megapose6d_amd import load_model as lm
+
+    cfg = lm.check_update_config(dict(backbone_str="vanilla_resnet34", multiview_type="front_3views", n_views=4, render_normals=True))
+    assert cfg.multiview_type == "TCO+front_3views" and cfg.n_rendered_views == 4 and cfg.predict_pose_update
+    assert cfg.depth_normalization_type == "tCR_scale" and lm.n_inputs_from_cfg(cfg) == 27
+    assert set(lm.NAMED_MODELS) == {"megapose-1.0-RGB", "megapose-1.0-RGBD", "megapose-1.0-RGB-multi-hypothesis", "megapose-1.0-RGB-multi-hypothesis-icp"}
+    sd = {"backbone.backbone.conv1.weight": 1, "backbone.head.0.bias": 2, "pose_fc.bias": 3}
+    assert set(lm.change_keys_of_older_models(sd)) == {"backbone.conv1.weight", "views_logits_head.bias", "pose_fc.bias"}
+
+
+def test_mesh_io_roundtrip_and_formats(tmp_path):
+    from megapose6d_amd import mesh_io
+    from megapose6d_amd import synthetic as syn
+
+    v, f, c = syn.make_lathe_mesh(3, n_theta=40, n_z=60)
+    assert len(v) >= 2000
+    syn.write_ply(tmp_path / "m.ply", v, f, c)
+    m = mesh_io.read_ply(tmp_path / "m.ply")
+    assert np.allclose(m["vertices"], v.astype(np.float32)) and np.array_equal(m["faces"], f)
+    assert np.allclose(m["colors"], c / 255.0)
+    with open(tmp_path / "m.obj", "w") as fh:
+        for p in v[:4]:
+            fh.write(f"v {p[0]} {p[1]} {p[2]}\n")
+        fh.write("f 1 2 3 4\n")
+    o = mesh_io.read_obj(tmp_path / "m.obj")
+    assert o["faces"].tolist() == [[0, 1, 2], [0, 2, 3]]
+    obj = syn.RigidObject("x", tmp_path / "m.ply", mesh_units="mm", ypr_offset_deg=(90.0, 0.0, 0.0))
+    e = mesh_io.load_rigid_object(obj)
+    assert np.allclose(e["points"], v.astype(np.float32) * 0.001, atol=1e-7)
+    assert np.allclose(e["vertices"][:, 0], -e["points"][:, 1], atol=1e-6)  # heading 90 deg about z
+    n = np.linalg.norm(e["normals"], axis=1)
+    assert np.allclose(n, 1.0, atol=1e-5)
+
+
+def test_oracle_rasteriser_analytic_properties():
+    """a fronto-parallel quad: exact pixel footprint (top-left rule), metric depth, albedo passthrough, normal LUT"""
+    from oracle import raster as orr
+
+    v = np.array([[-0.1, -0.1, 0], [0.1, -0.1, 0], [0.1, 0.1, 0], [-0.1, 0.1, 0]], np.float32)
+    mesh = {"vertices": v, "normals": np.tile(np.array([[0, 0, -1.0]], np.float32), (4, 1)),
+            "colors": np.tile(np.array([[0.2, 0.4, 0.6]], np.float32), (4, 1)), "faces": np.array([[0, 1, 2], [0, 2, 3]], np.int32)}
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 0.5
+    K = np.array([[100, 0, 32], [0, 100, 24], [0, 0, 1]], np.float32)
+    rgb, nrm, dep = orr.render(mesh, T[None], K[None], 48, 64, 3)
+    m = dep[0] > 0
+    # quad spans u in [12, 52], v in [4, 44]: pixel centres x+.5 in [12,52) -> x = 12..51 (right/bottom edges excluded)
+    ys, xs = np.nonzero(m)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (12, 51, 4, 43) and m.sum() == 40 * 40
+    assert np.allclose(dep[0][m], 0.5, atol=1e-6)
+    assert np.allclose(rgb[0][m], np.round(np.array([0.2, 0.4, 0.6]) * 255) / 255, atol=1e-7)
+    # normal (0,0,-1) in camera frame -> Panda view (x, z, -y) = (0,-1,0): frac -> (0, 0, 0) -> LUT texel blend of 0 and 247
+    assert nrm[0][m].min() >= 0 and nrm[0][m].max() <= 1
+    # invalid pose -> zeros
+    Tb = T.copy(); Tb[0, 0] = np.inf
+    r2, _, d2 = orr.render(mesh, Tb[None], K[None], 48, 64, 3)
+    assert r2.max() == 0 and d2.max() == 0
+    # beyond far plane -> nothing; two-sided: flipped winding renders the same
+    Tf = T.copy(); Tf[2, 3] = 10.5
+    assert orr.render(mesh, Tf[None], K[None], 48, 64, 2)[2].max() == 0
+    mesh2 = dict(mesh, faces=mesh["faces"][:, ::-1].copy())
+    d3 = orr.render(mesh2, T[None], K[None], 48, 64, 3)[2]
+    assert np.array_equal(d3 > 0, dep > 0) and np.allclose(d3, dep, atol=1e-6)
+
+
+def _gloo_worker(rank, world, port, n, k, q):
+    import torch.distributed as dist
+
+    from megapose6d_amd import distributed as mpd
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.arange(n * k, dtype=torch.float32).view(n, k)
+    mine = torch.as_tensor(mpd.shard_indices(n, rank, world))
+    out = mpd.gather_rows(full[mine], n, rank, world)
+    q.put((rank, bool(torch.equal(out, full)), len(mine)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 576, 1])
+def test_row_sharding_and_gather_gloo_world2(n):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n, 17, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+    assert sum(c for _, _, c in res) == n and abs(res[0][2] - res[1][2]) <= 1
