@@ -35,6 +35,14 @@ typedef void* mp_stream; /* hipStream_t */
 
 int mp_version(void);
 const char* mp_last_error(void);
+/* Per-launch HIP-event profiler: between begin/end every instrumented kernel launch is bracketed by hipEvents recorded on
+ * its launch stream.  mp_profile_query aggregates by kernel name: number of launches, summed duration (ms), and the summed
+ * ALGORITHMIC flops / bytes of those launches (DESIGN.md states each kernel's per-unit figures).  Returns 1 past the end. */
+int mp_profile_begin(void);
+int mp_profile_end(void);
+int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
+                     double* total_bytes);
+
 /* number of CUs etc. of the current device; fails loudly when no gfx950 device is usable */
 int mp_device_info(int* n_cus, int* lds_bytes, char* arch_name, int arch_name_len);
 
@@ -137,6 +145,7 @@ typedef struct {
   float* d_y_act;          /* optional second output relu(y*act_scale + act_shift)           */
   const float* d_act_scale;
   const float* d_act_shift;
+  int32_t c_real;          /* real (unpadded) input channels, for the profiler's algorithmic FLOP count; 0 = C   */
 } mp_conv_desc;
 
 int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);

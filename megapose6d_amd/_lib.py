@@ -52,6 +52,7 @@ class ConvDesc(C.Structure):
         ("d_y_act", C.c_void_p),
         ("d_act_scale", C.c_void_p),
         ("d_act_shift", C.c_void_p),
+        ("c_real", C.c_int32),
     ]
 
 
@@ -65,6 +66,9 @@ _vp, _i, _i64, _f, _sz, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_si
 SIGNATURES = {
     "mp_version": (_i, []),
     "mp_last_error": (C.c_char_p, []),
+    "mp_profile_begin": (_i, []),
+    "mp_profile_end": (_i, []),
+    "mp_profile_query": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mp_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "mp_mesh_db_create": (_i, [C.POINTER(MeshDesc), _i, C.POINTER(_vp)]),
     "mp_mesh_db_destroy": (_i, [_vp]),

@@ -125,7 +125,7 @@ int run_conv(const ConvLayer& L, const float* x, int N, int H, int W, int in_bor
              int relu, float* y_act, const BnAct* act, hipStream_t s) {
   mp_conv_desc d;
   memset(&d, 0, sizeof(d));
-  d.d_x = x; d.N = N; d.H = H; d.W = W; d.C = L.Cin_p; d.in_border = in_border;
+  d.d_x = x; d.N = N; d.H = H; d.W = W; d.C = L.Cin_p; d.c_real = L.Cin; d.in_border = in_border;
   d.d_w = L.d_w; d.d_bias = L.d_b; d.Cout = L.Cout; d.KH = L.K; d.KW = L.K; d.stride = L.stride; d.pad = L.pad;
   d.d_y = y; d.out_border = out_border; d.d_residual = res; d.relu = relu;
   d.d_y_act = y_act;

@@ -29,6 +29,15 @@ void set_error(const char* fmt, ...);
     }                                  \
   } while (0)
 
+// Optional per-launch HIP-event profiler (mp_profile_begin/end/query): events are recorded on the launch stream around
+// each instrumented kernel; aggregation happens at query time.  Disabled = zero overhead.
+struct ProfScope {
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware bijective remap of a linear workgroup id (8 XCDs, round-robin dispatch):

@@ -47,8 +47,45 @@ struct ConvParams {
   int n_mblocks, n_nblocks;
 };
 
+template <int TM, int TN, bool RES, bool RELU, bool ACT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[TM][TN], const int* row_off, int row0, int n_first) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n_first + j * 32;
+    if (n >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (ACT) {
+      sc = p.act_scale[n];
+      sh = p.act_shift[n];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int offs[16];
+      float res[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) offs[r] = row_off[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
+      if (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = offs[r] >= 0 ? p.residual[offs[r] + n] : 0.f;  // 16 loads in flight
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (offs[r] < 0) continue;
+        float v = acc[i][j][r] + bias;
+        if (RES) v += res[r];
+        if (RELU) v = fmaxf(v, 0.f);
+        if (p.y) p.y[offs[r] + n] = v;
+        if (ACT) p.y_act[offs[r] + n] = fmaxf(fmaf(v, sc, sh), 0.f);
+      }
+    }
+  }
+}
+
+// waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
+// keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_nhwc_f32_mfma(ConvParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma(ConvParams p) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
@@ -103,7 +140,6 @@ __global__ __launch_bounds__(256) void conv_nhwc_f32_mfma(ConvParams p) {
   const float* b_ptr = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + tid * 4;
   const int row_stride = p.Wp * p.C;  // floats between successive kh rows
 
-  float4 a_reg[A_LD4], b_reg[B_LD4];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -112,39 +148,67 @@ __global__ __launch_bounds__(256) void conv_nhwc_f32_mfma(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto load_chunk = [&](int chunk) {
-    const int kh = chunk / p.chunks_per_row;
-    const int kc = chunk - kh * p.chunks_per_row;
-    const int aoff = kh * row_stride + kc * BK;
-#pragma unroll
-    for (int i = 0; i < A_LD4; ++i) a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + aoff);
-    const float* bp = b_ptr + (size_t)chunk * (BN * BK);
-#pragma unroll
-    for (int i = 0; i < B_LD4; ++i) b_reg[i] = *reinterpret_cast<const float4*>(bp + i * 1024);
-  };
-  auto store_chunk = [&](int buf) {
-    float* as = As + buf * BM * LDS_LD;
-    float* bs = Bs + buf * BN * LDS_LD;
-#pragma unroll
-    for (int i = 0; i < A_LD4; ++i)
-      *reinterpret_cast<float4*>(as + (a_r0 + 32 * i) * LDS_LD + a_c4 * 4) = a_reg[i];
-#pragma unroll
-    for (int i = 0; i < B_LD4; ++i) {
-      const int idx = tid + 256 * i;  // float4 index inside the [BN][BK] tile
-      *reinterpret_cast<float4*>(bs + (idx >> 3) * LDS_LD + (idx & 7) * 4) = b_reg[i];
-    }
-  };
+  // Straight-line software pipeline (no lambdas / no conditional loads: hipcc otherwise parks the prefetch registers in
+  // scratch and waits for the loads right away).  The loads of chunk c+1 are issued before the MFMAs of chunk c and written
+  // to the other LDS buffer after them; the last iteration harmlessly re-loads the last chunk.
+// (explicit scalars, not arrays: the arrays only become registers after loop unrolling, and the sched_barrier intrinsic
+//  that pins the prefetch is a memory barrier to the optimiser, which would leave them in scratch)
+#define MP_LD4(P) (*reinterpret_cast<const float4*>(P))
+#define MP_CONV_LOAD(AOFF, BP)                          \
+  a0 = MP_LD4(a_ptr0 + (AOFF));                         \
+  a1 = MP_LD4(a_ptr1 + (AOFF));                         \
+  a2 = MP_LD4(a_ptr2 + (AOFF));                         \
+  a3 = MP_LD4(a_ptr3 + (AOFF));                         \
+  b0 = MP_LD4((BP));                                    \
+  b1 = MP_LD4((BP) + 1024);                             \
+  if constexpr (B_LD4 > 2) {                            \
+    b2 = MP_LD4((BP) + 2048);                           \
+    b3 = MP_LD4((BP) + 3072);                           \
+  }
+#define MP_ST4(P, V) (*reinterpret_cast<float4*>(P) = (V))
+#define MP_CONV_STORE(BUF)                                                        \
+  {                                                                               \
+    float* as_w = As + (BUF) * BM * LDS_LD + a_r0 * LDS_LD + a_c4 * 4;            \
+    float* bs_w = Bs + (BUF) * BN * LDS_LD + (tid >> 3) * LDS_LD + (tid & 7) * 4; \
+    MP_ST4(as_w, a0);                                                             \
+    MP_ST4(as_w + 32 * LDS_LD, a1);                                               \
+    MP_ST4(as_w + 64 * LDS_LD, a2);                                               \
+    MP_ST4(as_w + 96 * LDS_LD, a3);                                               \
+    MP_ST4(bs_w, b0);                                                             \
+    MP_ST4(bs_w + 32 * LDS_LD, b1);                                               \
+    if constexpr (B_LD4 > 2) {                                                    \
+      MP_ST4(bs_w + 64 * LDS_LD, b2);                                             \
+      MP_ST4(bs_w + 96 * LDS_LD, b3);                                             \
+    }                                                                             \
+  }
+  static_assert(A_LD4 == 4 && (B_LD4 == 2 || B_LD4 == 4), "staging code is written for BM = 128, BN in {64, 128}");
+  const float* a_ptr0 = a_ptr[0];
+  const float* a_ptr1 = a_ptr[1];
+  const float* a_ptr2 = a_ptr[2];
+  const float* a_ptr3 = a_ptr[3];
+  float4 a0, a1, a2, a3, b0, b1, b2, b3;
 
-  load_chunk(0);
-  store_chunk(0);
+  int aoff = 0, kc = 0;  // element offset / chunk-in-row of the chunk being prefetched
+  const float* bp = b_ptr;
+  MP_CONV_LOAD(aoff, bp)
+  MP_CONV_STORE(0)
   __syncthreads();
 
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
+  const int row_wrap = row_stride - p.chunks_per_row * BK;
   for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
     const int buf = chunk & 1;
-    const bool has_next = chunk + 1 < p.n_chunks;
-    if (has_next) load_chunk(chunk + 1);
+    if (chunk + 1 < p.n_chunks) {  // scalar (wave-uniform) pointer bump only; the loads themselves are unconditional
+      aoff += BK;
+      bp += BN * BK;
+      if (++kc == p.chunks_per_row) {
+        kc = 0;
+        aoff += row_wrap;
+      }
+    }
+    MP_CONV_LOAD(aoff, bp)
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
     const float* as = As + buf * BM * LDS_LD + (wm * WM + frag_row) * LDS_LD + frag_k;
     const float* bs = Bs + buf * BN * LDS_LD + (wn * WN + frag_row) * LDS_LD + frag_k;
 #pragma unroll
@@ -164,43 +228,33 @@ __global__ __launch_bounds__(256) void conv_nhwc_f32_mfma(ConvParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (has_next) store_chunk(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    MP_CONV_STORE(buf ^ 1)
     __syncthreads();
   }
+#undef MP_CONV_LOAD
+#undef MP_CONV_STORE
+#undef MP_LD4
+#undef MP_ST4
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const int col_l = lane & 31;
-  const int row_h = (lane >> 5) * 4;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 32 + col_l;
-    const bool n_ok = n < p.Cout;
-    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
-    float sc = 1.f, sh = 0.f;
-    if (p.y_act && n_ok) {
-      sc = p.act_scale[n];
-      sh = p.act_shift[n];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-        const int off = row_off[row];
-        if (off >= 0 && n_ok) {
-          float v = acc[i][j][r] + bias;
-          if (p.residual) v += p.residual[off + n];
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (p.y) p.y[off + n] = v;
-          if (p.y_act) p.y_act[off + n] = fmaxf(fmaf(v, sc, sh), 0.f);
-        }
-      }
-    }
+  // (compile-time flags: one straight-line store loop per fused mode instead of four data-dependent branches per element)
+  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
+  const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
+  switch (emode) {
+    case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
+    case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
+    case 2: conv_epilogue<TM, TN, false, true, false>(p, acc, row_off, erow0, en0); break;
+    case 3: conv_epilogue<TM, TN, true, true, false>(p, acc, row_off, erow0, en0); break;
+    case 4: conv_epilogue<TM, TN, false, false, true>(p, acc, row_off, erow0, en0); break;
+    case 5: conv_epilogue<TM, TN, true, false, true>(p, acc, row_off, erow0, en0); break;
+    case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
+    default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
   }
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch(const ConvParams& p, hipStream_t s) {
+static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
   ConvParams q = p;
   q.n_mblocks = ceil_div(p.M, BM);
   q.n_nblocks = ceil_div(p.Cout, BN);
@@ -212,6 +266,9 @@ static int launch(const ConvParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(q.n_mblocks * q.n_nblocks);
+  // algorithmic work of this launch: 2*MACs over the REAL (unpadded) reduction length; bytes = input + weights + output once
+  ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * (double)p.M * p.Cout * alg_k,
+                 4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
   hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN>), grid, dim3(256), lds, s, q);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
@@ -304,8 +361,9 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   int rc = make_params(d, &p);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (conv_bn_tile(d->Cout) == 64) return launch<128, 64, 64, 32>(p, s);
-  return launch<128, 128, 64, 64>(p, s);
+  const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
+  if (conv_bn_tile(d->Cout) == 64) return launch<128, 64, 64, 32>(p, s, alg_k);
+  return launch<128, 128, 64, 64>(p, s, alg_k);
 }
 
 extern "C" const char* mp_conv2d_kernel_name(const mp_conv_desc* d) {

@@ -121,6 +121,7 @@ extern "C" int mp_crop_roi_align(const float* d_images, int n_im, int C, int H, 
   if (b == 0) return MP_OK;
   dim3 grid(ceil_div((long)out_h * out_w, 256), b);
   hipStream_t s = (hipStream_t)stream;
+  ProfScope prof("crop_roi_align", 0.0, (double)b * C * 4.0 * out_h * out_w * 2.0, s);  // write + (<=) equal-sized source window read
   if (C == 3)
     hipLaunchKernelGGL(crop_roi_align_kernel<3>, grid, dim3(256), 0, s, d_images, H, W, d_im_ids, d_boxes, out_h, out_w, d_out,
                        (long long)stride_b, (long long)stride_y, (long long)stride_x, c0);

@@ -113,6 +113,7 @@ extern "C" int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * Ho * Wo * (C / 4);
   if (total == 0) return MP_OK;
+  ProfScope prof("maxpool3x3s2", 0.0, 4.0 * C * ((double)N * H * W + (double)N * Ho * Wo * (d_y && d_y_act ? 2 : 1)), (hipStream_t)stream);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, N, H, W, C,
                      in_border, d_y, out_border, Ho, Wo, d_y_act, d_sc, d_sh);
   MP_CHECK_HIP(hipGetLastError());
@@ -126,6 +127,7 @@ extern "C" int mp_pool_fc_heads(const float* d_x, int N, int H, int W, int C, in
   MP_REQUIRE(d_fc_w ? (d_fc_b != nullptr) : (n_feat == C), "mp_pool_fc_heads: fc bias missing or n_feat != C without fc");
   if (N == 0) return MP_OK;
   const size_t lds = (size_t)(C + n_feat) * sizeof(float);
+  ProfScope prof("pool_fc_heads", 2.0 * N * ((d_fc_w ? (double)C * n_feat : 0.0) + (double)n_feat * n_out), 4.0 * N * (double)H * W * C, (hipStream_t)stream);
   hipLaunchKernelGGL(pool_fc_heads_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, d_x, H, W, C, in_border, d_fc_w,
                      d_fc_b, n_feat, d_head_w, d_head_b, n_out, d_feat, d_out, d_sigmoid);
   MP_CHECK_HIP(hipGetLastError());

@@ -300,6 +300,7 @@ extern "C" int mp_pose_prepare(const float* d_TCO_in, const float* d_K, const in
              multiview == 0 ? 1 : 4);
   MP_REQUIRE(n_pts_main <= n_pts_stride && n_pts_views <= n_pts_stride && n_pts_main > 0, "mp_pose_prepare: bad point counts");
   if (b == 0) return MP_OK;
+  ProfScope prof("pose_prepare", 0.0, (double)b * (12.0 * n_pts_main + (V - 1) * 12.0 * n_pts_views), (hipStream_t)stream);
   hipLaunchKernelGGL(pose_prepare_kernel, dim3(b, V), dim3(256), 0, (hipStream_t)stream, d_TCO_in, d_K, d_mesh_ids, d_points,
                      n_pts_stride, n_pts_main, n_pts_views, V, multiview, im_h, im_w, out_h, out_w, lamb, d_TCO_n, d_tCR, d_TCV_O,
                      d_KV_crop, d_boxes_rend, d_boxes_crop);

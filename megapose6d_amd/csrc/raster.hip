@@ -424,7 +424,10 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   memcpy(L.color, lights->point_color, sizeof(L.color));
   VtxRec* vtx = (VtxRec*)d_ws;
   dim3 g1(ceil_div(db->max_verts, 256), n_views);
+  {
+  ProfScope prof("raster_transform", 0.0, (double)n_views * db->max_verts * (12.0 + sizeof(VtxRec)), s);
   hipLaunchKernelGGL(raster_transform, g1, dim3(256), 0, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, db->max_verts, vtx);
+  }
   const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + BIG_QUEUE * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
@@ -433,6 +436,9 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   }
   MP_REQUIRE(lds <= 160 * 1024 - 64, "mp_raster_render: image too wide for the LDS z-buffer");
   dim3 g2(ceil_div(h, BAND_H), n_views);
+  const int n_ch = (c_rgb >= 0 ? 3 : 0) + (((flags & MP_RASTER_NORMALS) && c_normals >= 0) ? 3 : 0) + (((flags & MP_RASTER_DEPTH) && c_depth >= 0) ? 1 : 0);
+  // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
+  ProfScope prof("raster_bands", 0.0, (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces), s);
   hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, vtx, db->max_verts,
                      h, w, flags, L, d_out, (long long)stride_v, views_per_item, (long long)stride_view, (long long)stride_y,
                      (long long)stride_x, c_rgb, c_normals, c_depth);

@@ -47,6 +47,28 @@ def _dev_i32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def profile_begin() -> None:
+    check(_lib.load().mp_profile_begin())
+
+
+def profile_end() -> Dict[str, Dict[str, float]]:
+    """Stop the per-launch event profiler and return {kernel: {launches, ms, flops, bytes}} (synchronises)."""
+    lib = _lib.load()
+    check(lib.mp_profile_end())
+    out: Dict[str, Dict[str, float]] = {}
+    i = 0
+    while True:
+        name = C.create_string_buffer(128)
+        n, ms, fl, by = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        rc = lib.mp_profile_query(i, name, 128, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+        if rc == 1:
+            break
+        check(rc)
+        out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+        i += 1
+    return out
+
+
 def device_info() -> Tuple[int, int, str]:
     lib = _lib.load()
     n_cu, lds = C.c_int(0), C.c_int(0)
