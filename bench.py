@@ -110,7 +110,8 @@ def main():
 
     tmp = tempfile.mkdtemp(prefix=f"mp_bench_r{rank}_")
     n_obj = world  # weak scaling: one object x 576 hypotheses per GPU
-    est, obs, det, _ = make_scene(n_objects=n_obj, seed=0, backbone=a.backbone, SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1)
+    est, obs, det, _ = make_scene(n_objects=n_obj, seed=0, backbone=a.backbone, SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1,
+                                   n_streams=int(os.environ.get("MP_N_STREAMS", "1")))
 
     def step():
         return est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=N_HYP)

@@ -44,9 +44,10 @@ struct mp_backbone {
   std::vector<int> stage_of_block;  // 0..3
   float *d_fc_w = nullptr, *d_fc_b = nullptr, *d_head_w = nullptr, *d_head_b = nullptr;
   std::vector<void*> allocs;
-  // workspace bookkeeping (borders are zeroed once per (pointer, batch, h, w))
-  void* ws_ptr = nullptr;
-  int ws_batch = 0, ws_h = 0, ws_w = 0;
+  // workspace bookkeeping: borders are zeroed once per (pointer, batch, h, w); several workspaces may be live at once
+  // (one per HIP stream when half-batches are interleaved on two streams)
+  struct WsKey { void* ptr; int batch, h, w; };
+  std::vector<WsKey> ws_known;
 };
 
 namespace {
@@ -256,9 +257,14 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
   MP_REQUIRE(ws_bytes >= need, "mp_backbone_forward: workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const Geometry g = geometry(bb, h, w);
-  if (bb->ws_ptr != d_ws || bb->ws_batch != batch || bb->ws_h != h || bb->ws_w != w) {
+  bool known = false;
+  for (const auto& k : bb->ws_known) known = known || (k.ptr == d_ws && k.batch == batch && k.h == h && k.w == w);
+  if (!known) {
     MP_CHECK_HIP(hipMemsetAsync(d_ws, 0, need, s));  // zero borders once; interiors are always overwritten
-    bb->ws_ptr = d_ws; bb->ws_batch = batch; bb->ws_h = h; bb->ws_w = w;
+    for (size_t i = 0; i < bb->ws_known.size();)     // a pointer re-used with another geometry invalidates its old entry
+      if (bb->ws_known[i].ptr == d_ws) bb->ws_known.erase(bb->ws_known.begin() + i); else ++i;
+    if (bb->ws_known.size() >= 8) bb->ws_known.erase(bb->ws_known.begin());
+    bb->ws_known.push_back({d_ws, batch, h, w});
   }
   float* p = (float*)d_ws;
   float* S = p; p += align_up(buf_floats(batch, g.h1, g.w1, 64), 64);

@@ -15,6 +15,8 @@
 // output relu(y*s+t) for pre-activation (WideResNet) blocks.
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s, MI355X_MICROARCH.md).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mp {
@@ -41,8 +43,8 @@ struct ConvParams {
   int Cout;
   int Hop, Wop, out_border;
   int KH;
-  int chunks_per_row;  // ceil(KW*C / BK)
-  int n_chunks;        // KH * chunks_per_row
+  int run;             // KW*C floats: contiguous (kw, c) taps of one kernel row
+  int n_chunks;        // ceil(KH*run / BK): the K loop walks the concatenated row runs
   int relu;
   int n_mblocks, n_nblocks;
 };
@@ -84,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma(ConvParams p) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ho = t % p.Ho;
     const int n = t / p.Ho;
     const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
-    a_ptr[i] = p.x + pix * p.C + a_c4 * 4;
+    a_ptr[i] = p.x + pix * p.C;
   }
   // output offsets of this tile's rows
   for (int r = tid; r < BM; r += 256) {
@@ -188,7 +190,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* a_ptr3 = a_ptr[3];
   float4 a0, a1, a2, a3, b0, b1, b2, b3;
 
-  int aoff = 0, kc = 0;  // element offset / chunk-in-row of the chunk being prefetched
+  // per-thread position of its float4 inside the concatenated K axis: j = offset in the current kernel row's run,
+  // aoff = element offset from the pixel's first tap (run % 4 == 0, so a float4 never straddles two rows)
+  // RAGGED (run % 32 != 0, the 7x7 / 5x5 stems): per-lane bookkeeping.  Otherwise chunks never straddle kernel rows and
+  // the bump is wave-uniform (scalar registers), which is what the 3x3 / 1x1 layers use.
+  int j = a_c4 * 4, aoff = a_c4 * 4;
+  if constexpr (RAGGED) {
+    while (j >= p.run) { j -= p.run; aoff += row_stride - p.run; }
+  }
+  int ju = 0;  // uniform run position (non-RAGGED)
   const float* bp = b_ptr;
   MP_CONV_LOAD(aoff, bp)
   MP_CONV_STORE(0)
@@ -196,15 +206,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
-  const int row_wrap = row_stride - p.chunks_per_row * BK;
+  const int row_wrap = row_stride - p.run;
   for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
     const int buf = chunk & 1;
-    if (chunk + 1 < p.n_chunks) {  // scalar (wave-uniform) pointer bump only; the loads themselves are unconditional
-      aoff += BK;
+    if (chunk + 1 < p.n_chunks) {  // advance to the next chunk; the loads themselves are unconditional
       bp += BN * BK;
-      if (++kc == p.chunks_per_row) {
-        kc = 0;
-        aoff += row_wrap;
+      aoff += BK;
+      if constexpr (RAGGED) {
+        j += BK;
+        while (j >= p.run) {  // crossed into the next kernel row(s) (runs shorter than BK wrap more than once)
+          j -= p.run;
+          aoff += row_wrap;
+        }
+      } else {
+        ju += BK;
+        if (ju == p.run) {
+          ju = 0;
+          aoff += row_wrap;
+        }
       }
     }
     MP_CONV_LOAD(aoff, bp)
@@ -218,18 +237,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+      if constexpr ((VARIANT & 1) != 0) {
+        if (kk == BK / 8 - 1) {  // write the prefetched chunk to the other buffer UNDER the last MFMA group
+          __builtin_amdgcn_sched_barrier(0);
+          MP_CONV_STORE(buf ^ 1)
+          __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      if constexpr ((VARIANT & 2) != 0) {
+#define MP_MFMA_ALL(C)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].C, bf[j].C, acc[i][j], 0, 0, 0);
+        MP_MFMA_ALL(x) MP_MFMA_ALL(y) MP_MFMA_ALL(z) MP_MFMA_ALL(w)
+#undef MP_MFMA_ALL
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    MP_CONV_STORE(buf ^ 1)
+    if constexpr ((VARIANT & 1) == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      MP_CONV_STORE(buf ^ 1)
+    }
     __syncthreads();
   }
 #undef MP_CONV_LOAD
@@ -253,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false>
 static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
   ConvParams q = p;
   q.n_mblocks = ceil_div(p.M, BM);
@@ -261,7 +297,7 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
   const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD) * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN>,
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -269,7 +305,7 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
   // algorithmic work of this launch: 2*MACs over the REAL (unpadded) reduction length; bytes = input + weights + output once
   ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * (double)p.M * p.Cout * alg_k,
                  4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
-  hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN>), grid, dim3(256), lds, s, q);
+  hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>), grid, dim3(256), lds, s, q);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
@@ -284,36 +320,38 @@ using namespace mp;
 extern "C" size_t mp_conv_packed_floats(int Cin_p, int Cout, int KH, int KW) {
   const int BN = conv_bn_tile(Cout);
   const int nblk = ceil_div(Cout, BN);
-  const int cpr = ceil_div((long)KW * Cin_p, BK);
-  return (size_t)nblk * KH * cpr * BN * BK;
+  const int n_chunks = ceil_div((long)KH * KW * Cin_p, BK);
+  return (size_t)nblk * n_chunks * BN * BK;
 }
 
+// packed[nb][chunk][n_local][k], K index = kh*(KW*Cin_p) + kw*Cin_p + c over the concatenated row runs (zero padded)
 extern "C" int mp_conv_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int Cin_p,
                                     const float* scale, float* packed) {
   MP_REQUIRE(w && packed && Cin_p >= Cin && (Cin_p % 4) == 0, "mp_conv_pack_weights: bad arguments");
   const int BN = conv_bn_tile(Cout);
   const int nblk = ceil_div(Cout, BN);
   const int run = KW * Cin_p;
-  const int cpr = ceil_div(run, BK);
+  const int k_total = KH * run;
+  const int n_chunks = ceil_div(k_total, BK);
   const size_t total = mp_conv_packed_floats(Cin_p, Cout, KH, KW);
   memset(packed, 0, total * sizeof(float));
   for (int nb = 0; nb < nblk; ++nb)
-    for (int kh = 0; kh < KH; ++kh)
-      for (int kc = 0; kc < cpr; ++kc) {
-        float* tile = packed + (((size_t)nb * KH + kh) * cpr + kc) * BN * BK;
-        for (int nl = 0; nl < BN; ++nl) {
-          const int n = nb * BN + nl;
-          if (n >= Cout) continue;
-          const float s = scale ? scale[n] : 1.f;
-          for (int k = 0; k < BK; ++k) {
-            const int j = kc * BK + k;
-            if (j >= run) continue;
-            const int kw = j / Cin_p, c = j % Cin_p;
-            if (c >= Cin) continue;
-            tile[nl * BK + k] = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw] * s;
-          }
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      float* tile = packed + ((size_t)nb * n_chunks + ch) * BN * BK;
+      for (int nl = 0; nl < BN; ++nl) {
+        const int n = nb * BN + nl;
+        if (n >= Cout) continue;
+        const float s = scale ? scale[n] : 1.f;
+        for (int k = 0; k < BK; ++k) {
+          const int kidx = ch * BK + k;
+          if (kidx >= k_total) continue;
+          const int kh = kidx / run, jj = kidx % run;
+          const int kw = jj / Cin_p, c = jj % Cin_p;
+          if (c >= Cin) continue;
+          tile[nl * BK + k] = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw] * s;
         }
       }
+    }
   return MP_OK;
 }
 
@@ -350,8 +388,8 @@ static int make_params(const mp_conv_desc* d, ConvParams* p) {
   p->Wop = Wo + 2 * d->out_border;
   p->out_border = d->out_border;
   p->KH = d->KH;
-  p->chunks_per_row = ceil_div((long)d->KW * d->C, BK);
-  p->n_chunks = d->KH * p->chunks_per_row;
+  p->run = d->KW * d->C;
+  p->n_chunks = ceil_div((long)d->KH * p->run, BK);
   p->relu = d->relu;
   return MP_OK;
 }
@@ -362,8 +400,15 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
-  if (conv_bn_tile(d->Cout) == 64) return launch<128, 64, 64, 32>(p, s, alg_k);
-  return launch<128, 128, 64, 64>(p, s, alg_k);
+  static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 1;  // tuning experiments only
+  const bool small = conv_bn_tile(d->Cout) == 64;
+  if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
+    return small ? launch<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch<128, 128, 64, 64, 1, true>(p, s, alg_k);
+  }
+  switch (variant) {
+    case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
+    default: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
+  }
 }
 
 extern "C" const char* mp_conv2d_kernel_name(const mp_conv_desc* d) {

@@ -8,7 +8,7 @@
 //
 // Pixel contract (identical, operation for operation, to oracle/raster.c -- see DESIGN.md "Rasteriser"):
 //   * camera-space vertex  Pc = R p + t  as an fmaf chain; screen  sx = fmaf(fx, x/z.., cx)
-//   * screen coords snapped to 1/256 px fixed point; coverage by exact int64 edge functions sampled at
+//   * screen coords snapped to 1/256 px fixed point; coverage by exact integer edge functions (evaluated in fp64) sampled at
 //     pixel centres (x+.5, y+.5) with the top-left fill rule; two-sided (no back-face culling)
 //   * depth test on wsum = sum b_i/z_i (perspective-correct 1/z), nearest wins, ties -> lowest triangle id;
 //     fragments outside [near, far] = [0.1, 10] m are discarded
@@ -17,7 +17,8 @@
 //
 // Structure: (1) raster_transform: one thread per (view, vertex) -> {X, Y (fixed point), 1/z, valid}
 //            (2) raster_bands: one workgroup per (view, band of BAND_H rows): 64-bit {depth,tri} z-buffer in
-//                LDS, triangle-parallel scan with LDS atomicMin, block-cooperative path for large triangles,
+//                LDS, row-bounds prefilter + LDS compaction, thread-per-triangle LDS atomicMin for tiny triangles and a
+//                wave-per-triangle queue for the rest,
 //                then a pixel-parallel resolve/shade that writes straight into the CNN input tensor slice.
 // Roofline: HBM-bound on the output writes ((3+3[+1])*4*h*w bytes per view).
 #include <cmath>
@@ -31,10 +32,13 @@ constexpr int SUBPIX = 256;
 constexpr float GUARD = 16384.f;  // |screen coord| limit (pixels) for the fixed-point path
 constexpr float Z_EPS = 1e-6f;
 constexpr float Z_NEAR = 0.1f, Z_FAR = 10.0f;
-constexpr int BAND_H = 30;
+constexpr int BAND_H = 16;
 constexpr int BAND_THREADS = 512;
-constexpr int BIG_TRI_AREA = 512;   // clipped-bbox pixels above which a triangle is rasterised by the whole block
-constexpr int BIG_QUEUE = 2048;
+constexpr int BIG_TRI_AREA = 128;   // clipped-bbox pixels above which a triangle is rasterised by a whole wave (a lane that
+                                    // walks a several-hundred-pixel bbox alone stalls its wave and the block's barrier)
+constexpr int BIG_QUEUE = 1024;
+constexpr int LIST_CAP = 2048;  // triangles compacted per scan chunk
+constexpr int STAGE_CH = 7;  // rgb(3) + normals(3) + depth(1) staged per pixel for coalesced stores
 
 struct MeshDev {
   const float* verts;
@@ -101,10 +105,33 @@ __global__ void raster_transform(const MeshDev* __restrict__ meshes, const int32
   out[(size_t)view * max_verts + v] = rec;
 }
 
+// Per (view, triangle): pixel-row range [ymin, ymax] the triangle can touch, packed ymin | ymax << 16 (0xFFFF = culled).
+// Lets every band skip non-overlapping triangles with one coalesced 4-byte read instead of 3 index + 3 vertex gathers.
+__global__ void raster_tri_bounds(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
+                                  const VtxRec* __restrict__ vtx, int max_verts, int max_faces, int h,
+                                  unsigned* __restrict__ bounds) {
+  const int view = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const MeshDev m = meshes[mesh_ids[view]];
+  if (t >= m.n_faces) return;
+  const VtxRec* vv = vtx + (size_t)view * max_verts;
+  const VtxRec v0 = vv[m.faces[3 * t]], v1 = vv[m.faces[3 * t + 1]], v2 = vv[m.faces[3 * t + 2]];
+  unsigned packed = 0xFFFFu;
+  if (v0.valid && v1.valid && v2.valid) {
+    const int Ymin = min(v0.Y, min(v1.Y, v2.Y)), Ymax = max(v0.Y, max(v1.Y, v2.Y));
+    const int ymin = max(0, (Ymin - 128 + 255) >> 8), ymax = min(h - 1, (Ymax - 128) >> 8);
+    if (ymin <= ymax) packed = (unsigned)ymin | ((unsigned)ymax << 16);
+  }
+  bounds[(size_t)view * max_faces + t] = packed;
+}
+
 struct TriSetup {
-  long long A0, B0, C0, A1, B1, C1, A2, B2, C2;  // E_i(sx,sy) = A_i*sx + B_i*sy + C_i (fixed-point sample coords, exact)
-  int t0, t1, t2;                                // fill-rule thresholds: sample is inside iff E_i >= t_i (0 or 1)
-  double inv_area;
+  // E_i(sx,sy) = A_i*sx + B_i*sy + C_i over fixed-point sample coordinates.  All quantities are integers below 2^47, held
+  // in fp64 where they (and every partial sum of the two-FMA evaluation) are exact; fp64 FMA runs at half the fp32 rate on
+  // gfx950, whereas 64-bit integer multiplies decompose into quarter-rate 32-bit multiplies.
+  double A0, B0, C0, A1, B1, C1, A2, B2, C2;
+  double t0, t1, t2;  // fill-rule thresholds: sample is inside iff E_i >= t_i (0 or 1)
+  float inv_area;     // 1 / (float)(2 * signed area) -- barycentric b_i = (float)E_i * inv_area
   float iz0, iz1, iz2;
   int xmin, xmax, ymin, ymax;  // pixel bbox (inclusive), clipped to the band
   bool ok;
@@ -113,12 +140,12 @@ struct TriSetup {
 // Edge a->b: E(p) = (bx-ax)*(py-ay) - (by-ay)*(px-ax).  With y pointing down and a positively oriented
 // triangle the interior is E >= 0; an edge is "left" if it goes up (dy < 0) and "top" if dy == 0 && dx > 0.
 // Top-left edges own their boundary samples (threshold 0); the others exclude E == 0 (threshold 1).
-__device__ __forceinline__ void edge_setup(int ax, int ay, int bx, int by, long long& A, long long& B, long long& C, int& thr) {
-  const long long dx = (long long)bx - ax, dy = (long long)by - ay;
-  A = -dy;
-  B = dx;
-  C = dy * ax - dx * ay;
-  thr = ((dy < 0) || (dy == 0 && dx > 0)) ? 0 : 1;
+__device__ __forceinline__ void edge_setup(int ax, int ay, int bx, int by, double& A, double& B, double& C, double& thr) {
+  const int dx = bx - ax, dy = by - ay;  // |.| < 2^24
+  A = -(double)dy;
+  B = (double)dx;
+  C = (double)dy * (double)ax - (double)dx * (double)ay;  // exact: products < 2^47
+  thr = ((dy < 0) || (dy == 0 && dx > 0)) ? 0.0 : 1.0;
 }
 
 // v1/v2 (and i1/i2) are swapped in place when the screen-space orientation is negative (two-sided rendering).
@@ -127,9 +154,9 @@ __device__ __forceinline__ TriSetup tri_setup(const VtxRec& v0, VtxRec& v1, VtxR
   TriSetup s;
   s.ok = false;
   if (!(v0.valid && v1.valid && v2.valid)) return s;
-  long long area = ((long long)v1.X - v0.X) * ((long long)v2.Y - v0.Y) - ((long long)v1.Y - v0.Y) * ((long long)v2.X - v0.X);
-  if (area == 0) return s;
-  if (area < 0) {
+  double area = (double)(v1.X - v0.X) * (double)(v2.Y - v0.Y) - (double)(v1.Y - v0.Y) * (double)(v2.X - v0.X);  // exact
+  if (area == 0.0) return s;
+  if (area < 0.0) {
     const VtxRec t = v1; v1 = v2; v2 = t;
     const int ti = i1; i1 = i2; i2 = ti;
     area = -area;
@@ -145,7 +172,7 @@ __device__ __forceinline__ TriSetup tri_setup(const VtxRec& v0, VtxRec& v1, VtxR
   edge_setup(v1.X, v1.Y, v2.X, v2.Y, s.A0, s.B0, s.C0, s.t0);  // edge opposite vertex 0
   edge_setup(v2.X, v2.Y, v0.X, v0.Y, s.A1, s.B1, s.C1, s.t1);
   edge_setup(v0.X, v0.Y, v1.X, v1.Y, s.A2, s.B2, s.C2, s.t2);
-  s.inv_area = 1.0 / (double)area;
+  s.inv_area = 1.0f / (float)area;
   s.iz0 = v0.invz;
   s.iz1 = v1.invz;
   s.iz2 = v2.invz;
@@ -154,14 +181,14 @@ __device__ __forceinline__ TriSetup tri_setup(const VtxRec& v0, VtxRec& v1, VtxR
 }
 
 __device__ __forceinline__ bool sample_tri(const TriSetup& s, int px, int py, float& b0, float& b1, float& b2, float& wsum) {
-  const long long sx = (long long)px * SUBPIX + 128, sy = (long long)py * SUBPIX + 128;
-  const long long e0 = s.A0 * sx + s.B0 * sy + s.C0;
-  const long long e1 = s.A1 * sx + s.B1 * sy + s.C1;
-  const long long e2 = s.A2 * sx + s.B2 * sy + s.C2;
+  const double sx = (double)(px * SUBPIX + 128), sy = (double)(py * SUBPIX + 128);
+  const double e0 = fma(s.A0, sx, fma(s.B0, sy, s.C0));  // exact integer arithmetic in fp64
+  const double e1 = fma(s.A1, sx, fma(s.B1, sy, s.C1));
+  const double e2 = fma(s.A2, sx, fma(s.B2, sy, s.C2));
   if (e0 < s.t0 || e1 < s.t1 || e2 < s.t2) return false;
-  b0 = (float)((double)e0 * s.inv_area);
-  b1 = (float)((double)e1 * s.inv_area);
-  b2 = (float)((double)e2 * s.inv_area);
+  b0 = (float)e0 * s.inv_area;
+  b1 = (float)e1 * s.inv_area;
+  b2 = (float)e2 * s.inv_area;
   wsum = fmaf(b2, s.iz2, fmaf(b1, s.iz1, b0 * s.iz0));
   return true;
 }
@@ -197,11 +224,15 @@ __device__ __forceinline__ float quant8(float v255) {
 template <bool kUnused = false>
 __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
-    const VtxRec* __restrict__ vtx, int max_verts, int h, int w, uint32_t flags, LightsDev lights,
-    float* __restrict__ out, long long stride_v, int views_per_item, long long stride_view, long long stride_y,
+    const VtxRec* __restrict__ vtx, const unsigned* __restrict__ bounds, int max_verts, int max_faces, int h, int w, uint32_t flags,
+    LightsDev lights, float* __restrict__ out, long long stride_v, int views_per_item, long long stride_view, long long stride_y,
     long long stride_x, int c_rgb, int c_normals, int c_depth) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];  // [BAND_H*w] + big-triangle queue
   int* big_queue = (int*)(zbuf + (size_t)BAND_H * w);
+  float* stage = (float*)(big_queue + BIG_QUEUE);  // [BAND_THREADS][STAGE_CH]
+  int* list = (int*)(stage + BAND_THREADS * STAGE_CH);  // [LIST_CAP]
+  __shared__ int list_n;
+  __shared__ int q_head;
   __shared__ int big_count;
 
   const int view = blockIdx.y;
@@ -211,41 +242,72 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
   const int npix = (y1 - y0 + 1) * w;
   const MeshDev m = meshes[mesh_ids[view]];
   const VtxRec* vv = vtx + (size_t)view * max_verts;
+  const unsigned* tb = bounds + (size_t)view * max_faces;
 
   for (int i = threadIdx.x; i < npix; i += BAND_THREADS) zbuf[i] = ~0ull;
-  if (threadIdx.x == 0) big_count = 0;
+  if (threadIdx.x == 0) { big_count = 0; q_head = 0; }
   __syncthreads();
 
   // ---- pass 1: triangle-parallel coverage + depth ------------------------------------------------
-  for (int t = threadIdx.x; t < m.n_faces; t += BAND_THREADS) {
-    int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
-    const VtxRec v0 = vv[i0];
-    VtxRec v1 = vv[i1], v2 = vv[i2];
-    const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
-    if (!s.ok) continue;
-    const int area = (s.xmax - s.xmin + 1) * (s.ymax - s.ymin + 1);
-    if (area > BIG_TRI_AREA) {
-      const int slot = atomicAdd(&big_count, 1);
-      if (slot < BIG_QUEUE) {
-        big_queue[slot] = t;
-        continue;
+  // Two steps per chunk of LIST_CAP triangles so that the expensive part runs on dense lanes: (a) scan the packed row
+  // bounds and compact the triangles overlapping this band into an LDS list (wave ballot + one LDS atomic per wave),
+  // (b) every thread takes list entries.  (A plain "if (!overlap) continue" loop leaves ~1 lane in 9 active.)
+  const int lane = threadIdx.x & 63;
+  for (int c0 = 0; c0 < ((flags & (1u << 16)) ? 0 : m.n_faces); c0 += LIST_CAP) {
+    if (threadIdx.x == 0) list_n = 0;
+    __syncthreads();
+    const int c1 = min(m.n_faces, c0 + LIST_CAP);
+    for (int tbase = c0 + (threadIdx.x & ~63); tbase < c1; tbase += BAND_THREADS) {
+      const int t = tbase + lane;
+      bool hit = false;
+      if (t < c1) {
+        const unsigned pb = tb[t];
+        hit = (int)(pb & 0xFFFFu) <= y1 && (int)(pb >> 16) >= y0;  // culled triangles carry ymin = 0xFFFF
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        int wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&list_n, __popcll(mask));
+        wbase = __shfl(wbase, 0);
+        if (hit) list[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = t;
       }
     }
-    for (int py = s.ymin; py <= s.ymax; ++py)
-      for (int px = s.xmin; px <= s.xmax; ++px) raster_pixel(s, px, py, t, y0, w, zbuf);
+    __syncthreads();
+    const int n_list = list_n;
+    for (int e = threadIdx.x; e < n_list; e += BAND_THREADS) {
+      const int t = list[e];
+      int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
+      const VtxRec v0 = vv[i0];
+      VtxRec v1 = vv[i1], v2 = vv[i2];
+      const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
+      if (!s.ok) continue;
+      const int area = (s.xmax - s.xmin + 1) * (s.ymax - s.ymin + 1);
+      if (area > BIG_TRI_AREA) {
+        const int slot = atomicAdd(&big_count, 1);
+        if (slot < BIG_QUEUE) {
+          big_queue[slot] = t;
+          continue;
+        }
+      }
+      for (int py = s.ymin; py <= s.ymax; ++py)
+        for (int px = s.xmin; px <= s.xmax; ++px) raster_pixel(s, px, py, t, y0, w, zbuf);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // ---- pass 1b: large triangles, whole block per triangle ----------------------------------------
-  const int nbig = min(big_count, BIG_QUEUE);
-  for (int q = 0; q < nbig; ++q) {
+  // ---- pass 1b: larger triangles: waves pull them from the queue, 64 lanes share one bbox -----------------
+  const int nbig = (flags & (1u << 17)) ? 0 : min(big_count, BIG_QUEUE);
+  for (;;) {
+    int q = 0;
+    if (lane == 0) q = atomicAdd(&q_head, 1);
+    q = __shfl(q, 0);
+    if (q >= nbig) break;
     const int t = big_queue[q];
     int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
     const VtxRec v0 = vv[i0];
     VtxRec v1 = vv[i1], v2 = vv[i2];
     const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
     const int bw = s.xmax - s.xmin + 1, bh = s.ymax - s.ymin + 1;
-    for (int i = threadIdx.x; i < bw * bh; i += BAND_THREADS)
-      raster_pixel(s, s.xmin + i % bw, s.ymin + i / bw, t, y0, w, zbuf);
+    for (int i = lane; i < bw * bh; i += 64) raster_pixel(s, s.xmin + i % bw, s.ymin + i / bw, t, y0, w, zbuf);
   }
   __syncthreads();
 
@@ -256,10 +318,18 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
   const bool no_quant = flags & MP_RASTER_NO_QUANT;
   float* out_v = out + (size_t)(view / views_per_item) * stride_v + (size_t)(view % views_per_item) * stride_view;
-  for (int i = threadIdx.x; i < npix; i += BAND_THREADS) {
-    const int py = y0 + i / w, px = i % w;
-    float* o = out_v + (size_t)py * stride_y + (size_t)px * stride_x;
-    const unsigned long long key = zbuf[i];
+  // channel map of the staged values -> output channel (only the enabled groups), so the store loop below can walk
+  // (pixel, channel) pairs with consecutive lanes on consecutive addresses (24/28-byte pieces instead of 4-byte scatters)
+  int n_ch = 0;
+  int ch_src[STAGE_CH], ch_dst[STAGE_CH];
+  if (c_rgb >= 0) { for (int k = 0; k < 3; ++k) { ch_src[n_ch] = k; ch_dst[n_ch++] = c_rgb + k; } }
+  if (do_norm) { for (int k = 0; k < 3; ++k) { ch_src[n_ch] = 3 + k; ch_dst[n_ch++] = c_normals + k; } }
+  if (do_depth) { ch_src[n_ch] = 6; ch_dst[n_ch++] = c_depth; }
+  for (int base = 0; base < npix; base += BAND_THREADS) {
+    const int i = base + threadIdx.x;
+    const bool live = i < npix;
+    const int py = y0 + (live ? i : 0) / w, px = (live ? i : 0) % w;
+    const unsigned long long key = (live && !(flags & (1u << 18))) ? zbuf[i] : ~0ull;
     float r = 0.f, g = 0.f, b = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, depth = 0.f;
     if (key != ~0ull) {
       const int t = (int)(key & 0xFFFFFFFFu);
@@ -317,9 +387,23 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
         else { nx = quant8(normal_lut(ex)); ny = quant8(normal_lut(ey)); nz = quant8(normal_lut(ez)); }
       }
     }
-    if (c_rgb >= 0) { o[c_rgb] = r; o[c_rgb + 1] = g; o[c_rgb + 2] = b; }
-    if (do_norm) { o[c_normals] = nx; o[c_normals + 1] = ny; o[c_normals + 2] = nz; }
-    if (do_depth) o[c_depth] = depth;
+    float* st = stage + threadIdx.x * STAGE_CH;
+    st[0] = r; st[1] = g; st[2] = b; st[3] = nx; st[4] = ny; st[5] = nz; st[6] = depth;
+    __syncthreads();
+    const int n_here = (flags & (1u << 19)) ? 0 : min(BAND_THREADS, npix - base);
+    // 8 lanes per pixel (channel slot k = lane & 7, active while k < n_ch), 64 pixels per pass: consecutive lanes write
+    // consecutive floats of one pixel, no per-element integer division (the chunk's first (row, col) is wave-uniform).
+    const int k = threadIdx.x & 7;
+    int src = ch_src[0], dst = ch_dst[0];
+#pragma unroll
+    for (int q = 1; q < STAGE_CH; ++q) if (k == q) { src = ch_src[q]; dst = ch_dst[q]; }
+    const int row0 = base / w, col0 = base - row0 * w;
+    for (int pl = threadIdx.x >> 3; pl < n_here; pl += BAND_THREADS / 8) {
+      int col = col0 + pl, rowp = row0;
+      while (col >= w) { col -= w; ++rowp; }
+      if (k < n_ch) out_v[(size_t)(y0 + rowp) * stride_y + (size_t)col * stride_x + dst] = stage[pl * STAGE_CH + src];
+    }
+    __syncthreads();
   }
 }
 
@@ -403,7 +487,7 @@ extern "C" float mp_mesh_db_radius(const mp_mesh_db* db, int i) {
 }
 
 extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views) {
-  return db ? (size_t)n_views * db->max_verts * sizeof(VtxRec) : 0;
+  return db ? (size_t)n_views * ((size_t)db->max_verts * sizeof(VtxRec) + (size_t)db->max_faces * sizeof(unsigned)) : 0;
 }
 
 extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
@@ -428,7 +512,14 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   ProfScope prof("raster_transform", 0.0, (double)n_views * db->max_verts * (12.0 + sizeof(VtxRec)), s);
   hipLaunchKernelGGL(raster_transform, g1, dim3(256), 0, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, db->max_verts, vtx);
   }
-  const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + BIG_QUEUE * sizeof(int);
+  unsigned* tri_bounds = (unsigned*)(vtx + (size_t)n_views * db->max_verts);
+  {
+    ProfScope prof("raster_tri_bounds", 0.0, (double)n_views * db->max_faces * (12.0 + 4.0), s);
+    hipLaunchKernelGGL(raster_tri_bounds, dim3(ceil_div(db->max_faces, 256), n_views), dim3(256), 0, s, db->d_meshes, d_mesh_ids, vtx,
+                       db->max_verts, db->max_faces, h, tri_bounds);
+  }
+  const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + BIG_QUEUE * sizeof(int) + (size_t)BAND_THREADS * STAGE_CH * sizeof(float) +
+                     LIST_CAP * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bands<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -439,8 +530,8 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (((flags & MP_RASTER_NORMALS) && c_normals >= 0) ? 3 : 0) + (((flags & MP_RASTER_DEPTH) && c_depth >= 0) ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   ProfScope prof("raster_bands", 0.0, (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces), s);
-  hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, vtx, db->max_verts,
-                     h, w, flags, L, d_out, (long long)stride_v, views_per_item, (long long)stride_view, (long long)stride_y,
+  hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, vtx, tri_bounds,
+                     db->max_verts, db->max_faces, h, w, flags, L, d_out, (long long)stride_v, views_per_item, (long long)stride_view, (long long)stride_y,
                      (long long)stride_x, c_rgb, c_normals, c_depth);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;

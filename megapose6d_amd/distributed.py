@@ -60,7 +60,12 @@ def gather_rows(local: torch.Tensor, n: int, r: int, world: int, group=None) -> 
     block = torch.zeros(per, k, dtype=local.dtype, device=local.device)
     block[: local.shape[0]] = local
     out = torch.empty(world * per, k, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, block, group=group) if local.is_cuda else _all_gather_cpu(out, block, world, group)
+    if dist.get_backend(group) == "nccl":  # RCCL over xGMI: one fused all-gather
+        dist.all_gather_into_tensor(out, block, group=group)
+    else:  # gloo (CPU tests, or several ranks sharing one GPU in tests): gather through host memory
+        host = torch.empty(world * per, k, dtype=local.dtype)
+        _all_gather_cpu(host, block.cpu(), world, group)
+        out.copy_(host)
     # out[q*per + j] is row q + j*world
     full = out.view(world, per, k).transpose(0, 1).reshape(per * world, k)
     return full[:n].contiguous()

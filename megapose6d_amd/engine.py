@@ -100,16 +100,18 @@ class MeshDB:
         self.n = len(meshes)
         self.max_vertices = lib.mp_mesh_db_max_vertices(h)
         self._keep = []
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}
 
     def radius(self, i: int) -> float:
         return _lib.load().mp_mesh_db_radius(self.handle, i)
 
-    def workspace(self, n_views: int, device) -> torch.Tensor:
+    def workspace(self, n_views: int, device, slot: int = 0) -> torch.Tensor:
+        """scratch for the transformed vertices / triangle bounds; one per `slot` (= concurrent HIP stream)"""
         need = _lib.load().mp_raster_workspace_bytes(self.handle, n_views)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(device):
-            self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
-        return self._ws
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need or ws.device != torch.device(device):
+            self._ws[slot] = ws = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
+        return ws
 
     def close(self):
         if getattr(self, "handle", None):
@@ -135,7 +137,7 @@ def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()) -> Ligh
 
 def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, h: int, w: int, flags: int,
                   lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
-                  c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0) -> None:
+                  c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0, slot: int = 0) -> None:
     """Render n views into `out` (float32 device tensor) at the given element strides."""
     lib = _lib.load()
     n = int(TCO.shape[0])
@@ -143,7 +145,7 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     TCO = _dev_f32(TCO)
     K = _dev_f32(K)
     assert out.dtype == torch.float32 and out.is_cuda
-    ws = db.workspace(n, out.device)
+    ws = db.workspace(n, out.device, slot)
     check(lib.mp_raster_render(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
                                out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x, c_rgb,
                                c_normals, c_depth, ws.data_ptr(), ws.numel(), _stream()))
@@ -170,8 +172,11 @@ DEPTH_NORM_MODES = {None: 0, "none": 0, "tCR_scale": 1, "tCR_scale_clamp_center"
 
 
 # --------------------------------------------------------------------------- #
-def padded_nhwc(n: int, h: int, w: int, c: int, border: int, device, slack: int = 64) -> torch.Tensor:
-    """Zero-initialised flat buffer holding a padded-NHWC tensor (+ read slack for the conv's chunked loads)."""
+def padded_nhwc(n: int, h: int, w: int, c: int, border: int, device, slack: Optional[int] = None) -> torch.Tensor:
+    """Zero-initialised flat buffer holding a padded-NHWC tensor + read slack: the conv's last 32-float K chunk may run
+    past the kernel window into the next padded row (its weights are zero there, the memory only has to be readable)."""
+    if slack is None:
+        slack = (w + 2 * border) * c + 64
     return torch.zeros(n * (h + 2 * border) * (w + 2 * border) * c + slack, dtype=torch.float32, device=device)
 
 
@@ -240,21 +245,22 @@ class Backbone:
         self.kind, self.c_in, self.n_out = kind, c_in, n_out
         self.c_in_p = lib.mp_backbone_input_channels_padded(h)
         self.in_border = lib.mp_backbone_input_border(h)
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}
 
-    def workspace(self, batch: int, h: int, w: int, device) -> torch.Tensor:
+    def workspace(self, batch: int, h: int, w: int, device, slot: int = 0) -> torch.Tensor:
         need = _lib.load().mp_backbone_workspace_bytes(self.handle, batch, h, w)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(device):
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._ws
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need or ws.device != torch.device(device):
+            self._ws.pop(slot, None)
+            self._ws[slot] = ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
 
     def flops(self, batch: int, h: int, w: int) -> float:
         return _lib.load().mp_backbone_flops(self.handle, batch, h, w)
 
     def forward(self, x: torch.Tensor, batch: int, h: int, w: int, out: torch.Tensor, sigmoid: Optional[torch.Tensor] = None,
-                feat: Optional[torch.Tensor] = None) -> None:
-        ws = self.workspace(batch, h, w, x.device)
+                feat: Optional[torch.Tensor] = None, slot: int = 0) -> None:
+        ws = self.workspace(batch, h, w, x.device, slot)
         check(_lib.load().mp_backbone_forward(self.handle, x.data_ptr(), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat),
                                               ws.data_ptr(), ws.numel(), _stream()))
 

@@ -81,7 +81,7 @@ class PoseEstimator(torch.nn.Module):
     def __init__(self, refiner_model: Optional[torch.nn.Module] = None, coarse_model: Optional[torch.nn.Module] = None,
                  detector_model: Optional[torch.nn.Module] = None, depth_refiner=None, bsz_objects: int = 8, bsz_images: int = 256,
                  SO3_grid_size: int = 576, max_rows_per_launch: int = 576, strict_batching: bool = False,
-                 distributed: bool = False) -> None:
+                 distributed: bool = False, n_streams: int = 1) -> None:
         super().__init__()
         self.coarse_model = coarse_model
         self.refiner_model = refiner_model
@@ -92,6 +92,9 @@ class PoseEstimator(torch.nn.Module):
         self.max_rows_per_launch = max_rows_per_launch
         self.strict_batching = strict_batching
         self.distributed = distributed
+        self.n_streams = max(1, int(n_streams))  # chunks are interleaved over this many HIP streams (tails / HBM-bound phases of
+        self.min_rows_per_stream = 64             # one chunk overlap the MFMA work of the other)
+        self._side_streams: List[torch.cuda.Stream] = []
         if self.refiner_model is not None:
             self.cfg = self.refiner_model.cfg
             self.mesh_db = self.refiner_model.mesh_db
@@ -117,6 +120,37 @@ class PoseEstimator(torch.nn.Module):
     # -- helpers -------------------------------------------------------------------------------------------------
     def _chunk(self, reference_bsz: int) -> int:
         return reference_bsz if self.strict_batching else max(self.max_rows_per_launch, 1)
+
+    def _plan(self, n_rows: int, reference_bsz: int) -> Tuple[int, List[torch.cuda.Stream]]:
+        """(rows per chunk, streams to interleave the chunks on).  With >= 2 streams a stage is cut into at least that many
+        chunks; every stream has its own CNN-input / backbone / raster workspaces (`slot`)."""
+        chunk = self._chunk(reference_bsz)
+        ns = 1 if self.strict_batching else self.n_streams
+        if ns > 1 and n_rows >= ns * self.min_rows_per_stream:
+            chunk = min(chunk, -(-n_rows // ns))
+        else:
+            ns = 1
+        cur = torch.cuda.current_stream()
+        if ns == 1:
+            return chunk, [cur]
+        while len(self._side_streams) < ns:
+            self._side_streams.append(torch.cuda.Stream())
+        streams = self._side_streams[:ns]
+        for st in streams:
+            st.wait_stream(cur)
+        return chunk, streams
+
+    @staticmethod
+    def _join(streams: List[torch.cuda.Stream], tensors) -> None:
+        """make the current stream wait for the side streams and adopt the tensors they produced"""
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            if st is not cur:
+                cur.wait_stream(st)
+        if len(streams) > 1 or (streams and streams[0] is not cur):
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
 
     def _grid_extents(self) -> torch.Tensor:
         if self._extents is None:  # [n_obj, M, 2]: depends only on (mesh, rotation) -- cosypose_ops.py:198-208
@@ -161,14 +195,16 @@ class PoseEstimator(torch.nn.Module):
         logits_l, scores_l = [], []
         crops, renders = [], []
         render_time = model_time = 0.0
-        chunk = self._chunk(self.bsz_images)
+        chunk, streams = self._plan(rows.numel(), self.bsz_images)
         n_batches = 0
-        for s in range(0, rows.numel(), chunk):
+        for ci, s in enumerate(range(0, rows.numel(), chunk)):
             sl = slice(s, min(s + chunk, rows.numel()))
             d = det_of_row[sl]
             labels_ = [labels_det[i] for i in d.tolist()]
-            out_ = coarse.forward_coarse(images=observation.images, K=K_rows[sl], labels=labels_, TCO_input=TCO_local[sl],
-                                         cuda_timer=cuda_timer, return_debug_data=return_debug_data, im_ids=det_im[d])
+            slot = ci % len(streams)
+            with torch.cuda.stream(streams[slot]):
+                out_ = coarse.forward_coarse(images=observation.images, K=K_rows[sl], labels=labels_, TCO_input=TCO_local[sl],
+                                             cuda_timer=cuda_timer, return_debug_data=return_debug_data, im_ids=det_im[d], slot=slot)
             render_time += out_["render_time"]
             model_time += out_["model_time"]
             logits_l.append(out_["logits"])
@@ -177,6 +213,7 @@ class PoseEstimator(torch.nn.Module):
                 crops.append(out_["images_crop"])
                 renders.append(out_["renders"])
             n_batches += 1
+        self._join(streams, logits_l + scores_l + crops + renders)
         packed = torch.cat([TCO_local.flatten(1), torch.cat(logits_l), torch.cat(scores_l)], dim=1)  # [rows, 18]
         packed = self._gather(packed, n)
         TCO = packed[:, :16].reshape(n, 4, 4).contiguous()
@@ -204,7 +241,7 @@ class PoseEstimator(torch.nn.Module):
         assert self.refiner_model is not None
         device = observation.images.device
         R = data_TCO_input.poses.shape[0]
-        chunk = self._chunk(self.bsz_objects)
+        chunk, streams = self._plan(len(self._shard(R)), self.bsz_objects)
         df = data_TCO_input.infos.copy()  # the reference adds these two columns to its per-batch copies (:155-156)
         df["refiner_batch_idx"] = np.arange(R) // chunk
         df["refiner_instance_idx"] = np.arange(R) % chunk
@@ -221,11 +258,16 @@ class PoseEstimator(torch.nn.Module):
         if cuda_timer:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        for s in range(0, rows.numel(), chunk):
+        produced = []
+        for ci, s in enumerate(range(0, rows.numel(), chunk)):
             r = rows[s : s + chunk]
             labels_ = [labels_all[i] for i in r.tolist()]
-            outputs_ = self.refiner_model(images=observation.images, K=K_all[r], TCO=poses_in[r], n_iterations=n_iterations,
-                                          labels=labels_, im_ids=im_all[r], materialize=keep_all_outputs, **refiner_kwargs)
+            slot = ci % len(streams)
+            with torch.cuda.stream(streams[slot]):
+                outputs_ = self.refiner_model(images=observation.images, K=K_all[r], TCO=poses_in[r], n_iterations=n_iterations,
+                                              labels=labels_, im_ids=im_all[r], materialize=keep_all_outputs, slot=slot, **refiner_kwargs)
+            for o in outputs_.values():
+                produced += [o.TCO_output, o.TCO_input, o.KV_crop, o.boxes_rend, o.boxes_crop, o.renders, o.images_crop]
             if keep_all_outputs:
                 all_outputs.append(outputs_)
             for n in range(1, n_iterations + 1):
@@ -236,6 +278,7 @@ class PoseEstimator(torch.nn.Module):
                 a["K_crop"].append(o.K_crop)
                 a["boxes_rend"].append(o.boxes_rend)
                 a["boxes_crop"].append(o.boxes_crop)
+        self._join(streams, produced)
         if cuda_timer:
             ev[1].record()
             torch.cuda.synchronize()
@@ -269,15 +312,17 @@ class PoseEstimator(torch.nn.Module):
         rows = torch.as_tensor(self._shard(R), device=device, dtype=torch.long)
         poses = data_TCO.poses.to(device=device, dtype=torch.float32)
         K_all = observation.K[im_all.long()].float()
-        chunk = self._chunk(self.bsz_images)
+        chunk, streams = self._plan(rows.numel(), self.bsz_images)
         logits_l, scores_l, crops, renders = [], [], [], []
         render_time = model_time = 0.0
         n_batches = 0
-        for s in range(0, rows.numel(), chunk):
+        for ci, s in enumerate(range(0, rows.numel(), chunk)):
             r = rows[s : s + chunk]
-            out_ = self.coarse_model.forward_coarse(images=observation.images, K=K_all[r], labels=[labels_all[i] for i in r.tolist()],
-                                                    TCO_input=poses[r], cuda_timer=cuda_timer, return_debug_data=return_debug_data,
-                                                    im_ids=im_all[r])
+            slot = ci % len(streams)
+            with torch.cuda.stream(streams[slot]):
+                out_ = self.coarse_model.forward_coarse(images=observation.images, K=K_all[r], labels=[labels_all[i] for i in r.tolist()],
+                                                        TCO_input=poses[r], cuda_timer=cuda_timer, return_debug_data=return_debug_data,
+                                                        im_ids=im_all[r], slot=slot)
             render_time += out_["render_time"]
             model_time += out_["model_time"]
             logits_l.append(out_["logits"])
@@ -286,6 +331,7 @@ class PoseEstimator(torch.nn.Module):
                 crops.append(out_["images_crop"])
                 renders.append(out_["renders"])
             n_batches += 1
+        self._join(streams, logits_l + scores_l + crops + renders)
         packed = torch.cat([torch.cat(logits_l), torch.cat(scores_l)], dim=1) if rows.numel() else torch.zeros(0, 2, device=device)
         packed = self._gather(packed, R)
         logits, scores = packed[:, 0:1].contiguous(), packed[:, 1:2].contiguous()

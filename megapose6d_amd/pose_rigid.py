@@ -142,8 +142,8 @@ class PosePredictor(nn.Module):
         self.debug = False
         self.timing_dict: Dict[str, float] = defaultdict(float)
         self._engine_bb: Optional[eng.Backbone] = None
-        self._x: Optional[torch.Tensor] = None
-        self._x_rows = 0
+        self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
+        self._x_rows: Dict[int, int] = {}
         self._label_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # -- engine plumbing -----------------------------------------------------------------------------------------
@@ -157,14 +157,15 @@ class PosePredictor(nn.Module):
             self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict())
         return self._engine_bb
 
-    def _x_buffer(self, rows: int, device) -> torch.Tensor:
+    def _x_buffer(self, rows: int, device, slot: int = 0) -> torch.Tensor:
         bb = self._backbone_engine()
         h, w = self.render_size
-        if self._x is None or self._x_rows < rows or self._x.device != device:
-            self._x = None
-            self._x = eng.padded_nhwc(rows, h, w, bb.c_in_p, bb.in_border, device)
-            self._x_rows = rows
-        return self._x
+        x = self._x.get(slot)
+        if x is None or self._x_rows[slot] < rows or x.device != device:
+            self._x.pop(slot, None)
+            self._x[slot] = x = eng.padded_nhwc(rows, h, w, bb.c_in_p, bb.in_border, device)
+            self._x_rows[slot] = rows
+        return x
 
     def _x_geometry(self):
         bb = self._backbone_engine()
@@ -188,14 +189,14 @@ class PosePredictor(nn.Module):
             return [Panda3dLightData(light_type="ambient", color=(1.0, 1.0, 1.0, 1.0))]  # pose_rigid.py:374-376
         return make_scene_lights()
 
-    def _nchw_view(self, rows: int, c0: int, c1: int) -> torch.Tensor:
+    def _nchw_view(self, rows: int, c0: int, c1: int, slot: int = 0) -> torch.Tensor:
         bb = self._backbone_engine()
         h, w = self.render_size
-        return eng.padded_view(self._x, self._x_rows, h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
+        return eng.padded_view(self._x[slot], self._x_rows[slot], h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
 
     # -- the fused step ------------------------------------------------------------------------------------------
     def _step(self, images: torch.Tensor, im_ids: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO_in: torch.Tensor,
-              want_sigmoid: bool):
+              want_sigmoid: bool, slot: int = 0):
         """images [n_im,C,H,W] (C already trimmed to the model's input channels), im_ids [b] row -> image.
         Returns dict of device tensors; the CNN input stays in self._x."""
         device = TCO_in.device
@@ -207,7 +208,7 @@ class PosePredictor(nn.Module):
         points = self.mesh_db.sampled_points(2000)
         TCO_n, tCR, TCV_O, KV_crop, boxes_rend, boxes_crop = eng.pose_prepare(
             TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode, (H, W), (h, w), 1.4)
-        x = self._x_buffer(b, device)
+        x = self._x_buffer(b, device, slot)
         s_row, s_y, s_x, off = self._x_geometry()
         eng.crop_roi_align(images, im_ids, boxes_crop, h, w, x, s_row, s_y, s_x, 0, off)
         nin, nper = self._n_input_channels, self._n_single_render_channels
@@ -216,7 +217,7 @@ class PosePredictor(nn.Module):
         self.renderer.render_into(view_ids, TCV_O.view(b * V, 4, 4), KV_crop.view(b * V, 3, 3), self._lights(), (h, w), x, s_row,
                                   s_y, s_x, nin, nin + 3 if self.render_normals else -1,
                                   nin + (6 if self.render_normals else 3) if self.render_depth else -1, off,
-                                  views_per_item=V, stride_view=nper)
+                                  views_per_item=V, stride_view=nper, slot=slot)
         render_time = time.time() - t0
         mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
         bb = self._backbone_engine()
@@ -231,7 +232,7 @@ class PosePredictor(nn.Module):
         n_out = bb.n_out
         out = torch.empty(b, n_out, dtype=torch.float32, device=device)
         sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
-        bb.forward(x, b, h, w, out, sig)
+        bb.forward(x, b, h, w, out, sig, slot=slot)
         return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,
                     sigmoid=sig, render_time=render_time)
 
@@ -244,7 +245,7 @@ class PosePredictor(nn.Module):
     @torch.no_grad()
     def forward(self, images: torch.Tensor, K: torch.Tensor, labels: List[str], TCO: torch.Tensor, n_iterations: int = 1,
                 random_ambient_light: bool = False, im_ids: Optional[torch.Tensor] = None,
-                materialize: bool = True) -> Dict[str, PosePredictorOutput]:
+                materialize: bool = True, slot: int = 0) -> Dict[str, PosePredictorOutput]:
         """Same contract as the reference forward (pose_rigid.py:498-604).  Engine extensions: `im_ids` lets several rows
         share one observation frame (images is then [n_im,C,H,W] and K stays per-row); `materialize=False` skips the
         clones of the crops/renders (they stay valid only until the next step)."""
@@ -261,7 +262,7 @@ class PosePredictor(nn.Module):
         TCO_input = TCO
         nin = self._n_input_channels
         for n in range(n_iterations):
-            st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=False)
+            st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=False, slot=slot)
             K_crop = st["KV_crop"][:, 0]
             if self.predict_pose_update:
                 TCO_output = eng.pose_update(st["TCO_n"], st["KV_crop"], st["out"], st["tCR"], 9 * self.n_rendered_views)
@@ -273,8 +274,8 @@ class PosePredictor(nn.Module):
                 renderings_logits = st["out"]
             renders = images_crop = None
             if materialize:
-                images_crop = self._nchw_view(bsz, 0, nin).clone()
-                renders = self._nchw_view(bsz, nin, self.backbone.n_inputs).clone()
+                images_crop = self._nchw_view(bsz, 0, nin, slot).clone()
+                renders = self._nchw_view(bsz, nin, self.backbone.n_inputs, slot).clone()
             outputs[f"iteration={n + 1}"] = PosePredictorOutput(
                 renders=renders, images_crop=images_crop, TCO_input=st["TCO_n"], TCO_output=TCO_output, TCV_O_input=st["TCV_O"],
                 tCR=st["tCR"], labels=labels, K=K, K_crop=K_crop, KV_crop=st["KV_crop"], network_outputs=network_outputs,
@@ -286,7 +287,7 @@ class PosePredictor(nn.Module):
     @torch.no_grad()
     def forward_coarse(self, images: torch.Tensor, K: torch.Tensor, labels: List[str], TCO_input: torch.Tensor,
                        cuda_timer: bool = False, return_debug_data: bool = False,
-                       im_ids: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+                       im_ids: Optional[torch.Tensor] = None, slot: int = 0) -> Dict[str, Any]:
         """pose_rigid.py:634-708: logits/scores [b,1] of each hypothesis."""
         assert self.predict_rendered_views_logits, "Method only valid if coarse classification model"
         images = self._prep_images(images)
@@ -299,7 +300,7 @@ class PosePredictor(nn.Module):
         if cuda_timer:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True)
+        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True, slot=slot)
         elapsed = 0.0
         if cuda_timer:
             ev1.record()
@@ -309,8 +310,8 @@ class PosePredictor(nn.Module):
                "TCO_n": st["TCO_n"], "K_crop": st["KV_crop"][:, 0], "boxes_rend": st["boxes_rend"], "boxes_crop": st["boxes_crop"]}
         if return_debug_data:
             nin = self._n_input_channels
-            out["images_crop"] = self._nchw_view(bsz, 0, nin).clone()
-            out["renders"] = self._nchw_view(bsz, nin, self.backbone.n_inputs).clone()
+            out["images_crop"] = self._nchw_view(bsz, 0, nin, slot).clone()
+            out["renders"] = self._nchw_view(bsz, nin, self.backbone.n_inputs, slot).clone()
         return out
 
     @torch.no_grad()

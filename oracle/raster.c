@@ -62,7 +62,7 @@ static int floordiv256(int a) { return (a >= 0) ? (a / 256) : -((-a + 255) / 256
 typedef struct {
   int64_t A[3], B[3], Cc[3];
   int thr[3];
-  double inv_area;
+  float inv_area; /* 1 / (float)(2 * area) */
   float iz[3];
   int idx[3];
 } tri_t;
@@ -86,7 +86,7 @@ static int setup(const vtx_t* vv, int i0, int i1, int i2, tri_t* t) {
   edge(&vv[i1], &vv[i2], &t->A[0], &t->B[0], &t->Cc[0], &t->thr[0]);
   edge(&vv[i2], &vv[i0], &t->A[1], &t->B[1], &t->Cc[1], &t->thr[1]);
   edge(&vv[i0], &vv[i1], &t->A[2], &t->B[2], &t->Cc[2], &t->thr[2]);
-  t->inv_area = 1.0 / (double)area;
+  t->inv_area = 1.0f / (float)area;
   t->iz[0] = vv[i0].invz; t->iz[1] = vv[i1].invz; t->iz[2] = vv[i2].invz;
   return 1;
 }
@@ -96,7 +96,7 @@ static int sample(const tri_t* t, int px, int py, float b[3], float* wsum) {
   for (int i = 0; i < 3; ++i) {
     const int64_t e = t->A[i] * sx + t->B[i] * sy + t->Cc[i];
     if (e < t->thr[i]) return 0;
-    b[i] = (float)((double)e * t->inv_area);
+    b[i] = (float)e * t->inv_area; /* int64 -> float is correctly rounded; the GPU converts the same integer from fp64 */
   }
   *wsum = fmaf(b[2], t->iz[2], fmaf(b[1], t->iz[1], b[0] * t->iz[0]));
   return 1;

@@ -40,7 +40,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_conv_weight_packing_layout():
-    """host-side packing: [nblk][kh][chunk][BN][32] with (kw,c) runs, zero padded"""
+    """host-side packing: [nblk][chunk][BN][32] over the concatenated (kh)(kw,c) K axis, zero padded"""
     from megapose6d_amd import _lib
 
     lib = _lib.load()
@@ -48,15 +48,16 @@ def test_conv_weight_packing_layout():
     w = np.random.RandomState(0).randn(Cout, Cin, K, K).astype(np.float32)
     scale = np.random.RandomState(1).rand(Cout).astype(np.float32) + 0.5
     n = lib.mp_conv_packed_floats(Cp, Cout, K, K)
-    cpr = -(-K * Cp // 32)
-    assert n == 1 * K * cpr * 64 * 32
+    run = K * Cp
+    n_chunks = -(-K * run // 32)
+    assert n == 1 * n_chunks * 64 * 32
     out = np.empty(n, np.float32)
     _lib.check(lib.mp_conv_pack_weights(w.ctypes.data, Cout, Cin, K, K, Cp, scale.ctypes.data, out.ctypes.data))
-    p = out.reshape(1, K, cpr, 64, 32)
+    p = out.reshape(1, n_chunks, 64, 32)
     for (co, ci, kh, kw) in [(0, 0, 0, 0), (63, 8, 6, 6), (17, 3, 2, 5)]:
-        j = kw * Cp + ci
-        assert p[0, kh, j // 32, co, j % 32] == np.float32(w[co, ci, kh, kw] * scale[co])
-    assert p[0, 0, 0, 0, 9] == 0 and p[0, 0, cpr - 1, 0, 31] == 0  # padded channel / run tail
+        kidx = kh * run + kw * Cp + ci  # K walks the concatenated (kw, c) runs of the kernel rows
+        assert p[0, kidx // 32, co, kidx % 32] == np.float32(w[co, ci, kh, kw] * scale[co])
+    assert p[0, 0, 0, 9] == 0 and p[0, n_chunks - 1, 0, 31] == 0  # padded channel / K tail
 
 
 def test_tensor_collection_semantics():
