@@ -1,0 +1,157 @@
+"""-m gpu: edge cases of the hot path through the reference-shaped API (ragged chunks, several frames, repeated labels,
+meshes of different sizes, degenerate inputs) -- the cases the reference's own code paths distinguish."""
+import tempfile
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def multi_scene():
+    """2 frames with different intrinsics, 3 detections: two instances of obj_000000 in frame 0, obj_000001 in frame 1."""
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.scene import build_estimator, render_observation
+    from megapose6d_amd.tcoll import PandasTensorCollection
+    from megapose6d_amd.types import ObservationTensor
+
+    tmp = tempfile.mkdtemp(prefix="mp_edge_")
+    ds = syn.make_object_dataset(tmp, n_objects=2, seed=21, n_theta=48, n_z=60)  # 2882-vertex meshes ...
+    v, f, c = syn.make_lathe_mesh(99, n_theta=80, n_z=70)                          # ... and a 5602-vertex one (padding path)
+    syn.write_ply(ds[1].mesh_path, v, f, c)
+    est = build_estimator(ds, SO3_grid_size=72)
+    rng = np.random.RandomState(4)
+    K0 = syn.K_EXAMPLE.astype(np.float32)
+    K1 = K0.copy()
+    K1[0, 0] *= 0.9; K1[1, 1] *= 0.9; K1[0, 2] += 11.0
+    r = est.coarse_model.renderer
+    posesA = np.stack([syn.random_pose(rng, (0.5, 0.7), 0.25) for _ in range(2)])
+    posesA[1, 0, 3] += 0.12
+    im0, bb0 = render_observation(r, ["obj_000000", "obj_000000"], posesA, K0, seed=1)
+    poseB = np.stack([syn.random_pose(rng, (0.5, 0.7), 0.1)])
+    im1, bb1 = render_observation(r, ["obj_000001"], poseB, K1, seed=2)
+    obs = ObservationTensor(torch.cat([im0, im1]), torch.from_numpy(np.stack([K0, K1])).cuda())
+    infos = pd.DataFrame(dict(label=["obj_000000", "obj_000000", "obj_000001"], batch_im_id=[0, 0, 1]))
+    det = PandasTensorCollection(infos, bboxes=torch.from_numpy(np.concatenate([bb0, bb1])).cuda())
+    return tmp, ds, est, obs, det
+
+
+def _oracle(tmp, ds, grid=72):
+    from megapose6d_amd import mesh_io
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.mesh_db import MeshDataBase
+    from megapose6d_amd.pose_estimator import load_SO3_grid
+    from oracle import pipeline as op
+    from oracle import raster as orr
+
+    meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}
+    db = MeshDataBase.from_object_ds(ds).batched()
+    rend = orr.OracleBatchRenderer(meshes)
+    preds = {}
+    for role, seed in (("coarse", 11), ("refiner", 12)):
+        cfg = syn.make_cfg(role)
+        head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
+        preds[role] = op.OraclePosePredictor(cfg, syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), head, n_out, seed=seed),
+                                             db.labels.tolist(), db.points, rend)
+    return op.OraclePoseEstimator(preds["coarse"], preds["refiner"], load_SO3_grid(grid), bsz=24)
+
+
+def test_multi_frame_multi_instance_vs_oracle(multi_scene):
+    tmp, ds, est, obs, det = multi_scene
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=2)
+    # add_instance_id (inference/utils.py:151-171): instances numbered within (batch_im_id, label)
+    assert final.infos.sort_values(["batch_im_id", "instance_id"])["instance_id"].tolist() == [0, 1, 0]
+    infos = det.infos.copy()
+    infos["instance_id"] = [0, 1, 0]
+    res = _oracle(tmp, ds).run(obs.images.cpu(), obs.K.cpu(), infos, det.bboxes.cpu(), n_refiner_iterations=2, n_pose_hypotheses=2)
+    lg = extra["coarse"]["data"]["logits"].flatten().cpu()
+    scale = max(1.0, res["coarse_logits"].abs().max().item())
+    assert (lg - res["coarse_logits"]).abs().max().item() < 1e-4 * scale
+    key = lambda df: list(zip(df["batch_im_id"], df["label"], df["instance_id"], df["hypothesis_id"]))
+    got_f = extra["coarse_filter"]["preds"]
+    assert sorted(key(got_f.infos)) == sorted(key(res["filtered_infos"]))
+    order = [key(got_f.infos).index(k) for k in key(res["filtered_infos"])]
+    for n in range(2):
+        p = extra["refiner_all_hypotheses"]["preds"][f"iteration={n + 1}"].poses.cpu()[order]
+        assert (p - res["refiner_poses"][n]).abs().max().item() < 1e-4
+    kf = lambda df: list(zip(df["batch_im_id"], df["label"], df["instance_id"]))
+    of = [kf(final.infos).index(k) for k in kf(res["final_infos"])]
+    assert (final.poses.cpu()[of] - res["final_TCO"]).abs().max().item() < 1e-4
+
+
+def test_ragged_chunks_match_single_launch(multi_scene):
+    """216 coarse rows in chunks of 50 (last chunk ragged) and refiner rows in chunks of 4 == one big launch"""
+    tmp, ds, est, obs, det = multi_scene
+    f1, e1 = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=3)
+    old = est.max_rows_per_launch
+    try:
+        est.max_rows_per_launch = 50
+        f2, e2 = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=3)
+        assert e2["coarse"]["data"]["n_batches"] == 5
+        est.max_rows_per_launch = 4
+        est.n_streams = 2
+        est.min_rows_per_stream = 2
+        f3, _ = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=3)
+    finally:
+        est.max_rows_per_launch, est.n_streams, est.min_rows_per_stream = old, 1, 64
+    assert (e1["coarse"]["data"]["logits"] - e2["coarse"]["data"]["logits"]).abs().max().item() < 1e-4
+    assert (f1.poses - f2.poses).abs().max().item() < 1e-5 and (f1.poses - f3.poses).abs().max().item() < 1e-5
+
+
+def test_coarse_estimates_entry_point_and_single_row(multi_scene):
+    """run_inference_pipeline(coarse_estimates=...) skips coarse + top-K (pose_estimator.py:587-590); 1 row, 1 iteration = config 1"""
+    from megapose6d_amd.tcoll import PandasTensorCollection
+
+    tmp, ds, est, obs, det = multi_scene
+    _, e = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=1, n_pose_hypotheses=1)
+    ce = e["coarse_filter"]["preds"]
+    one = PandasTensorCollection(ce.infos.iloc[[2]].copy(), poses=ce.poses[[2]].clone())
+    final, extra = est.run_inference_pipeline(obs, coarse_estimates=one, n_refiner_iterations=1)
+    assert extra["coarse"]["data"] is None and len(final) == 1
+    ref = e["refiner_all_hypotheses"]["preds"]["iteration=1"].poses[2]
+    assert (final.poses[0] - ref).abs().max().item() < 1e-5
+
+
+def test_degenerate_inputs(multi_scene):
+    from megapose6d_amd.tcoll import PandasTensorCollection
+
+    tmp, ds, est, obs, det = multi_scene
+    # unknown label -> KeyError (label -> mesh lookup, rigid_mesh_database.py:147 / panda3d_batch_renderer.py:243)
+    bad = PandasTensorCollection(det.infos.assign(label=["obj_000000", "nope", "obj_000001"]), bboxes=det.bboxes)
+    with pytest.raises(KeyError):
+        est.run_inference_pipeline(obs, detections=bad, n_refiner_iterations=1)
+    # missing required columns -> AssertionError (inference/types.py:77-86)
+    with pytest.raises(AssertionError):
+        est.forward_coarse_model(obs, PandasTensorCollection(pd.DataFrame(dict(label=["obj_000000"])), bboxes=det.bboxes[:1]))
+    # neither detections nor a detector
+    with pytest.raises(AssertionError):
+        est.run_inference_pipeline(obs)
+    # a non-finite hypothesis renders zeros and yields a finite logit; the other rows are unaffected
+    T = est.forward_coarse_model(obs, det)[0].poses[:4].clone()
+    ref = est.coarse_model.forward_coarse(obs.images, obs.K[[0]].repeat(4, 1, 1), ["obj_000000"] * 4, T,
+                                          im_ids=torch.zeros(4, dtype=torch.int32, device="cuda"))["logits"].clone()
+    T[1, 0, 3] = float("nan")
+    out = est.coarse_model.forward_coarse(obs.images, obs.K[[0]].repeat(4, 1, 1), ["obj_000000"] * 4, T,
+                                          im_ids=torch.zeros(4, dtype=torch.int32, device="cuda"), return_debug_data=True)
+    assert torch.equal(out["logits"][[0, 2, 3]], ref[[0, 2, 3]])
+    assert out["renders"][1].abs().max() == 0
+    # object far outside the frame: still finite outputs
+    T2 = T[[0]].clone()
+    T2[0, 0, 3] = 5.0
+    o2 = est.coarse_model.forward_coarse(obs.images, obs.K[[0]], ["obj_000000"], T2, im_ids=torch.zeros(1, dtype=torch.int32, device="cuda"))
+    assert torch.isfinite(o2["logits"]).all()
+
+
+def test_mesh_with_too_few_vertices_is_rejected(tmp_path):
+    """lib3d/mesh_ops.py:79: the deterministic 2000-point sampling asserts n_points <= n_vertices"""
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.mesh_db import MeshDataBase
+
+    v, f, c = syn.make_lathe_mesh(1, n_theta=16, n_z=20)
+    syn.write_ply(tmp_path / "small.ply", v, f, c)
+    db = MeshDataBase.from_object_ds(syn.RigidObjectDataset([syn.RigidObject("small", tmp_path / "small.ply", mesh_units="mm")])).batched()
+    with pytest.raises(AssertionError):
+        db.sampled_points(2000)
