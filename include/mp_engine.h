@@ -149,6 +149,15 @@ typedef struct {
 } mp_conv_desc;
 
 int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);
+
+/* OPTIONAL fast mode: the same fp32 convolution evaluated with bf16 MFMA through an EXACT 3-way split of every operand
+ * (x = hi + mid + lo, 3 x 8 mantissa bits; every partial product is exact in fp32, only the accumulation order differs from
+ * the native fp32-MFMA path).  n_products = 9 (all pairs) or 6 (drops the pairs weighing <= 2^-24).  d_w must point at a
+ * blob from mp_conv_pack_weights_split.  See csrc/conv_split.hip. */
+size_t mp_conv_packed_split_bytes(int Cin_p, int Cout, int KH, int KW);
+int mp_conv_pack_weights_split(const float* h_w_oihw, int Cout, int Cin, int KH, int KW, int Cin_p,
+                               const float* h_scale, void* h_packed);
+int mp_conv2d_nhwc_split(const mp_conv_desc* desc, int n_products, mp_stream stream);
 /* the name of the kernel instantiation mp_conv2d_nhwc would launch (for profiling)        */
 const char* mp_conv2d_kernel_name(const mp_conv_desc* desc);
 
@@ -182,6 +191,9 @@ typedef struct {
 /* views_logits_head.*.  head: 0 = pose_fc (9 outputs), 1 = views_logits_head (n_views).     */
 int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* h_state,
                        int n_tensors, mp_backbone** out);
+/* precision: 0 = native fp32 MFMA (default, what mp_backbone_create builds), 9 / 6 = bf16x9 / bf16x6 split emulation */
+int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* h_state,
+                          int n_tensors, int precision, mp_backbone** out);
 int mp_backbone_destroy(mp_backbone* bb);
 int mp_backbone_input_channels_padded(const mp_backbone* bb);
 int mp_backbone_input_border(const mp_backbone* bb);

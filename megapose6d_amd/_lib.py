@@ -82,10 +82,14 @@ SIGNATURES = {
     "mp_conv_packed_floats": (_sz, [_i, _i, _i, _i]),
     "mp_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "mp_conv_packed_split_bytes": (_sz, [_i, _i, _i, _i]),
+    "mp_conv_pack_weights_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mp_conv2d_nhwc_split": (_i, [C.POINTER(ConvDesc), _i, _vp]),
     "mp_conv2d_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
+    "mp_backbone_create_ex": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, _i, C.POINTER(_vp)]),
     "mp_backbone_destroy": (_i, [_vp]),
     "mp_backbone_input_channels_padded": (_i, [_vp]),
     "mp_backbone_input_border": (_i, [_vp]),

@@ -17,7 +17,7 @@ namespace mp {
 
 struct ConvLayer {
   int Cin, Cin_p, Cout, K, stride, pad;
-  float* d_w = nullptr;
+  float* d_w = nullptr;   // packed fp32 weights, or the bf16 split blob when the backbone runs in split mode
   float* d_b = nullptr;  // folded BN shift (may be null)
 };
 
@@ -38,6 +38,7 @@ using namespace mp;
 
 struct mp_backbone {
   int kind, c_in, c_in_p, in_border, head_kind, n_out, n_feat;
+  int precision = 0;  // 0 native fp32 MFMA, 9 / 6 bf16 split products
   bool wide;
   ConvLayer stem;
   std::vector<Block> blocks;
@@ -101,10 +102,18 @@ int make_conv(mp_backbone* bb, const StateMap& sm, const std::string& wkey, cons
     int rc = bn_affine(sm, bnkey, Cout, scale, shift);
     if (rc) return rc;
   }
-  std::vector<float> packed(mp_conv_packed_floats(Cin_p, Cout, K, K));
-  int rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
-  if (rc) return rc;
-  rc = upload(bb, packed, &L->d_w);
+  int rc;
+  if (bb->precision == 0) {
+    std::vector<float> packed(mp_conv_packed_floats(Cin_p, Cout, K, K));
+    rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
+    if (rc) return rc;
+    rc = upload(bb, packed, &L->d_w);
+  } else {
+    std::vector<float> packed((mp_conv_packed_split_bytes(Cin_p, Cout, K, K) + 3) / 4);
+    rc = mp_conv_pack_weights_split(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
+    if (rc) return rc;
+    rc = upload(bb, packed, &L->d_w);
+  }
   if (rc) return rc;
   if (!bnkey.empty()) {
     rc = upload(bb, shift, &L->d_b);
@@ -122,8 +131,8 @@ int make_bnact(mp_backbone* bb, const StateMap& sm, const std::string& bnkey, in
   return upload(bb, shift, &a->d_shift);
 }
 
-int run_conv(const ConvLayer& L, const float* x, int N, int H, int W, int in_border, float* y, int out_border, const float* res,
-             int relu, float* y_act, const BnAct* act, hipStream_t s) {
+int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, int H, int W, int in_border, float* y, int out_border,
+             const float* res, int relu, float* y_act, const BnAct* act, hipStream_t s) {
   mp_conv_desc d;
   memset(&d, 0, sizeof(d));
   d.d_x = x; d.N = N; d.H = H; d.W = W; d.C = L.Cin_p; d.c_real = L.Cin; d.in_border = in_border;
@@ -131,7 +140,7 @@ int run_conv(const ConvLayer& L, const float* x, int N, int H, int W, int in_bor
   d.d_y = y; d.out_border = out_border; d.d_residual = res; d.relu = relu;
   d.d_y_act = y_act;
   if (y_act) { d.d_act_scale = act->d_scale; d.d_act_shift = act->d_shift; }
-  return mp_conv2d_nhwc(&d, s);
+  return bb->precision == 0 ? mp_conv2d_nhwc(&d, s) : mp_conv2d_nhwc_split(&d, bb->precision, s);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -161,13 +170,20 @@ const int kStageC[4] = {64, 128, 256, 512};
 
 extern "C" int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
                                   mp_backbone** out) {
+  return mp_backbone_create_ex(kind, c_in, head_kind, n_head_out, st, n_tensors, 0, out);
+}
+
+extern "C" int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
+                                     int precision, mp_backbone** out) {
   MP_REQUIRE(out && st && n_tensors > 0, "mp_backbone_create: bad arguments");
+  MP_REQUIRE(precision == 0 || precision == 9 || precision == 6, "mp_backbone_create: precision must be 0, 9 or 6");
   MP_REQUIRE(kind >= 0 && kind <= 2, "mp_backbone_create: unknown backbone kind %d", kind);
   MP_REQUIRE(c_in >= 1 && c_in <= 64, "mp_backbone_create: bad c_in %d", c_in);
   StateMap sm;
   for (int i = 0; i < n_tensors; ++i) sm[st[i].name] = std::make_pair(st[i].h_data, st[i].numel);
   mp_backbone* bb = new mp_backbone();
   bb->kind = kind;
+  bb->precision = precision;
   bb->wide = kind != MP_BACKBONE_VANILLA_RESNET34;
   bb->c_in = c_in;
   bb->c_in_p = (c_in + 3) / 4 * 4;
@@ -279,7 +295,7 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
   }
   int rc;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
-  rc = run_conv(bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s);
+  rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s);
   if (rc) return rc;
   const Block& b0 = bb->blocks[0];
   rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, 64, 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
@@ -294,28 +310,28 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
     const bool last = (i + 1 == nb);
     if (!bb->wide) {
       // y1 = relu(bn1(conv1(x))); idn = bn(down(x)) | x; out = relu(bn2(conv2(y1)) + idn)
-      rc = run_conv(blk.conv1, A[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
+      rc = run_conv(bb, blk.conv1, A[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
       if (rc) return rc;
       const float* idn = A[si];
       if (blk.has_down) {
-        rc = run_conv(blk.down, A[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
+        rc = run_conv(bb, blk.down, A[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
         if (rc) return rc;
         idn = Cf[so];
       }
-      rc = run_conv(blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 1, nullptr, nullptr, s);
+      rc = run_conv(bb, blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 1, nullptr, nullptr, s);
       if (rc) return rc;
     } else {
       // a = relu(bn1(x)) was produced upstream into Aact[si]; residual = down(a) | x
-      rc = run_conv(blk.conv1, Aact[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
+      rc = run_conv(bb, blk.conv1, Aact[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
       if (rc) return rc;
       const float* idn = A[si];
       if (blk.has_down) {
-        rc = run_conv(blk.down, Aact[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
+        rc = run_conv(bb, blk.down, Aact[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
         if (rc) return rc;
         idn = Cf[so];
       }
       const BnAct* next_pre = last ? nullptr : &bb->blocks[i + 1].pre;
-      rc = run_conv(blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 0, last ? nullptr : Aact[so], next_pre, s);
+      rc = run_conv(bb, blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 0, last ? nullptr : Aact[so], next_pre, s);
       if (rc) return rc;
     }
   }

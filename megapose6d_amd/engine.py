@@ -200,7 +200,7 @@ def conv_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray
 def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int, w_packed: torch.Tensor,
                 bias: Optional[torch.Tensor], Cout: int, K: int, stride: int, pad: int, y: Optional[torch.Tensor], out_border: int,
                 residual: Optional[torch.Tensor] = None, relu: bool = False, y_act: Optional[torch.Tensor] = None,
-                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None) -> None:
+                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None, split_products: int = 0) -> None:
     lib = _lib.load()
     d = ConvDesc()
     d.d_x, d.N, d.H, d.W, d.C, d.in_border = x.data_ptr(), N, H, W, Cp, in_border
@@ -208,7 +208,21 @@ def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, stride, pad
     d.d_y, d.out_border, d.d_residual, d.relu = _ptr(y), out_border, _ptr(residual), int(relu)
     d.d_y_act, d.d_act_scale, d.d_act_shift = _ptr(y_act), _ptr(act_scale), _ptr(act_shift)
-    check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
+    if split_products:
+        check(lib.mp_conv2d_nhwc_split(C.byref(d), split_products, _stream()))
+    else:
+        check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
+
+
+def conv_pack_weights_split(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
+    """bf16 (hi, mid, lo) pieces for the split-precision conv; returns a uint8 blob"""
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin, KH, KW = w.shape
+    out = np.empty(lib.mp_conv_packed_split_bytes(cin_p, Cout, KH, KW), dtype=np.uint8)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    check(lib.mp_conv_pack_weights_split(w.ctypes.data, Cout, Cin, KH, KW, cin_p, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    return out
 
 
 def maxpool3x3s2(x, N, H, W, Cc, in_border, y, out_border, y_act=None, sc=None, sh=None) -> None:
@@ -224,7 +238,7 @@ def pool_fc_heads(x, N, H, W, Cc, in_border, fc_w, fc_b, n_feat, head_w, head_b,
 class Backbone:
     """mp_backbone: whole CNN + head resident on the device, one call per forward."""
 
-    def __init__(self, kind: str, c_in: int, head: str, n_out: int, state_dict: Dict[str, torch.Tensor]):
+    def __init__(self, kind: str, c_in: int, head: str, n_out: int, state_dict: Dict[str, torch.Tensor], precision: int = 0):
         lib = _lib.load()
         if kind not in BACKBONE_KINDS:
             raise EngineError(f"unknown backbone '{kind}' (pose_models_cfg.py:106-118 supports {list(BACKBONE_KINDS)})")
@@ -240,7 +254,8 @@ class Backbone:
         for i, (k, a) in enumerate(items):
             arr[i] = NamedTensor(k, a.ctypes.data, a.size)
         h = C.c_void_p()
-        check(lib.mp_backbone_create(BACKBONE_KINDS[kind], c_in, 0 if head == "pose" else 1, n_out, arr, len(items), C.byref(h)))
+        check(lib.mp_backbone_create_ex(BACKBONE_KINDS[kind], c_in, 0 if head == "pose" else 1, n_out, arr, len(items), precision, C.byref(h)))
+        self.precision = precision
         self.handle = h
         self.kind, self.c_in, self.n_out = kind, c_in, n_out
         self.c_in_p = lib.mp_backbone_input_channels_padded(h)
