@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--backbone", default="vanilla_resnet34")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="0 = native fp32 MFMA (default, what `value` is quoted on); 9 / 6 = optional bf16 split modes")
     a = ap.parse_args()
 
     from megapose6d_amd import distributed as mpd
@@ -111,7 +112,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix=f"mp_bench_r{rank}_")
     n_obj = world  # weak scaling: one object x 576 hypotheses per GPU
     est, obs, det, _ = make_scene(n_objects=n_obj, seed=0, backbone=a.backbone, SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1,
-                                   n_streams=int(os.environ.get("MP_N_STREAMS", "1")))
+                                   n_streams=int(os.environ.get("MP_N_STREAMS", "1")), precision=a.precision)
 
     def step():
         return est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=N_HYP)
@@ -139,23 +140,31 @@ def main():
     assert len(final) == n_obj and torch.isfinite(final.poses).all()
 
     if rank == 0:
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_nhwc_f32_mfma")}
+        conv = {k: v for k, v in prof.items() if k.startswith("conv_nhwc_f32")}
         dom_name = max(conv, key=lambda k: conv[k]["ms"])
         dom = conv[dom_name]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         all_conv_tf = sum(v["flops"] for v in conv.values()) / (sum(v["ms"] for v in conv.values()) * 1e-3) / 1e12
         kernel_ms = {k: round(v["ms"] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         rb = prof.get("raster_bands")
+        traffic, traffic_src = None, None
+        tfile = ROOT / "profiles" / "r01_conv_traffic.json"  # PMC cannot be sampled from inside the process: committed rocprofv3 summary
+        if tfile.is_file():
+            tj = json.loads(tfile.read_text())
+            k = tj["kernels"].get(dom_name.replace(" ", ""))
+            if k:
+                traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], tj["source"]
         out = {
             "metric": METRIC, "value": n_obj * N_HYP * a.steps / dt, "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == 0 else f"f32 via exact bf16x{a.precision} operand split (bf16 MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"megapose-1.0-RGB structure ({a.backbone} coarse 9ch + refiner 27ch), {n_obj} object(s) x 576 hypotheses x 5 refine "
                                    "iters (n_pose_hypotheses=576) + re-score, 640x480 frame, 240x320 crops, 10k-triangle meshes",
                        "rows_per_step": n_obj * (2 * N_HYP + N_HYP * N_ITERS), "views_per_step": n_obj * (2 * N_HYP + 4 * N_HYP * N_ITERS),
                        "parallelism": f"rows sharded rank::world over {world} GPU(s)", "arch": arch, "cus": n_cu},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": dom["launches"],
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic_src, "alg_bytes_per_launch": dom["bytes"] / dom["launches"], "launches": dom["launches"],
                          "avg_launch_ms": dom["ms"] / dom["launches"], "avg_launch_gflop": dom["flops"] / dom["launches"] / 1e9,
                          "all_conv_kernels_tflops": all_conv_tf},
             "raster": None if rb is None else {"bound": "hbm", "kernel": "raster_bands", "achieved_GBps": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9,

@@ -72,32 +72,39 @@ __device__ __forceinline__ void epilogue(const Params& p, const f32x16 (&acc)[TM
 }
 
 // exact 3-way truncation split of 4 floats -> three packed bf16x4 (8 bytes each)
+// v_perm_b32 selector 0x07060302: result = {hi16(second arg) in the low half, hi16(first arg) in the high half}
+__device__ __forceinline__ unsigned pack_hi16(unsigned e1, unsigned e0) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
   const float f[4] = {v.x, v.y, v.z, v.w};
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    h[i] = __float_as_uint(f[i]) & 0xFFFF0000u;
-    const float r = f[i] - __uint_as_float(h[i]);  // exact
-    m[i] = __float_as_uint(r) & 0xFFFF0000u;
-    const float q = r - __uint_as_float(m[i]);      // exact, <= 8 significant bits
+    h[i] = __float_as_uint(f[i]);                                   // only the upper 16 bits are kept by the packing below
+    const float r = f[i] - __uint_as_float(h[i] & 0xFFFF0000u);     // exact
+    m[i] = __float_as_uint(r);
+    const float q = r - __uint_as_float(m[i] & 0xFFFF0000u);        // exact, <= 8 significant bits
     l[i] = __float_as_uint(q);
   }
-  hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-  mid = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-  lo = make_uint2((l[0] >> 16) | (l[1] & 0xFFFF0000u), (l[2] >> 16) | (l[3] & 0xFFFF0000u));
+  hi = make_uint2(pack_hi16(h[1], h[0]), pack_hi16(h[3], h[2]));
+  mid = make_uint2(pack_hi16(m[1], m[0]), pack_hi16(m[3], m[2]));
+  lo = make_uint2(pack_hi16(l[1], l[0]), pack_hi16(l[3], l[2]));
 }
 
-template <int BM, int BN, int WM, int WN, int NPROD, bool RAGGED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_bf16split(Params p) {
-  static_assert(BM == 128 && (BN == 128 || BN == 64) && (BM / WM) * (BN / WN) == 4, "tile shape");
+template <int NW, int BM, int BN, int WM, int WN, int NPROD, bool RAGGED, bool DBUF>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_nhwc_f32_bf16split(Params p) {
+  static_assert(BM == 32 * NW && (BN == 128 || BN == 64) && (BM / WM) * (BN / WN) == NW, "tile shape");
+  constexpr int NT = NW * 64;      // threads
+  constexpr int RSTEP = NT / 8;    // A rows covered by one pass of the threads (8 lanes per 32-float row piece)
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int B_LD = 3 * BN * BK * 2 / 16 / 256;  // 16-byte loads per thread for the weight pieces (6 or 3)
+  constexpr int B_LD = 3 * BN * BK * 2 / 16 / NT;  // 16-byte loads per thread for the weight pieces (6 or 3)
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
-  unsigned short* As = smem_h;                       // [3][BM][LDH]
-  unsigned short* Bs = smem_h + 3 * BM * LDH;        // [3][BN][LDH]
-  int* row_off = (int*)(Bs + 3 * BN * LDH);          // [BM]
+  constexpr int NBUF = DBUF ? 2 : 1;
+  constexpr int A_SZ = 3 * BM * LDH, B_SZ = 3 * BN * LDH;   // bf16 elements per buffer
+  unsigned short* As0 = smem_h;                      // [NBUF][3][BM][LDH]
+  unsigned short* Bs0 = smem_h + NBUF * A_SZ;        // [NBUF][3][BN][LDH]
+  int* row_off = (int*)(Bs0 + NBUF * B_SZ);          // [BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / (BN / WN), wn = wave % (BN / WN);
@@ -109,13 +116,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* a_ptr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int m = m0 + a_r0 + 32 * i;
+    int m = m0 + a_r0 + RSTEP * i;
     m = m < p.M ? m : p.M - 1;
     const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, n = t / p.Ho;
     const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
     a_ptr[i] = p.x + pix * p.C;
   }
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     const int m = m0 + r;
     int off = -1;
     if (m < p.M) {
@@ -151,36 +158,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   a1 = *reinterpret_cast<const float4*>(a_ptr1 + aoff);              \
   a2 = *reinterpret_cast<const float4*>(a_ptr2 + aoff);              \
   a3 = *reinterpret_cast<const float4*>(a_ptr3 + aoff);              \
-  b0 = bp[0]; b1 = bp[256]; b2 = bp[512];                            \
-  if constexpr (B_LD == 6) { b3 = bp[768]; b4 = bp[1024]; b5 = bp[1280]; }
+  b0 = bp[0]; b1 = bp[NT]; b2 = bp[2 * NT];                          \
+  if constexpr (B_LD == 6) { b3 = bp[3 * NT]; b4 = bp[4 * NT]; b5 = bp[5 * NT]; }
 #define MPS_BST(Q, V)                                                                                     \
   {                                                                                                       \
-    const int idx = tid + 256 * (Q); /* 16-byte piece inside [3][BN][4 groups of 8 bf16] */                \
+    const int idx = tid + NT * (Q); /* 16-byte piece inside [3][BN][4 groups of 8 bf16] */                \
     const int s_ = idx / (BN * 4), rem = idx - s_ * (BN * 4);                                             \
-    *reinterpret_cast<uint4*>(Bs + (s_ * BN + (rem >> 2)) * LDH + (rem & 3) * 8) = (V);                   \
+    *reinterpret_cast<uint4*>(Bs_w + (s_ * BN + (rem >> 2)) * LDH + (rem & 3) * 8) = (V);                   \
   }
-#define MPS_STORE()                                                                                       \
+#define MPS_SPLIT()            \
+  split4(a0, h0, m0_, l0);     \
+  split4(a1, h1, m1_, l1);     \
+  split4(a2, h2, m2_, l2);     \
+  split4(a3, h3, m3_, l3);
+#define MPS_WRITE(BUF)                                                                                    \
   {                                                                                                       \
-    uint2 h, m, l;                                                                                        \
-    unsigned short* aw = As + a_r0 * LDH + a_c4 * 4;                                                      \
-    split4(a0, h, m, l);                                                                                  \
-    *reinterpret_cast<uint2*>(aw) = h; *reinterpret_cast<uint2*>(aw + BM * LDH) = m; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l; \
-    split4(a1, h, m, l); aw += 32 * LDH;                                                                  \
-    *reinterpret_cast<uint2*>(aw) = h; *reinterpret_cast<uint2*>(aw + BM * LDH) = m; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l; \
-    split4(a2, h, m, l); aw += 32 * LDH;                                                                  \
-    *reinterpret_cast<uint2*>(aw) = h; *reinterpret_cast<uint2*>(aw + BM * LDH) = m; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l; \
-    split4(a3, h, m, l); aw += 32 * LDH;                                                                  \
-    *reinterpret_cast<uint2*>(aw) = h; *reinterpret_cast<uint2*>(aw + BM * LDH) = m; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l; \
+    unsigned short* Bs_w = Bs0 + (BUF) * B_SZ;                                                            \
+    unsigned short* aw = As0 + (BUF) * A_SZ + a_r0 * LDH + a_c4 * 4;                                      \
+    *reinterpret_cast<uint2*>(aw) = h0; *reinterpret_cast<uint2*>(aw + BM * LDH) = m0_; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l0; \
+    aw += RSTEP * LDH;                                                                                     \
+    *reinterpret_cast<uint2*>(aw) = h1; *reinterpret_cast<uint2*>(aw + BM * LDH) = m1_; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l1; \
+    aw += RSTEP * LDH;                                                                                     \
+    *reinterpret_cast<uint2*>(aw) = h2; *reinterpret_cast<uint2*>(aw + BM * LDH) = m2_; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l2; \
+    aw += RSTEP * LDH;                                                                                     \
+    *reinterpret_cast<uint2*>(aw) = h3; *reinterpret_cast<uint2*>(aw + BM * LDH) = m3_; *reinterpret_cast<uint2*>(aw + 2 * BM * LDH) = l3; \
     MPS_BST(0, b0) MPS_BST(1, b1) MPS_BST(2, b2)                                                          \
     if constexpr (B_LD == 6) { MPS_BST(3, b3) MPS_BST(4, b4) MPS_BST(5, b5) }                             \
   }
+#define MPS_STORE(BUF) MPS_SPLIT() MPS_WRITE(BUF)
+  uint2 h0, m0_, l0, h1, m1_, l1, h2, m2_, l2, h3, m3_, l3;
 
   MPS_LOAD()
-  MPS_STORE()
+  MPS_STORE(0)
   __syncthreads();
 
   const int frow = lane & 31, fk = (lane >> 5) * 8;
   for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+    const int buf = DBUF ? (chunk & 1) : 0;
     if (chunk + 1 < p.n_chunks) {
       bp += 3 * BN * BK * 2 / 16;
       aoff += BK;
@@ -194,8 +208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     MPS_LOAD()
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned short* as = As + (wm * WM + frow) * LDH + fk;
-    const unsigned short* bs = Bs + (wn * WN + frow) * LDH + fk;
+    const unsigned short* as = As0 + buf * A_SZ + (wm * WM + frow) * LDH + fk;
+    const unsigned short* bs = Bs0 + buf * B_SZ + (wn * WN + frow) * LDH + fk;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[TM][3], bf[TN][3];
@@ -209,11 +223,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < 3; ++s)
           bf[jn][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + (s * BN + jn * 32) * LDH + ks * 16));
+      if constexpr (DBUF) {
+        if (ks == 1) {  // split + write the prefetched chunk into the other buffer under the last MFMA group
+          __builtin_amdgcn_sched_barrier(0);
+          MPS_STORE(buf ^ 1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        if (ks == 1) {  // split the prefetched A rows in registers under the last MFMA group (VALU and MFMA pipes overlap)
+          MPS_SPLIT()
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-          // smallest terms first; pairs (sa, sb) ordered by sa + sb descending
+          // smallest terms first
           if constexpr (NPROD == 9) {
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[jn][2], acc[i][jn], 0, 0, 0);
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[jn][2], acc[i][jn], 0, 0, 0);
@@ -227,13 +252,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[jn][0], acc[i][jn], 0, 0, 0);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // every wave is done reading the tile
-    MPS_STORE()
-    __syncthreads();
+    if constexpr (DBUF) {
+      __syncthreads();
+    } else {
+      __syncthreads();  // every wave is done reading the tile
+      MPS_WRITE(0)
+      __syncthreads();
+    }
   }
 #undef MPS_LOAD
 #undef MPS_STORE
+#undef MPS_SPLIT
+#undef MPS_WRITE
+#undef MPS_BST
 
   const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
   const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
@@ -251,20 +282,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 static inline int bn_tile(int Cout) { return Cout <= 64 ? 64 : 128; }
 
-template <int BN, int WM, int WN, int NPROD, bool RAGGED>
+template <int NW, int BN, int WM, int WN, int NPROD, bool RAGGED, bool DBUF>
 static int launch(Params p, hipStream_t s, double flops, double bytes) {
-  p.n_mblocks = ceil_div(p.M, 128);
+  constexpr int BM = 32 * NW;
+  p.n_mblocks = ceil_div(p.M, BM);
   p.n_nblocks = ceil_div(p.Cout, BN);
-  const size_t lds = (size_t)(3 * 128 * LDH + 3 * BN * LDH) * sizeof(unsigned short) + 128 * sizeof(int);
+  const size_t lds = (size_t)(DBUF ? 2 : 1) * (3 * BM * LDH + 3 * BN * LDH) * sizeof(unsigned short) + BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_bf16split<128, BN, WM, WN, NPROD, RAGGED>,
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_bf16split<NW, BM, BN, WM, WN, NPROD, RAGGED, DBUF>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   ProfScope prof(BN == 64 ? (NPROD == 9 ? "conv_nhwc_f32_bf16x9<128,64>" : "conv_nhwc_f32_bf16x6<128,64>")
-                          : (NPROD == 9 ? "conv_nhwc_f32_bf16x9<128,128>" : "conv_nhwc_f32_bf16x6<128,128>"), flops, bytes, s);
-  hipLaunchKernelGGL((conv_nhwc_f32_bf16split<128, BN, WM, WN, NPROD, RAGGED>), dim3(p.n_mblocks * p.n_nblocks), dim3(256), lds, s, p);
+                 : NW == 8 ? (NPROD == 9 ? "conv_nhwc_f32_bf16x9<256,128>" : "conv_nhwc_f32_bf16x6<256,128>")
+                           : (NPROD == 9 ? "conv_nhwc_f32_bf16x9<128,128>" : "conv_nhwc_f32_bf16x6<128,128>"), flops, bytes, s);
+  hipLaunchKernelGGL((conv_nhwc_f32_bf16split<NW, BM, BN, WM, WN, NPROD, RAGGED, DBUF>), dim3(p.n_mblocks * p.n_nblocks), dim3(NW * 64), lds, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
@@ -338,11 +371,17 @@ extern "C" int mp_conv2d_nhwc_split(const mp_conv_desc* d, int n_products, mp_st
   const double flops = 2.0 * (double)M * d->Cout * d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
   const double bytes = 4.0 * ((double)M * d->stride * d->stride * d->C + (double)M * d->Cout) + 6.0 * p.n_chunks * split::BK * d->Cout;
   hipStream_t s = (hipStream_t)stream;
+  static const bool dbuf = getenv("MP_SPLIT_DBUF") ? atoi(getenv("MP_SPLIT_DBUF")) != 0 : false;  // tuning knob: single-buffered LDS keeps 2 workgroups per CU and measured faster
   const bool small = split::bn_tile(d->Cout) == 64, ragged = p.run % split::BK != 0, nine = n_products == 9;
-#define MPS_GO(BN, WM, WN)                                                                                   \
-  return nine ? (ragged ? split::launch<BN, WM, WN, 9, true>(p, s, flops, bytes) : split::launch<BN, WM, WN, 9, false>(p, s, flops, bytes)) \
-              : (ragged ? split::launch<BN, WM, WN, 6, true>(p, s, flops, bytes) : split::launch<BN, WM, WN, 6, false>(p, s, flops, bytes));
-  if (small) { MPS_GO(64, 64, 32) }
-  MPS_GO(128, 64, 64)
+#define MPS_GO(NW, BN, WM, WN)                                                                               \
+  if (dbuf)                                                                                                   \
+    return nine ? (ragged ? split::launch<NW, BN, WM, WN, 9, true, true>(p, s, flops, bytes) : split::launch<NW, BN, WM, WN, 9, false, true>(p, s, flops, bytes)) \
+                : (ragged ? split::launch<NW, BN, WM, WN, 6, true, true>(p, s, flops, bytes) : split::launch<NW, BN, WM, WN, 6, false, true>(p, s, flops, bytes)); \
+  return nine ? (ragged ? split::launch<NW, BN, WM, WN, 9, true, false>(p, s, flops, bytes) : split::launch<NW, BN, WM, WN, 9, false, false>(p, s, flops, bytes)) \
+              : (ragged ? split::launch<NW, BN, WM, WN, 6, true, false>(p, s, flops, bytes) : split::launch<NW, BN, WM, WN, 6, false, false>(p, s, flops, bytes));
+  static const bool big = getenv("MP_SPLIT_BIG") ? atoi(getenv("MP_SPLIT_BIG")) != 0 : false;  // 256x128 tile, 8 waves: measured equal to 128x128 (tuning knob)
+  if (small) { MPS_GO(4, 64, 64, 32) }
+  if (big && !dbuf) { MPS_GO(8, 128, 64, 64) }
+  MPS_GO(4, 128, 64, 64)
 #undef MPS_GO
 }

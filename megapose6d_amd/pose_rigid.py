@@ -154,7 +154,9 @@ class PosePredictor(nn.Module):
     def _backbone_engine(self) -> eng.Backbone:
         if self._engine_bb is None:
             head, n_out = ("pose", 9) if self.predict_pose_update else ("logits", self.n_rendered_views)
-            self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict())
+            # conv_precision: 0 = native fp32 MFMA (default); 9 / 6 = optional bf16 split modes (csrc/conv_split.hip)
+            self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict(),
+                                           precision=int(getattr(self, "conv_precision", 0)))
         return self._engine_bb
 
     def _x_buffer(self, rows: int, device, slot: int = 0) -> torch.Tensor:
