@@ -86,6 +86,38 @@ def cpu_baseline(tmp_dir: str, obs_images: torch.Tensor, K: torch.Tensor, bboxes
                       "linearly per stage; Panda3D replaced by the oracle's C rasteriser"}
 
 
+def extras(est, obs, det, steps: int) -> dict:
+    """Secondary numbers (NOT `value`): the released inference parameters (n_pose_hypotheses = 1 / 5) and the
+    optional split-precision conv modes on the headline workload.  Same timing discipline, 1 warm-up + `steps` timed calls."""
+
+    def timed(k_hyp: int) -> float:
+        est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=k_hyp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=k_hyp)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    out = {}
+    for k in (1, 5):
+        dt = timed(k)
+        out[f"n_pose_hypotheses={k}"] = {"ms_per_call": dt * 1e3, "coarse_hypotheses_per_s": N_HYP / dt,
+                                         "note": "576 coarse rows + K x 5 refine rows + K score rows (megapose-1.0-RGB[-multi-hypothesis] defaults)"}
+    for prec in (9, 6):
+        for m in (est.coarse_model, est.refiner_model):
+            m.conv_precision = prec
+            m._engine_bb = None
+        dt = timed(N_HYP)
+        out[f"conv_bf16x{prec}_split"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
+                                          "note": "optional mode: fp32 operands split exactly into 3 bf16 pieces, bf16 MFMA, fp32 accumulate; "
+                                                  "meets the same parity bounds (tests/test_gpu_pipeline.py), not used for `value`"}
+    for m in (est.coarse_model, est.refiner_model):
+        m.conv_precision = 0
+        m._engine_bb = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--backbone", default="vanilla_resnet34")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (faithful K=1/K=5 configs, optional split-precision modes)")
     ap.add_argument("--precision", type=int, default=0, help="0 = native fp32 MFMA (default, what `value` is quoted on); 9 / 6 = optional bf16 split modes")
     a = ap.parse_args()
 
@@ -173,6 +206,8 @@ def main():
             "stage_s": {"coarse": extra["coarse"]["data"]["time"], "refiner": extra["refiner"]["data"]["time"],
                         "scoring": extra["scoring"]["data"]["time"], "total": extra["time"]},
         }
+        if world == 1 and not a.no_extras:
+            out["extras"] = extras(est, obs, det, a.steps)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tmp, obs.images, obs.K, det.bboxes)
             out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
