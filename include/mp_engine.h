@@ -241,6 +241,20 @@ int mp_pose_update(const float* d_TCO /*[b,4,4]*/, const float* d_K_crop /*[b,3,
                    int k_stride_floats, const float* d_out9 /*[b,9]*/, const float* d_tCR /*[b,3]*/, int b,
                    float* d_TCO_out, mp_stream stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* Depth refiner (ICP): replaces inference/icp_refiner.py:128-175 icp_refinement +          */
+/* :195-262 ICPRefiner.refine_poses (masks refiner_utils.py:30-56).  The reference's ICP    */
+/* core is OpenCV-contrib ppf_match_3d_ICP (third party, parity unpinned); this is a        */
+/* projective point-to-plane ICP with the same budget / acceptance rule (csrc/icp.hip).     */
+/* d_depth_meas [n_images,H,W] metres (0 = invalid), d_depth_rend [n_rows,H,W] rendered at  */
+/* d_TCO, d_K_images [n_images,3,3], d_K_rows [n_rows,3,3].  retval[n] = 0 ok / -1 kept.    */
+/* ------------------------------------------------------------------------------------ */
+size_t mp_icp_workspace_bytes(int n_images, int n_rows, int H, int W);
+int mp_icp_refine(const float* d_depth_meas, int n_images, const int32_t* d_im_ids, const float* d_depth_rend,
+                  const float* d_K_images, const float* d_K_rows, const float* d_TCO, int n_rows, int H, int W,
+                  int n_iterations, int n_levels, float tolerance, int n_min_points, float* d_TCO_out,
+                  int32_t* d_retval, float* d_residual, void* d_workspace, size_t workspace_bytes, mp_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

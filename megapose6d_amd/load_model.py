@@ -169,7 +169,9 @@ def load_named_model(model_name: str, object_dataset, n_workers: int = 4, bsz_im
         models_root=LOCAL_DATA_DIR / "megapose-models")
     depth_refiner = None
     if model.get("depth_refiner", None) == "ICP":
-        raise NotImplementedError("the ICP depth refiner is a 'next' row (SURVEY.md section 8f-1)")
+        from .icp_refiner import ICPRefiner
+
+        depth_refiner = ICPRefiner(mesh_db, refiner_model.renderer)
     return PoseEstimator(refiner_model=refiner_model, coarse_model=coarse_model, detector_model=None, depth_refiner=depth_refiner,
                          bsz_objects=8, bsz_images=bsz_images)
 

@@ -1,0 +1,95 @@
+"""CPU (numpy, float64 accumulation) restatement of the engine's depth refiner (megapose6d_amd/csrc/icp.hip).
+TEST INFRASTRUCTURE ONLY.
+
+What it follows in the reference: masks /root/reference/src/megapose/inference/refiner_utils.py:30-56 (threshold 0.1 m),
+valid range 0.2..5 m, back-projection and centroid pre-alignment /root/reference/src/megapose/inference/icp_refiner.py:98-125,
+:140-162, acceptance rule :172-175, :257-258.  The ICP core of the reference is OpenCV-contrib ppf_match_3d_ICP (third-party,
+absent -> "parity unpinned"); engine and oracle both implement projective point-to-plane ICP, 4 levels x 25 iterations.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def target_normals(depth: np.ndarray, K: np.ndarray) -> np.ndarray:
+    H, W = depth.shape
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    ys, xs = np.mgrid[0:H, 0:W]
+    xm, xp = np.maximum(xs - 2, 0), np.minimum(xs + 2, W - 1)
+    ym, yp = np.maximum(ys - 2, 0), np.minimum(ys + 2, H - 1)
+    d = depth.astype(np.float32)
+    dl, dr, du, dd = d[ys, xm], d[ys, xp], d[ym, xs], d[yp, xs]
+    ok = (d > 0) & (dl > 0) & (dr > 0) & (du > 0) & (dd > 0)
+    f = np.float32
+    ax = (xp - cx).astype(f) * dr / f(fx) - (xm - cx).astype(f) * dl / f(fx)
+    ay = (ys - cy).astype(f) * (dr - dl) / f(fy)
+    az = dr - dl
+    bx = (xs - cx).astype(f) * (dd - du) / f(fx)
+    by = (yp - cy).astype(f) * dd / f(fy) - (ym - cy).astype(f) * du / f(fy)
+    bz = dd - du
+    n = np.stack([ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx], -1).astype(np.float64)
+    ln = np.linalg.norm(n, axis=-1, keepdims=True)
+    ok &= ln[..., 0] > 0
+    n = n / np.where(ln > 0, ln, 1)
+    n = np.where(n[..., 2:3] > 0, -n, n)
+    return np.where(ok[..., None], n, 0.0)
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def icp_refine(depth_meas, depth_rend, K, TCO, n_iterations=100, n_levels=4, tolerance=0.05, n_min_points=1000):
+    """one object: returns (TCO_refined, retval, residual)"""
+    H, W = depth_meas.shape
+    fx, fy, cx, cy = [float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])]
+    dm, dr = depth_meas.astype(np.float64), depth_rend.astype(np.float64)
+    mask = (dm > 0) & (dr > 0) & (np.abs(dm - dr) <= 0.1) & (dm > 0.2) & (dm < 5.0)
+    if mask.sum() < n_min_points:
+        return TCO.copy(), -1, -1.0
+    ys, xs = np.mgrid[0:H, 0:W]
+    bp = lambda d: np.stack([(xs - cx) * d / fx, (ys - cy) * d / fy, d], -1)
+    P_t, P_s = bp(dm), bp(dr)
+    normals = target_normals(depth_meas, K)
+    T = np.eye(4)
+    T[:3, 3] = P_t[mask].mean(0) - P_s[mask].mean(0)
+    per = -(-n_iterations // n_levels)
+    residual = -1.0
+    for l in range(n_levels):
+        stride = 1 << (n_levels - 1 - l)
+        d_max = tolerance * (n_levels - l)
+        sub = np.zeros_like(mask)
+        sub[::stride, ::stride] = True
+        S0 = P_s[mask & sub]
+        for _ in range(per):
+            S = S0 @ T[:3, :3].T + T[:3, 3]
+            ok = S[:, 2] > 0.05
+            qx = np.rint(fx * S[:, 0] / np.where(ok, S[:, 2], 1) + cx).astype(np.int64)
+            qy = np.rint(fy * S[:, 1] / np.where(ok, S[:, 2], 1) + cy).astype(np.int64)
+            ok &= (qx >= 0) & (qx < W) & (qy >= 0) & (qy < H)
+            qx, qy = np.clip(qx, 0, W - 1), np.clip(qy, 0, H - 1)
+            zt = dm[qy, qx]
+            nt = normals[qy, qx]
+            ok &= (zt > 0.2) & (zt < 5.0) & (np.abs(nt).sum(1) > 0)
+            Tt = np.stack([(qx - cx) * zt / fx, (qy - cy) * zt / fy, zt], -1)
+            D = S - Tt
+            ok &= (D * D).sum(1) <= d_max * d_max
+            if ok.sum() < 50:
+                return TCO.copy(), -1, -1.0
+            S_, n_, r = S[ok], nt[ok], (nt[ok] * D[ok]).sum(1)
+            J = np.concatenate([np.cross(S_, n_), n_], 1)
+            A = J.T @ J + 1e-9 * ok.sum() * np.eye(6)
+            x = np.linalg.solve(A, -(J.T @ r))
+            residual = float(np.sqrt((r * r).mean()))
+            Tn = np.eye(4)
+            Tn[:3, :3] = _rodrigues(x[:3])
+            Tn[:3, 3] = x[3:]
+            T = Tn @ T
+    if not (0 <= residual <= tolerance):
+        return TCO.copy(), -1, residual
+    return (T @ TCO.astype(np.float64)).astype(np.float32), 0, residual

@@ -1,0 +1,90 @@
+"""-m gpu: depth refiner (ICP).  The reference's ICP core is OpenCV ppf_match_3d_ICP (parity unpinned); the engine's algorithm
+is checked against its own CPU oracle (oracle/icp.py) and on what ICP must do: pull a perturbed pose back onto the measured depth."""
+import tempfile
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene():
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.renderer import Panda3dBatchRenderer
+    from megapose6d_amd.types import Panda3dLightData
+
+    ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_icp_"), n_objects=2, seed=31)
+    r = Panda3dBatchRenderer(ds, n_workers=1)
+    rng = np.random.RandomState(3)
+    K = torch.from_numpy(syn.K_EXAMPLE.astype(np.float32)).cuda()
+    gt = np.stack([syn.random_pose(rng, (0.45, 0.6), 0.2), syn.random_pose(rng, (0.5, 0.7), 0.2)])
+    gt[1, 0, 3] += 0.15
+    labels = [o.label for o in ds.list_objects]
+    amb = [[Panda3dLightData("ambient")]] * 2
+    d = r.render(labels, torch.from_numpy(gt).cuda(), K[None].repeat(2, 1, 1), amb, (480, 640), render_depth=True).depths[:, 0]
+    depth = torch.where((d[0] > 0) & ((d[1] == 0) | (d[0] < d[1])), d[0], d[1])
+    g = torch.Generator().manual_seed(0)
+    depth = torch.where(depth > 0, depth + (torch.randn(480, 640, generator=g) * 0.001).cuda(), depth)
+    return ds, r, labels, K, gt, depth
+
+
+def _perturb(T, rng, rot_deg=3.0, trans=0.008):
+    a = np.deg2rad(rot_deg) * rng.uniform(-1, 1, 3)
+    from oracle.icp import _rodrigues
+
+    P = T.copy().astype(np.float64)
+    P[:3, :3] = _rodrigues(a) @ P[:3, :3]
+    P[:3, 3] += rng.uniform(-trans, trans, 3)
+    return P.astype(np.float32)
+
+
+def test_icp_refiner_vs_oracle_and_ground_truth():
+    from megapose6d_amd.icp_refiner import ICPRefiner
+    from megapose6d_amd.tcoll import PandasTensorCollection
+    from megapose6d_amd.types import Panda3dLightData
+    from oracle import icp as oicp
+
+    ds, r, labels, K, gt, depth = _scene()
+    rng = np.random.RandomState(8)
+    init = np.stack([_perturb(gt[0], rng), _perturb(gt[1], rng), _perturb(gt[0], rng, 1.0, 0.3)])  # row 2: 30 cm off -> rejected
+    lab3 = [labels[0], labels[1], labels[0]]
+    preds = PandasTensorCollection(pd.DataFrame(dict(label=lab3, batch_im_id=0, instance_id=[0, 0, 1])), poses=torch.from_numpy(init).cuda())
+    ref = ICPRefiner(None, r)
+    out, extra = ref.refine_poses(preds, depth=depth[None], K=K[None])
+    assert torch.equal(out.poses_input, preds.poses)
+    retval = extra["retval"].cpu().numpy()
+    assert retval.tolist() == [0, 0, -1]
+    assert torch.equal(out.poses[2], preds.poses[2])  # rejected -> input pose kept (icp_refiner.py:257-258)
+    # oracle of the same algorithm on the same rendered depth
+    amb = [[Panda3dLightData("ambient")]] * 3
+    rend = r.render(lab3, torch.from_numpy(init).cuda(), K[None].repeat(3, 1, 1), amb, (480, 640), render_depth=True).depths[:, 0].cpu().numpy()
+    dm = depth.cpu().numpy()
+    Kn = K.cpu().numpy()
+    for n in range(3):
+        T_o, rv_o, res_o = oicp.icp_refine(dm, rend[n], Kn, init[n])
+        assert rv_o == retval[n]
+        if rv_o == 0:
+            assert np.abs(out.poses[n].cpu().numpy() - T_o).max() < 2e-4
+            assert abs(extra["residual"][n].item() - res_o) < 1e-4
+    # it actually refines: translation error w.r.t. the ground truth shrinks by > 3x; the rotation error does not grow (the lathe
+    # meshes are close to surfaces of revolution: the spin about their axis is barely observable from depth)
+    for n in range(2):
+        e0 = np.linalg.norm(init[n][:3, 3] - gt[n][:3, 3])
+        e1 = np.linalg.norm(out.poses[n].cpu().numpy()[:3, 3] - gt[n][:3, 3])
+        r0 = np.linalg.norm(init[n][:3, :3] - gt[n][:3, :3])
+        r1 = np.linalg.norm(out.poses[n].cpu().numpy()[:3, :3] - gt[n][:3, :3])
+        assert e1 < e0 / 3 and r1 < r0, (n, e0, e1, r0, r1)
+
+
+def test_pipeline_with_depth_refiner():
+    """run_inference_pipeline(run_depth_refiner=True) (pose_estimator.py:607-616): extra_data['depth_refiner'] and final poses"""
+    from megapose6d_amd.icp_refiner import ICPRefiner
+    from megapose6d_amd.scene import make_scene
+
+    est, obs, det, gt = make_scene(n_objects=1, seed=0, SO3_grid_size=72, rgbd=True)
+    est.depth_refiner = ICPRefiner(est.mesh_db, est.refiner_model.renderer)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=1, n_pose_hypotheses=1, run_depth_refiner=True)
+    assert "depth_refiner" in extra and len(final) == 1 and torch.isfinite(final.poses).all()
+    assert "depth refiner=" in extra["timing_str"]

@@ -168,3 +168,26 @@ def test_oracle_pipeline_against_reference_orchestration(pipeline_gold, tmp_path
     # render-request count predicted by SURVEY.md section 3: M + K*n_iter*4 + K
     assert renderer.n_views == int(g["n_render_views"]) == 72 + 2 * 3 * 4 + 2
     assert set(["coarse", "coarse_filter", "refiner", "refiner_all_hypotheses", "scoring", "time", "timing_str"]) <= set(g["extra_keys"].tolist())
+
+
+def test_icp_oracle_recovers_known_offset():
+    """oracle/icp.py on a closed-form depth map: a 4 mm depth offset + 2 px shift is pulled back; too few points -> rejected"""
+    import numpy as np
+
+    from oracle import icp
+
+    H, W = 120, 160
+    K = np.array([[150, 0, 80], [0, 150, 60], [0, 0, 1.0]])
+    ys, xs = np.mgrid[0:H, 0:W]
+    surf = lambda x, y: (0.6 + 0.05 * np.sin(x / 9.0) * np.cos(y / 7.0)).astype(np.float32)
+    meas = surf(xs, ys)
+    meas[:20] = 0
+    rend = surf(xs + 2.0, ys) + 0.004
+    T = np.eye(4, dtype=np.float32)
+    T_ref, rv, res = icp.icp_refine(meas, rend, K, T, n_min_points=500)
+    assert rv == 0 and 0 <= res < 2e-3
+    assert -0.006 < T_ref[2, 3] < -0.002          # moves the model back towards the measurement
+    _, rv2, _ = icp.icp_refine(meas, rend, K, T, n_min_points=10 ** 6)
+    assert rv2 == -1
+    n = icp.target_normals(meas, K)
+    assert np.allclose(np.linalg.norm(n[40:100, 20:140], axis=-1), 1.0, atol=1e-6) and (n[..., 2] <= 0).all()
