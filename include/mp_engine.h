@@ -63,6 +63,14 @@ typedef struct {
 } mp_mesh_desc;
 
 int mp_mesh_db_create(const mp_mesh_desc* h_meshes, int n_meshes, mp_mesh_db** out);
+/* UV texture of mesh `mesh_id` (replaces Panda3D's assimp/texture loading, panda3d_scene_renderer.py:192-207: the albedo of a
+ * textured RigidObject): h_uvs = per-corner (u,v) [n_faces][3][2] float32 in the corner order of h_faces (v = 0 at the FIRST
+ * texel row passed here, i.e. the host flips image rows so that v grows with the row index); h_texels = RGBA8 mip chain, level l
+ * of size max(1,w>>l) x max(1,h>>l), levels concatenated (built on the host: megapose6d_amd.mesh_io.build_mip_chain).
+ * Sampling: repeat wrap, bilinear, per-triangle level selection; albedo = vertex colour x texel / 255. */
+#define MP_TEX_MAX_LEVELS 15
+int mp_mesh_db_set_texture(mp_mesh_db* db, int mesh_id, const float* h_uvs, const uint32_t* h_texels, int tex_w, int tex_h,
+                           int n_levels);
 int mp_mesh_db_destroy(mp_mesh_db* db);
 int mp_mesh_db_max_vertices(const mp_mesh_db* db);
 /* bounding-sphere radius (AABB centre) of mesh i, used for the point-light placement

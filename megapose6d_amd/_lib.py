@@ -71,6 +71,7 @@ SIGNATURES = {
     "mp_profile_query": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mp_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "mp_mesh_db_create": (_i, [C.POINTER(MeshDesc), _i, C.POINTER(_vp)]),
+    "mp_mesh_db_set_texture": (_i, [_vp, _i, _vp, _vp, _i, _i, _i]),
     "mp_mesh_db_destroy": (_i, [_vp]),
     "mp_mesh_db_max_vertices": (_i, [_vp]),
     "mp_mesh_db_radius": (_f, [_vp, _i]),

@@ -14,6 +14,8 @@
 //     fragments outside [near, far] = [0.1, 10] m are discarded
 //   * attributes interpolated perspective-correctly; RGB = albedo * light; normals through the 32^3 LUT
 //     (separable, linear filter, repeat wrap); uint8 quantisation then /255.
+//   * albedo = vertex colour, modulated for UV-textured meshes by a bilinear, repeat-wrapped sample of a host-built
+//     RGBA8 mip chain; the mip level is chosen per triangle from its texel-area / pixel-area ratio (thresholds 2, 8, 32, ...).
 //
 // Structure: (1) raster_transform: one thread per (view, vertex) -> {X, Y (fixed point), 1/z, valid}
 //            (2) raster_bands: one workgroup per (view, band of BAND_H rows): 64-bit {depth,tri} z-buffer in
@@ -48,6 +50,11 @@ struct MeshDev {
   int n_verts, n_faces;
   float radius;
   float center[3];
+  // UV texture (optional): per-corner uv [n_faces][3][2]; RGBA8 mip chain, level l at texels + tex_off[l], size (w>>l, h>>l) >= 1
+  const float* uvs;
+  const uint32_t* texels;
+  int tex_w, tex_h, tex_levels;
+  int tex_off[MP_TEX_MAX_LEVELS];
 };
 
 struct VtxRec {
@@ -216,6 +223,43 @@ __device__ __forceinline__ float normal_lut(float n) {
   return fmaf(b - a, f, a);
 }
 
+// Texture sample (contract shared with oracle/raster.c): repeat wrap, texel centres at (i + .5) / size, bilinear, result on the
+// 0..255 scale per channel.
+__device__ __forceinline__ void tex_sample(const MeshDev& m, int level, float u, float v, float& r, float& g, float& b) {
+  const int tw = max(1, m.tex_w >> level), th = max(1, m.tex_h >> level);
+  const uint32_t* tx = m.texels + m.tex_off[level];
+  const float fu = fmaf(u - floorf(u), (float)tw, -0.5f), fv = fmaf(v - floorf(v), (float)th, -0.5f);
+  const float flu = floorf(fu), flv = floorf(fv);
+  const float au = fu - flu, av = fv - flv;
+  int x0 = (int)flu, y0 = (int)flv;
+  if (x0 < 0) x0 = tw - 1;
+  if (y0 < 0) y0 = th - 1;
+  if (x0 >= tw) x0 = tw - 1;   // u - floor(u) can round to 1.0f for tiny negative u
+  if (y0 >= th) y0 = th - 1;
+  const int x1 = (x0 + 1 == tw) ? 0 : x0 + 1, y1 = (y0 + 1 == th) ? 0 : y0 + 1;
+  const uint32_t t00 = tx[y0 * tw + x0], t01 = tx[y0 * tw + x1], t10 = tx[y1 * tw + x0], t11 = tx[y1 * tw + x1];
+  float out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a00 = (float)((t00 >> (8 * c)) & 255u), a01 = (float)((t01 >> (8 * c)) & 255u);
+    const float a10 = (float)((t10 >> (8 * c)) & 255u), a11 = (float)((t11 >> (8 * c)) & 255u);
+    const float top = fmaf(a01 - a00, au, a00), bot = fmaf(a11 - a10, au, a10);
+    out[c] = fmaf(bot - top, av, top);
+  }
+  r = out[0]; g = out[1]; b = out[2];
+}
+
+// mip level of a triangle: texels per pixel r = |uv area| * w * h / (screen area); level = #thresholds {2, 8, 32, ...} below r
+__device__ __forceinline__ int tex_level(const MeshDev& m, const float* uv, float inv_area2) {
+  const float du1 = uv[2] - uv[0], dv1 = uv[3] - uv[1], du2 = uv[4] - uv[0], dv2 = uv[5] - uv[1];
+  const float at = fabsf(du1 * dv2 - du2 * dv1) * ((float)m.tex_w * (float)m.tex_h);
+  const float r = at * (inv_area2 * 65536.0f);   // inv_area2 = 1 / (2 * area in 1/256-px units)
+  int level = 0;
+  float thr = 2.0f;
+  while (level + 1 < m.tex_levels && r > thr) { ++level; thr *= 4.0f; }
+  return level;
+}
+
 __device__ __forceinline__ float quant8(float v255) {
   const float q = floorf(fminf(fmaxf(v255, 0.f), 255.f) + 0.5f);
   return q / 255.0f;
@@ -336,6 +380,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
       int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
       const VtxRec v0 = vv[i0];
       VtxRec v1 = vv[i1], v2 = vv[i2];
+      const int i1_in = i1;
       const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, py, py);
       float b0, b1, b2, wsum;
       (void)sample_tri(s, px, py, b0, b1, b2, wsum);
@@ -346,6 +391,15 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
       float ar = fmaf(w2, c2[0], fmaf(w1, c1[0], w0 * c0[0])) * z;
       float ag = fmaf(w2, c2[1], fmaf(w1, c1[1], w0 * c0[1])) * z;
       float ab = fmaf(w2, c2[2], fmaf(w1, c1[2], w0 * c0[2])) * z;
+      if (m.uvs) {
+        const float* uv = m.uvs + 6 * (size_t)t;
+        const int k1 = (i1 == i1_in) ? 1 : 2, k2 = 3 - k1;   // corner slots follow the orientation swap
+        const float u = fmaf(w2, uv[2 * k2], fmaf(w1, uv[2 * k1], w0 * uv[0])) * z;
+        const float v = fmaf(w2, uv[2 * k2 + 1], fmaf(w1, uv[2 * k1 + 1], w0 * uv[1])) * z;
+        float tr, tg, tb2;
+        tex_sample(m, tex_level(m, uv, s.inv_area), u, v, tr, tg, tb2);
+        ar *= tr / 255.0f; ag *= tg / 255.0f; ab *= tb2 / 255.0f;
+      }
       const float* n0 = m.normals + 3 * i0; const float* n1 = m.normals + 3 * i1; const float* n2 = m.normals + 3 * i2;
       // interpolated object-frame normal (perspective-correct, NOT renormalised: texcoord semantics)
       const float onx = fmaf(w2, n2[0], fmaf(w1, n1[0], w0 * n0[0])) * z;
@@ -446,6 +500,8 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
     db->allocs.push_back(dv); db->allocs.push_back(dn); db->allocs.push_back(dc); db->allocs.push_back(df);
     m.verts = dv; m.normals = dn; m.colors = dc; m.faces = df;
     m.n_verts = d.n_vertices; m.n_faces = d.n_faces;
+    m.uvs = nullptr; m.texels = nullptr; m.tex_w = m.tex_h = m.tex_levels = 0;
+    for (int l = 0; l < MP_TEX_MAX_LEVELS; ++l) m.tex_off[l] = 0;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int v = 0; v < d.n_vertices; ++v)
       for (int k = 0; k < 3; ++k) {
@@ -470,6 +526,29 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
   MP_CHECK_HIP(hipMalloc(&db->d_meshes, n * sizeof(MeshDev)));
   MP_CHECK_HIP(hipMemcpy(db->d_meshes, db->h_meshes.data(), n * sizeof(MeshDev), hipMemcpyHostToDevice));
   *out = db;
+  return MP_OK;
+}
+
+extern "C" int mp_mesh_db_set_texture(mp_mesh_db* db, int mesh_id, const float* h_uvs, const uint32_t* h_texels, int tex_w, int tex_h,
+                                      int n_levels) {
+  MP_REQUIRE(db && mesh_id >= 0 && mesh_id < db->n && h_uvs && h_texels, "mp_mesh_db_set_texture: bad arguments");
+  MP_REQUIRE(tex_w > 0 && tex_h > 0 && tex_w <= 16384 && tex_h <= 16384 && n_levels >= 1 && n_levels <= MP_TEX_MAX_LEVELS,
+             "mp_mesh_db_set_texture: bad texture size %dx%d / %d levels", tex_w, tex_h, n_levels);
+  MeshDev& m = db->h_meshes[mesh_id];
+  size_t total = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    m.tex_off[l] = (int)total;
+    total += (size_t)std::max(1, tex_w >> l) * std::max(1, tex_h >> l);
+  }
+  float* duv;
+  uint32_t* dtex;
+  MP_CHECK_HIP(hipMalloc(&duv, (size_t)m.n_faces * 6 * sizeof(float)));
+  MP_CHECK_HIP(hipMalloc(&dtex, total * sizeof(uint32_t)));
+  MP_CHECK_HIP(hipMemcpy(duv, h_uvs, (size_t)m.n_faces * 6 * sizeof(float), hipMemcpyHostToDevice));
+  MP_CHECK_HIP(hipMemcpy(dtex, h_texels, total * sizeof(uint32_t), hipMemcpyHostToDevice));
+  db->allocs.push_back(duv); db->allocs.push_back(dtex);
+  m.uvs = duv; m.texels = dtex; m.tex_w = tex_w; m.tex_h = tex_h; m.tex_levels = n_levels;
+  MP_CHECK_HIP(hipMemcpy(db->d_meshes + mesh_id, &m, sizeof(MeshDev), hipMemcpyHostToDevice));
   return MP_OK;
 }
 

@@ -80,7 +80,8 @@ def device_info() -> Tuple[int, int, str]:
 # --------------------------------------------------------------------------- #
 class MeshDB:
     """Device-resident meshes (mp_mesh_db).  `meshes`: list of dicts with float32 arrays
-    vertices [V,3] (metres), normals [V,3], colors [V,3] in [0,1], int32 faces [T,3]."""
+    vertices [V,3] (metres), normals [V,3], colors [V,3] in [0,1], int32 faces [T,3]; optionally uvs [T,3,2] and
+    texture_mips (list of uint32 [h_l, w_l] RGBA8 levels) for UV-textured objects."""
 
     def __init__(self, meshes: Sequence[Dict[str, np.ndarray]]):
         lib = _lib.load()
@@ -99,6 +100,14 @@ class MeshDB:
         self.handle = h
         self.n = len(meshes)
         self.max_vertices = lib.mp_mesh_db_max_vertices(h)
+        for i, m in enumerate(meshes):  # optional UV texture: per-corner uvs [T,3,2] + RGBA8 mip chain (mesh_io.build_mip_chain)
+            if m.get("uvs") is not None and m.get("texture_mips") is not None:
+                uv = np.ascontiguousarray(m["uvs"], dtype=np.float32)
+                mips = m["texture_mips"]
+                assert uv.shape == (np.asarray(m["faces"]).shape[0], 3, 2)
+                th, tw = mips[0].shape[:2]
+                flat = np.ascontiguousarray(np.concatenate([lv.reshape(-1) for lv in mips]).astype(np.uint32))
+                check(lib.mp_mesh_db_set_texture(h, i, uv.ctypes.data, flat.ctypes.data, tw, th, len(mips)))
         self._keep = []
         self._ws: Dict[int, torch.Tensor] = {}
 

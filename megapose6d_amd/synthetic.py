@@ -145,6 +145,85 @@ def make_object_dataset(out_dir, n_objects: int = 1, seed: int = 0, n_theta: int
     return RigidObjectDataset(objs)
 
 
+def make_texture_image(seed: int = 0, h: int = 128, w: int = 256) -> np.ndarray:
+    """procedural uint8 [h,w,3] picture (row 0 = top): colour checker + gradients + fine noise (so mip levels differ)"""
+    rng = np.random.RandomState(seed)
+    ys, xs = np.mgrid[0:h, 0:w]
+    chk = ((xs // 16 + ys // 16) % 2).astype(np.float64)
+    base = np.stack([0.25 + 0.6 * chk, 0.2 + 0.7 * xs / (w - 1), 0.9 - 0.7 * ys / (h - 1)], axis=-1)
+    base += rng.uniform(-0.1, 0.1, size=base.shape)
+    return np.round(np.clip(base, 0, 1) * 255).astype(np.uint8)
+
+
+def lathe_corner_uvs(verts: np.ndarray, faces: np.ndarray, n_theta: int, n_z: int, radius_mm: float) -> np.ndarray:
+    """cylindrical per-corner uvs [T,3,2] for make_lathe_mesh (seam-free: the wrap-around column gets u = 1)"""
+    uv = np.zeros((len(faces), 3, 2))
+    n_side = 2 * (n_z - 1) * n_theta
+    for t, tri in enumerate(faces):
+        if t < n_side:
+            j0 = min(int(c) % n_theta for c in tri)
+            for k, c in enumerate(tri):
+                i, j = divmod(int(c), n_theta)
+                if j == 0 and j0 == 0 and any(int(cc) % n_theta == n_theta - 1 for cc in tri):
+                    j = n_theta
+                uv[t, k] = (j / n_theta, i / (n_z - 1))
+        else:  # caps: planar map
+            for k, c in enumerate(tri):
+                uv[t, k] = (0.5 + verts[c, 0] / (4 * radius_mm), 0.5 + verts[c, 1] / (4 * radius_mm))
+    return uv
+
+
+def make_textured_object(out_dir, label: str = "tex_000000", seed: int = 0, fmt: str = "obj", n_theta: int = 48, n_z: int = 40,
+                         with_vertex_colors: bool = False) -> "RigidObject":
+    """A UV-textured lathe object written as OBJ+MTL+PNG (`fmt="obj"`), ascii PLY with a per-face texcoord list + `comment
+    TextureFile` (`"ply_face"`, the BOP/YCB-V layout) or binary PLY with per-vertex s,t (`"ply_vertex"`)."""
+    from PIL import Image
+
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    radius = 35.0
+    v, f, c = make_lathe_mesh(seed, n_theta=n_theta, n_z=n_z, height_mm=140.0, radius_mm=radius)
+    uv = lathe_corner_uvs(v, f, n_theta, n_z, radius)
+    Image.fromarray(make_texture_image(seed)).save(out_dir / f"{label}.png")
+    if fmt == "obj":
+        lines = [f"mtllib {label}.mtl", "usemtl m0"]
+        for i, p in enumerate(v):
+            lines.append("v %.6f %.6f %.6f" % tuple(p) + (" %.6f %.6f %.6f" % tuple(c[i] / 255.0) if with_vertex_colors else ""))
+        flat = uv.reshape(-1, 2)
+        lines += ["vt %.6f %.6f" % tuple(t) for t in flat]
+        for t, tri in enumerate(f):
+            lines.append("f " + " ".join(f"{int(tri[k]) + 1}/{3 * t + k + 1}" for k in range(3)))
+        (out_dir / f"{label}.obj").write_text("\n".join(lines) + "\n")
+        (out_dir / f"{label}.mtl").write_text(f"newmtl m0\nKd 1 1 1\nmap_Kd {label}.png\n")
+        path = out_dir / f"{label}.obj"
+    elif fmt == "ply_face":
+        hdr = ["ply", "format ascii 1.0", f"comment TextureFile {label}.png", f"element vertex {len(v)}", "property float x",
+               "property float y", "property float z", f"element face {len(f)}", "property list uchar int vertex_indices",
+               "property list uchar float texcoord", "end_header"]
+        body = ["%.6f %.6f %.6f" % tuple(p) for p in v]
+        body += ["3 %d %d %d 6 " % tuple(tri) + " ".join("%.6f" % x for x in uv[t].reshape(-1)) for t, tri in enumerate(f)]
+        (out_dir / f"{label}.ply").write_text("\n".join(hdr + body) + "\n")
+        path = out_dir / f"{label}.ply"
+    elif fmt == "ply_vertex":
+        th = np.arctan2(v[:, 1], v[:, 0]) / (2 * np.pi) % 1.0
+        st = np.stack([th, (v[:, 2] - v[:, 2].min()) / np.ptp(v[:, 2])], axis=1)
+        arr = np.zeros(len(v), dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("s", "<f4"), ("t", "<f4")]))
+        arr["x"], arr["y"], arr["z"], arr["s"], arr["t"] = v[:, 0], v[:, 1], v[:, 2], st[:, 0], st[:, 1]
+        hdr = ["ply", "format binary_little_endian 1.0", f"comment TextureFile {label}.png", f"element vertex {len(v)}"]
+        hdr += [f"property float {n}" for n in ("x", "y", "z", "s", "t")]
+        hdr += [f"element face {len(f)}", "property list uchar int vertex_indices", "end_header"]
+        fa = np.zeros(len(f), dtype=np.dtype([("n", "u1"), ("i", "<i4", (3,))]))
+        fa["n"], fa["i"] = 3, f
+        path = out_dir / f"{label}.ply"
+        with open(path, "wb") as fh:
+            fh.write(("\n".join(hdr) + "\n").encode("ascii"))
+            fh.write(arr.tobytes())
+            fh.write(fa.tobytes())
+    else:
+        raise ValueError(fmt)
+    return RigidObject(label=label, mesh_path=path, mesh_units="mm")
+
+
 # --------------------------------------------------------------------------- #
 # seeded weights in the reference checkpoint layout
 # --------------------------------------------------------------------------- #

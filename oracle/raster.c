@@ -53,6 +53,55 @@ static float quant8(float v255) {
   return q / 255.0f;
 }
 
+/* UV texture: RGBA8 mip chain (levels concatenated, level l = max(1,w>>l) x max(1,h>>l)), repeat wrap, bilinear.
+ * Replaces the texture stage of Panda3D's auto-shader (panda3d_scene_renderer.py:192-207 loads the textured model);
+ * pixel parity with OpenGL's trilinear/anisotropic filtering is unpinned -- this is the engine's contract. */
+typedef struct {
+  const float* uvs;        /* [n_faces][3][2] or NULL */
+  const uint32_t* texels;
+  int w, h, levels;
+} tex_t;
+
+static int tex_offset(const tex_t* tx, int level) {
+  int off = 0;
+  for (int l = 0; l < level; ++l) {
+    const int tw = (tx->w >> l) > 1 ? (tx->w >> l) : 1, th = (tx->h >> l) > 1 ? (tx->h >> l) : 1;
+    off += tw * th;
+  }
+  return off;
+}
+
+static void tex_sample(const tex_t* tx, int level, float u, float v, float out[3]) {
+  const int tw = (tx->w >> level) > 1 ? (tx->w >> level) : 1, th = (tx->h >> level) > 1 ? (tx->h >> level) : 1;
+  const uint32_t* t = tx->texels + tex_offset(tx, level);
+  const float fu = fmaf(u - floorf(u), (float)tw, -0.5f), fv = fmaf(v - floorf(v), (float)th, -0.5f);
+  const float flu = floorf(fu), flv = floorf(fv);
+  const float au = fu - flu, av = fv - flv;
+  int x0 = (int)flu, y0 = (int)flv;
+  if (x0 < 0) x0 = tw - 1;
+  if (y0 < 0) y0 = th - 1;
+  if (x0 >= tw) x0 = tw - 1;
+  if (y0 >= th) y0 = th - 1;
+  const int x1 = (x0 + 1 == tw) ? 0 : x0 + 1, y1 = (y0 + 1 == th) ? 0 : y0 + 1;
+  const uint32_t t00 = t[y0 * tw + x0], t01 = t[y0 * tw + x1], t10 = t[y1 * tw + x0], t11 = t[y1 * tw + x1];
+  for (int c = 0; c < 3; ++c) {
+    const float a00 = (float)((t00 >> (8 * c)) & 255u), a01 = (float)((t01 >> (8 * c)) & 255u);
+    const float a10 = (float)((t10 >> (8 * c)) & 255u), a11 = (float)((t11 >> (8 * c)) & 255u);
+    const float top = fmaf(a01 - a00, au, a00), bot = fmaf(a11 - a10, au, a10);
+    out[c] = fmaf(bot - top, av, top);
+  }
+}
+
+static int tex_level(const tex_t* tx, const float* uv, float inv_area2) {
+  const float du1 = uv[2] - uv[0], dv1 = uv[3] - uv[1], du2 = uv[4] - uv[0], dv2 = uv[5] - uv[1];
+  const float at = fabsf(du1 * dv2 - du2 * dv1) * ((float)tx->w * (float)tx->h);
+  const float r = at * (inv_area2 * 65536.0f);
+  int level = 0;
+  float thr = 2.0f;
+  while (level + 1 < tx->levels && r > thr) { ++level; thr *= 4.0f; }
+  return level;
+}
+
 static int imin(int a, int b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
 
@@ -114,7 +163,9 @@ typedef struct {
 
 void oracle_raster_render(const float* verts, const float* normals, const float* colors, const int32_t* faces, int n_verts,
                           int n_faces, float radius, const float* TCO, const float* K, int n_views, int h, int w,
-                          uint32_t flags, const lights_t* L, float* out_rgb, float* out_normals, float* out_depth) {
+                          uint32_t flags, const lights_t* L, float* out_rgb, float* out_normals, float* out_depth,
+                          const float* uvs, const uint32_t* texels, int tex_w, int tex_h, int tex_levels) {
+  const tex_t tx = {uvs, texels, tex_w, tex_h, tex_levels};
   vtx_t* vv = (vtx_t*)malloc(sizeof(vtx_t) * (size_t)n_verts);
   float* zb = (float*)malloc(sizeof(float) * (size_t)h * w);   /* best wsum so far (0 = empty) */
   int* tb = (int*)malloc(sizeof(int) * (size_t)h * w);
@@ -189,6 +240,15 @@ void oracle_raster_render(const float* verts, const float* normals, const float*
         for (int k = 0; k < 3; ++k) {
           col[k] = fmaf(w2, colors[3 * i2 + k], fmaf(w1, colors[3 * i1 + k], w0 * colors[3 * i0 + k])) * z;
           on[k] = fmaf(w2, normals[3 * i2 + k], fmaf(w1, normals[3 * i1 + k], w0 * normals[3 * i0 + k])) * z;
+        }
+        if (tx.uvs && tx.texels) {
+          const float* uv = tx.uvs + 6 * (size_t)t;
+          const int k1 = (i1 == faces[3 * t + 1]) ? 1 : 2, k2 = 3 - k1; /* corner slots follow the orientation swap */
+          const float u = fmaf(w2, uv[2 * k2], fmaf(w1, uv[2 * k1], w0 * uv[0])) * z;
+          const float v = fmaf(w2, uv[2 * k2 + 1], fmaf(w1, uv[2 * k1 + 1], w0 * uv[1])) * z;
+          float tc[3];
+          tex_sample(&tx, tex_level(&tx, uv, tr.inv_area), u, v, tc);
+          for (int k = 0; k < 3; ++k) col[k] *= tc[k] / 255.0f;
         }
         float lr = L->ambient[0], lg = L->ambient[1], lb = L->ambient[2];
         if (L->n_point > 0) {

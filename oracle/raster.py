@@ -73,8 +73,16 @@ def render(mesh: Dict[str, np.ndarray], TCO: np.ndarray, K: np.ndarray, h: int, 
     dep = np.zeros((nv, h, w), np.float32)
     L = lights if lights is not None else lights_struct()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
+    uv_p, tex_p, tw, th, nl = C.c_void_p(None), C.c_void_p(None), 0, 0, 0
+    if mesh.get("uvs") is not None and mesh.get("texture_mips") is not None:
+        uv = np.ascontiguousarray(mesh["uvs"], np.float32)
+        mips = mesh["texture_mips"]
+        flat = np.ascontiguousarray(np.concatenate([lv.reshape(-1) for lv in mips]).astype(np.uint32))
+        th, tw = mips[0].shape[:2]
+        uv_p, tex_p, nl = p(uv), p(flat), len(mips)
     lib().oracle_raster_render(p(v), p(n), p(c), p(f), C.c_int(v.shape[0]), C.c_int(f.shape[0]), C.c_float(mesh_radius(v)), p(T),
-                               p(Kk), C.c_int(nv), C.c_int(h), C.c_int(w), C.c_uint32(flags), C.byref(L), p(rgb), p(nrm), p(dep))
+                               p(Kk), C.c_int(nv), C.c_int(h), C.c_int(w), C.c_uint32(flags), C.byref(L), p(rgb), p(nrm), p(dep),
+                               uv_p, tex_p, C.c_int(tw), C.c_int(th), C.c_int(nl))
     return rgb, nrm, dep
 
 

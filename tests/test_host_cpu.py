@@ -179,3 +179,60 @@ def test_row_sharding_and_gather_gloo_world2(n):
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res)
     assert sum(c for _, _, c in res) == n and abs(res[0][2] - res[1][2]) <= 1
+
+
+def test_textured_mesh_ingestion(tmp_path):
+    """UV-textured assets: OBJ+MTL+PNG, PLY per-face texcoord (BOP layout), PLY per-vertex s,t -> per-corner uvs +
+    RGBA8 mip chain; vertex order untouched"""
+    from megapose6d_amd import mesh_io
+    from megapose6d_amd import synthetic as syn
+
+    ms = {fmt: mesh_io.load_rigid_object(syn.make_textured_object(tmp_path / fmt, seed=3, fmt=fmt)) for fmt in ("obj", "ply_face", "ply_vertex")}
+    v, f, _ = syn.make_lathe_mesh(3, n_theta=48, n_z=40, height_mm=140.0, radius_mm=35.0)
+    for m in ms.values():
+        assert m["uvs"].shape == (len(f), 3, 2) and m["uvs"].dtype == np.float32
+        assert np.array_equal(m["faces"], f) and np.allclose(m["points"], v * 1e-3, atol=1e-6)
+        mips = m["texture_mips"]
+        assert [l.shape for l in mips] == [(128 >> k if 128 >> k else 1, 256 >> k if 256 >> k else 1) for k in range(9)]
+        assert all(l.dtype == np.uint32 and (l >> 24 == 255).all() for l in mips)
+    assert np.array_equal(ms["obj"]["uvs"], ms["ply_face"]["uvs"])
+    # image rows are flipped so that v grows with the row index: texel row 0 = bottom row of the picture
+    img = syn.make_texture_image(3)
+    lvl0 = ms["obj"]["texture_mips"][0]
+    assert np.array_equal(lvl0 & 255, img[::-1, :, 0]) and np.array_equal((lvl0 >> 16) & 255, img[::-1, :, 2])
+    # mip level 1 = rounded 2x2 means
+    r0 = img[::-1, :, 0].astype(np.uint32)
+    want = (r0[0::2, 0::2] + r0[1::2, 0::2] + r0[0::2, 1::2] + r0[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(ms["obj"]["texture_mips"][1] & 255, want)
+    # odd sizes clamp at the edge and end in a single texel
+    odd = mesh_io.build_mip_chain((np.arange(37 * 50 * 3) % 251).astype(np.uint8).reshape(37, 50, 3))
+    assert [l.shape for l in odd] == [(37, 50), (18, 25), (9, 12), (4, 6), (2, 3), (1, 1)]
+    # a missing texture file is an error, an OBJ without vt stays untextured
+    (tmp_path / "obj" / "tex_000000.png").unlink()
+    with pytest.raises(FileNotFoundError):
+        mesh_io.load_rigid_object(syn.RigidObject("x", tmp_path / "obj" / "tex_000000.obj", mesh_units="mm"))
+
+
+def test_oracle_textured_quad_known_answer():
+    """oracle/raster.c texture contract: a fronto-parallel quad mapped 1:1 onto a 2-colour texture reproduces the texels at level 0,
+    and their mean when minified"""
+    from megapose6d_amd import mesh_io
+    from oracle import raster as orr
+
+    tex = np.zeros((64, 64, 3), np.uint8)
+    tex[:, :32] = (255, 0, 0)
+    tex[:, 32:] = (0, 0, 255)
+    s = 0.1
+    mesh = {"vertices": np.array([[-s, -s, 0], [s, -s, 0], [s, s, 0], [-s, s, 0]], np.float32), "normals": np.tile([[0, 0, -1.0]], (4, 1)).astype(np.float32),
+            "colors": np.ones((4, 3), np.float32), "faces": np.array([[0, 1, 2], [0, 2, 3]], np.int32),
+            "uvs": np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32), "texture_mips": mesh_io.build_mip_chain(tex)}
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 1.0
+    K = np.array([[320, 0, 32], [0, 320, 32], [0, 0, 1]], np.float32)   # quad = 64 x 64 px: one texel per pixel
+    rgb, _, _ = orr.render(mesh, T[None], K[None], 64, 64, 0)
+    assert np.array_equal(rgb[0, 5:60, 2:30], np.broadcast_to(np.float32([1, 0, 0]), (55, 28, 3)))
+    assert np.array_equal(rgb[0, 5:60, 34:62], np.broadcast_to(np.float32([0, 0, 1]), (55, 28, 3)))
+    K2 = np.array([[5, 0, 1], [0, 5, 1], [0, 0, 1]], np.float32)          # quad = 1 x 1 px -> coarsest levels: purple
+    rgb2, _, _ = orr.render(mesh, T[None], K2[None], 2, 2, 0)
+    px = rgb2[0][rgb2[0].sum(-1) > 0]
+    assert len(px) >= 1 and (np.abs(px[:, 0] - 0.5) < 0.02).all() and (np.abs(px[:, 2] - 0.5) < 0.02).all()
