@@ -1,0 +1,93 @@
+"""-m gpu: BASELINE.json configs 3 and 4 at their full sizes, checked through size-independent properties of the path
+(every (object, hypothesis) row is independent): a detection's result does not depend on which other
+detections / frames share the launch, on the order of the detections, or on how rows are chunked."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _by_key(final):
+    df = final.infos.reset_index(drop=True)
+    return {(int(df["batch_im_id"][i]), str(df["label"][i]), int(df["instance_id"][i])): final.poses[i] for i in range(len(df))}
+
+
+def test_config3_rgbd_8_objects_x_576_hypotheses_row_independence():
+    """megapose-1.0-RGBD structure (RGB coarse + 32-channel RGBD refiner), 8 objects x 576 hypotheses ALL refined 5 iterations"""
+    from megapose6d_amd.scene import make_scene
+    from megapose6d_amd.tcoll import PandasTensorCollection
+
+    est, obs, det, gt = make_scene(n_objects=8, seed=7, rgbd=True, SO3_grid_size=576)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=576)
+    assert len(final) == 8 and torch.isfinite(final.poses).all()
+    assert len(extra["coarse"]["preds"]) == 8 * 576 and len(extra["refiner_all_hypotheses"]["preds"]["iteration=5"]) == 8 * 576
+    R = final.poses[:, :3, :3]
+    assert (R @ R.transpose(1, 2) - torch.eye(3, device="cuda")).abs().max() < 1e-4
+    full = _by_key(final)
+    # (1) one detection alone == the same detection inside the 8-object launch
+    one = PandasTensorCollection(det.infos.iloc[[5]].reset_index(drop=True), bboxes=det.bboxes[[5]])
+    f1, _ = est.run_inference_pipeline(obs, detections=one, n_refiner_iterations=5, n_pose_hypotheses=576)
+    k = (0, str(det.infos.iloc[5]["label"]), int(det.infos.iloc[5]["instance_id"]))   # make_detections numbers instances 0..7
+    assert k in full, list(full)
+    assert (f1.poses[0] - full[k]).abs().max().item() < 1e-5
+    # (2) reversed detection order -> same per-object poses
+    rev = list(range(7, -1, -1))
+    detr = PandasTensorCollection(det.infos.iloc[rev].reset_index(drop=True), bboxes=det.bboxes[rev])
+    fr, _ = est.run_inference_pipeline(obs, detections=detr, n_refiner_iterations=5, n_pose_hypotheses=576)
+    for key, pose in _by_key(fr).items():
+        assert (pose - full[key]).abs().max().item() < 1e-5
+    # (3) per-hypothesis scores: the arg-max really is the best-scoring refined hypothesis of each object
+    sc = extra["scoring"]["preds"].infos
+    best = sc.loc[sc.groupby("label")["pose_logit"].idxmax()].set_index("label")["pose_logit"]
+    got = final.infos.set_index("label")["pose_logit"]
+    assert np.allclose(got.sort_index().values, best.sort_index().values)
+
+
+def test_config4_64_detections_over_8_frames_multi_hypothesis():
+    """megapose-1.0-RGB-multi-hypothesis (K=5) on 64 detections / 8 frames / 16 distinct meshes, 576-rotation grid"""
+    import tempfile
+
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.scene import build_estimator, render_observation
+    from megapose6d_amd.tcoll import PandasTensorCollection
+    from megapose6d_amd.types import ObservationTensor
+
+    ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_cfg4_"), n_objects=16, seed=40, n_theta=48, n_z=50)
+    est = build_estimator(ds, SO3_grid_size=576)
+    r = est.coarse_model.renderer
+    rng = np.random.RandomState(9)
+    K = syn.K_EXAMPLE.astype(np.float32)
+    labels_all = [o.label for o in ds.list_objects]
+    frames, rows, boxes = [], [], []
+    for f in range(8):
+        labs = [labels_all[(2 * f + j) % 16] for j in range(8)]      # every mesh appears 4 times over the 8 frames
+        poses = np.stack([syn.random_pose(rng, (0.5, 0.8), 0.3) for _ in labs])
+        im, bb = render_observation(r, labs, poses, K, seed=f)
+        frames.append(im)
+        rows += [dict(label=l, batch_im_id=f) for l in labs]
+        boxes.append(bb)
+    obs = ObservationTensor(torch.cat(frames), torch.from_numpy(np.repeat(K[None], 8, 0)).cuda())
+    det = PandasTensorCollection(pd.DataFrame(rows), bboxes=torch.from_numpy(np.concatenate(boxes)).cuda())
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=5)
+    assert len(final) == 64 and torch.isfinite(final.poses).all()
+    assert len(extra["coarse"]["preds"]) == 64 * 576 and len(extra["coarse_filter"]["preds"]) == 64 * 5
+    assert extra["coarse_filter"]["preds"].infos.groupby(["batch_im_id", "label", "instance_id"]).size().eq(5).all()
+    full = _by_key(final)
+    # frame 6 alone (its batch_im_id re-based to 0 over a 1-frame observation) gives the same poses
+    sel = np.nonzero(det.infos["batch_im_id"].values == 6)[0].tolist()
+    sub = PandasTensorCollection(det.infos.iloc[sel].assign(batch_im_id=0).reset_index(drop=True), bboxes=det.bboxes[sel])
+    obs6 = ObservationTensor(obs.images[[6]].contiguous(), obs.K[[6]].contiguous())
+    f6, _ = est.run_inference_pipeline(obs6, detections=sub, n_refiner_iterations=5, n_pose_hypotheses=5)
+    for (im, lab, inst), pose in _by_key(f6).items():
+        assert (pose - full[(6, lab, inst)]).abs().max().item() < 1e-5
+    # chunking: 36 864 coarse rows in launches of 1000 (ragged tail) == launches of 576
+    old = est.max_rows_per_launch
+    try:
+        est.max_rows_per_launch = 1000
+        f2, _ = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=5)
+    finally:
+        est.max_rows_per_launch = old
+    for key, pose in _by_key(f2).items():
+        assert (pose - full[key]).abs().max().item() < 1e-5
