@@ -31,7 +31,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 N_HYP, N_ITERS = 576, 5
 
 
-def cpu_baseline(tmp_dir: str, obs_images: torch.Tensor, K: torch.Tensor, bboxes: torch.Tensor, budget_s: float = 20.0) -> dict:
+def cpu_baseline(tmp_dir: str, obs_images: torch.Tensor, K: torch.Tensor, bboxes: torch.Tensor, budget_s: float = 20.0,
+                 threads: int = 0) -> dict:
     """Oracle (port of the reference CPU path: reference orchestration + torch-CPU fp32 CNN + C software rasteriser standing in
     for Panda3D, which cannot be installed offline) on a bounded sample of the same workload.  Threads: min(host cores, 32)
     -- more threads only add OpenMP overhead at these batch sizes (the reference itself pins 1 thread, __init__.py:39-40).
@@ -44,7 +45,7 @@ def cpu_baseline(tmp_dir: str, obs_images: torch.Tensor, K: torch.Tensor, bboxes
     from oracle import pipeline as op
     from oracle import raster as orr
 
-    threads = min(os.cpu_count() or 1, 32)
+    threads = threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     ds = syn.make_object_dataset(tmp_dir, n_objects=1, seed=0)
     meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}
@@ -193,7 +194,8 @@ def main():
             "dtype": "f32" if a.precision == 0 else f"f32 via exact bf16x{a.precision} operand split (bf16 MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"megapose-1.0-RGB structure ({a.backbone} coarse 9ch + refiner 27ch), {n_obj} object(s) x 576 hypotheses x 5 refine "
                                    "iters (n_pose_hypotheses=576) + re-score, 640x480 frame, 240x320 crops, 10k-triangle meshes",
-                       "rows_per_step": n_obj * (2 * N_HYP + N_HYP * N_ITERS), "views_per_step": n_obj * (2 * N_HYP + 4 * N_HYP * N_ITERS),
+                       "rows_per_step": n_obj * (2 * N_HYP + N_HYP * N_ITERS),
+                       "evals_per_s": n_obj * (2 * N_HYP + N_HYP * N_ITERS) * a.steps / dt, "views_per_step": n_obj * (2 * N_HYP + 4 * N_HYP * N_ITERS),
                        "parallelism": f"rows sharded rank::world over {world} GPU(s)", "arch": arch, "cus": n_cu},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
@@ -211,6 +213,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tmp, obs.images, obs.K, det.bboxes)
             out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # the thread setting `import megapose` itself enforces (reference src/megapose/__init__.py:39-40), smaller sample
+            out["cpu_baseline_1thread"] = cpu_baseline(tmp, obs.images, obs.K, det.bboxes, budget_s=8.0, threads=1)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -154,6 +154,8 @@ typedef struct {
   const float* d_act_scale;
   const float* d_act_shift;
   int32_t c_real;          /* real (unpadded) input channels, for the profiler's algorithmic FLOP count; 0 = C   */
+  float* d_splitk_ws;      /* optional scratch: with it, launches whose tile grid cannot fill the chip (small batches) split  */
+  int64_t splitk_ws_floats;/* the K loop over several workgroups and reduce deterministically (fixed order); NULL = never    */
 } mp_conv_desc;
 
 int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);

@@ -53,6 +53,8 @@ class ConvDesc(C.Structure):
         ("d_act_scale", C.c_void_p),
         ("d_act_shift", C.c_void_p),
         ("c_real", C.c_int32),
+        ("d_splitk_ws", C.c_void_p),
+        ("splitk_ws_floats", C.c_int64),
     ]
 
 

@@ -131,8 +131,10 @@ int make_bnact(mp_backbone* bb, const StateMap& sm, const std::string& bnkey, in
   return upload(bb, shift, &a->d_shift);
 }
 
+constexpr size_t SPLITK_WS_FLOATS = 12u << 20;  // 48 MB of split-K scratch at the end of the workspace (>= 512 tiles of 128 x 128)
+
 int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, int H, int W, int in_border, float* y, int out_border,
-             const float* res, int relu, float* y_act, const BnAct* act, hipStream_t s) {
+             const float* res, int relu, float* y_act, const BnAct* act, hipStream_t s, float* splitk_ws = nullptr) {
   mp_conv_desc d;
   memset(&d, 0, sizeof(d));
   d.d_x = x; d.N = N; d.H = H; d.W = W; d.C = L.Cin_p; d.c_real = L.Cin; d.in_border = in_border;
@@ -140,6 +142,8 @@ int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, i
   d.d_y = y; d.out_border = out_border; d.d_residual = res; d.relu = relu;
   d.d_y_act = y_act;
   if (y_act) { d.d_act_scale = act->d_scale; d.d_act_shift = act->d_shift; }
+  d.d_splitk_ws = splitk_ws;
+  d.splitk_ws_floats = splitk_ws ? (int64_t)SPLITK_WS_FLOATS : 0;
   return bb->precision == 0 ? mp_conv2d_nhwc(&d, s) : mp_conv2d_nhwc_split(&d, bb->precision, s);
 }
 
@@ -262,6 +266,7 @@ extern "C" size_t mp_backbone_workspace_bytes(const mp_backbone* bb, int batch, 
   size_t fl = align_up(buf_floats(batch, g.h1, g.w1, 64), 64);
   const int per_stage = bb->wide ? 4 : 3;
   for (int s = 0; s < 4; ++s) fl += per_stage * align_up(buf_floats(batch, g.hs[s], g.ws[s], kStageC[s]), 64);
+  fl += SPLITK_WS_FLOATS;
   return fl * sizeof(float);
 }
 
@@ -293,9 +298,10 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
     Bf[st] = p; p += n;
     Cf[st] = p; p += n;
   }
+  float* SK = p;  // split-K scratch (SPLITK_WS_FLOATS)
   int rc;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
-  rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s);
+  rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK);
   if (rc) return rc;
   const Block& b0 = bb->blocks[0];
   rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, 64, 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
@@ -310,28 +316,28 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
     const bool last = (i + 1 == nb);
     if (!bb->wide) {
       // y1 = relu(bn1(conv1(x))); idn = bn(down(x)) | x; out = relu(bn2(conv2(y1)) + idn)
-      rc = run_conv(bb, blk.conv1, A[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
+      rc = run_conv(bb, blk.conv1, A[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s, SK);
       if (rc) return rc;
       const float* idn = A[si];
       if (blk.has_down) {
-        rc = run_conv(bb, blk.down, A[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
+        rc = run_conv(bb, blk.down, A[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s, SK);
         if (rc) return rc;
         idn = Cf[so];
       }
-      rc = run_conv(bb, blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 1, nullptr, nullptr, s);
+      rc = run_conv(bb, blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 1, nullptr, nullptr, s, SK);
       if (rc) return rc;
     } else {
       // a = relu(bn1(x)) was produced upstream into Aact[si]; residual = down(a) | x
-      rc = run_conv(bb, blk.conv1, Aact[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s);
+      rc = run_conv(bb, blk.conv1, Aact[si], batch, Hi, Wi, 1, Bf[so], 1, nullptr, 1, nullptr, nullptr, s, SK);
       if (rc) return rc;
       const float* idn = A[si];
       if (blk.has_down) {
-        rc = run_conv(bb, blk.down, Aact[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s);
+        rc = run_conv(bb, blk.down, Aact[si], batch, Hi, Wi, 1, Cf[so], 1, nullptr, 0, nullptr, nullptr, s, SK);
         if (rc) return rc;
         idn = Cf[so];
       }
       const BnAct* next_pre = last ? nullptr : &bb->blocks[i + 1].pre;
-      rc = run_conv(bb, blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 0, last ? nullptr : Aact[so], next_pre, s);
+      rc = run_conv(bb, blk.conv2, Bf[so], batch, g.hs[so], g.ws[so], 1, A[so], 1, idn, 0, last ? nullptr : Aact[so], next_pre, s, SK);
       if (rc) return rc;
     }
   }

@@ -17,6 +17,8 @@
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s, MI355X_MICROARCH.md).
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace mp {
@@ -47,6 +49,10 @@ struct ConvParams {
   int n_chunks;        // ceil(KH*run / BK): the K loop walks the concatenated row runs
   int relu;
   int n_mblocks, n_nblocks;
+  // split-K (small M: too few tiles to fill 256 CUs): blockIdx.y owns chunks [y*chunks_per_split, ...) and writes raw partial
+  // sums to partial[y][M][Cout]; conv_splitk_reduce adds them in a fixed order and applies the epilogue (deterministic)
+  float* partial;
+  int k_split, chunks_per_split;
 };
 
 template <int TM, int TN, bool RES, bool RELU, bool ACT>
@@ -86,7 +92,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
-template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false>
+template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, bool SPLITK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma(ConvParams p) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -195,11 +201,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // RAGGED (run % 32 != 0, the 7x7 / 5x5 stems): per-lane bookkeeping.  Otherwise chunks never straddle kernel rows and
   // the bump is wave-uniform (scalar registers), which is what the 3x3 / 1x1 layers use.
   int j = a_c4 * 4, aoff = a_c4 * 4;
-  if constexpr (RAGGED) {
-    while (j >= p.run) { j -= p.run; aoff += row_stride - p.run; }
-  }
   int ju = 0;  // uniform run position (non-RAGGED)
   const float* bp = b_ptr;
+  int c_begin = 0, c_end = p.n_chunks;
+  if constexpr (SPLITK) {
+    c_begin = blockIdx.y * p.chunks_per_split;
+    c_end = min(p.n_chunks, c_begin + p.chunks_per_split);
+    bp += (size_t)c_begin * (BN * BK);
+    if constexpr (RAGGED) {
+      const int jj = a_c4 * 4 + c_begin * BK;
+      const int kh = jj / p.run;
+      j = jj - kh * p.run;
+      aoff = kh * row_stride + j;
+    } else {
+      const int kh = (c_begin * BK) / p.run;
+      ju = c_begin * BK - kh * p.run;
+      aoff = a_c4 * 4 + kh * row_stride + ju;
+    }
+  } else if constexpr (RAGGED) {
+    while (j >= p.run) { j -= p.run; aoff += row_stride - p.run; }
+  }
   MP_CONV_LOAD(aoff, bp)
   MP_CONV_STORE(0)
   __syncthreads();
@@ -207,9 +228,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
   const int row_wrap = row_stride - p.run;
-  for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-    const int buf = chunk & 1;
-    if (chunk + 1 < p.n_chunks) {  // advance to the next chunk; the loads themselves are unconditional
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int buf = (chunk - c_begin) & 1;
+    if (chunk + 1 < c_end) {  // advance to the next chunk; the loads themselves are unconditional
       bp += BN * BK;
       aoff += BK;
       if constexpr (RAGGED) {
@@ -275,8 +296,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   // (compile-time flags: one straight-line store loop per fused mode instead of four data-dependent branches per element)
-  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
   const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
+  if constexpr (SPLITK) {
+    float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int n = en0 + jn * 32;
+      if (n >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + erow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) part[(size_t)m * p.Cout + n] = acc[i][jn][r];
+        }
+    }
+    return;
+  }
+  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
   switch (emode) {
     case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
     case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
@@ -287,6 +324,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
     default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
   }
+}
+
+// sum of the k_split partial tiles in ascending split order + the fused epilogue (bias, residual, ReLU, pre-activation output)
+__global__ __launch_bounds__(256) void conv_splitk_reduce(ConvParams p) {
+  const int c4 = p.Cout >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.M * c4) return;
+  const int m = (int)(idx / c4), n = (int)(idx % c4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)m * p.Cout + n);
+  for (int z = 1; z < p.k_split; ++z) {
+    const float4 q = *reinterpret_cast<const float4*>(p.partial + ((size_t)z * p.M + m) * p.Cout + n);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  const int wo = m % p.Wo;
+  const int t = m / p.Wo;
+  const int ho = t % p.Ho;
+  const int nn = t / p.Ho;
+  const size_t off = ((((size_t)nn * p.Hop) + ho + p.out_border) * p.Wop + wo + p.out_border) * p.Cout + n;
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (p.residual) {
+    const float4 r = *reinterpret_cast<const float4*>(p.residual + off);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (p.y) *reinterpret_cast<float4*>(p.y + off) = v;
+  if (p.y_act) {
+    const float4 sc = *reinterpret_cast<const float4*>(p.act_scale + n), sh = *reinterpret_cast<const float4*>(p.act_shift + n);
+    float4 a;
+    a.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    a.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    *reinterpret_cast<float4*>(p.y_act + off) = a;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false>
+static int launch_splitk(const ConvParams& p, hipStream_t s, double alg_k) {
+  ConvParams q = p;
+  q.n_mblocks = ceil_div(p.M, BM);
+  q.n_nblocks = ceil_div(p.Cout, BN);
+  const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD) * sizeof(float) + BM * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  {
+    ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>/splitk" : "conv_nhwc_f32_mfma<128,128,64,64>/splitk",
+                   2.0 * (double)p.M * p.Cout * alg_k,
+                   4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
+    hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED, true>), dim3(q.n_mblocks * q.n_nblocks, q.k_split), dim3(256),
+                       lds, s, q);
+  }
+  ProfScope prof("conv_splitk_reduce", 0.0, 4.0 * (double)p.M * p.Cout * (q.k_split + 1), s);
+  hipLaunchKernelGGL(conv_splitk_reduce, dim3(ceil_div((long)p.M * (p.Cout / 4), 256L)), dim3(256), 0, s, q);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false>
@@ -391,6 +488,9 @@ static int make_params(const mp_conv_desc* d, ConvParams* p) {
   p->run = d->KW * d->C;
   p->n_chunks = ceil_div((long)d->KH * p->run, BK);
   p->relu = d->relu;
+  p->partial = nullptr;
+  p->k_split = 1;
+  p->chunks_per_split = p->n_chunks;
   return MP_OK;
 }
 
@@ -402,6 +502,20 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
   static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 1;  // tuning experiments only
   const bool small = conv_bn_tile(d->Cout) == 64;
+  // split-K when the tile grid cannot fill the chip (small batches: the released K = 1 / K = 5 refiner passes)
+  static const int splitk_on = getenv("MP_CONV_SPLITK") ? atoi(getenv("MP_CONV_SPLITK")) : 1;
+  const int n_tiles = ceil_div(p.M, 128) * ceil_div(p.Cout, small ? 64 : 128);
+  if (splitk_on && d->d_splitk_ws && n_tiles < 192 && (p.Cout % 4) == 0 && p.n_chunks >= 8) {
+    long S = std::min<long>(ceil_div(512, n_tiles), p.n_chunks / 4);
+    S = std::min<long>(S, d->splitk_ws_floats / ((long)p.M * p.Cout));
+    if (S >= 2) {
+      p.chunks_per_split = ceil_div(p.n_chunks, (int)S);
+      p.k_split = ceil_div(p.n_chunks, p.chunks_per_split);
+      p.partial = d->d_splitk_ws;
+      if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1, true>(p, s, alg_k);
+      return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
+    }
+  }
   if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
     return small ? launch<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch<128, 128, 64, 64, 1, true>(p, s, alg_k);
   }

@@ -34,12 +34,16 @@ constexpr int SUBPIX = 256;
 constexpr float GUARD = 16384.f;  // |screen coord| limit (pixels) for the fixed-point path
 constexpr float Z_EPS = 1e-6f;
 constexpr float Z_NEAR = 0.1f, Z_FAR = 10.0f;
-constexpr int BAND_H = 16;
+#ifndef MP_BAND_H
+#define MP_BAND_H 16
+#endif
+constexpr int BAND_H = MP_BAND_H;
 constexpr int BAND_THREADS = 512;
 constexpr int BIG_TRI_AREA = 128;   // clipped-bbox pixels above which a triangle is rasterised by a whole wave (a lane that
                                     // walks a several-hundred-pixel bbox alone stalls its wave and the block's barrier)
 constexpr int BIG_QUEUE = 1024;
-constexpr int LIST_CAP = 2048;  // triangles compacted per scan chunk
+constexpr int SCAN_CHUNK = 2048;  // triangles scanned between two looks at the list fill level
+constexpr int LIST_CAP = 4096;    // compacted triangle list (drained when another scan chunk might not fit)
 constexpr int STAGE_CH = 7;  // rgb(3) + normals(3) + depth(1) staged per pixel for coalesced stores
 
 struct MeshDev {
@@ -50,8 +54,12 @@ struct MeshDev {
   int n_verts, n_faces;
   float radius;
   float center[3];
-  // UV texture (optional): per-corner uv [n_faces][3][2]; RGBA8 mip chain, level l at texels + tex_off[l], size (w>>l, h>>l) >= 1
-  const float* uvs;
+  const float* uvs;  // UV texture (optional): per-corner uv [n_faces][3][2], NULL = vertex colours only
+};
+
+// texture of mesh i (kept out of MeshDev so that the untextured path does not carry it in registers):
+// RGBA8 mip chain, level l at texels + tex_off[l], size max(1, w>>l) x max(1, h>>l)
+struct TexDev {
   const uint32_t* texels;
   int tex_w, tex_h, tex_levels;
   int tex_off[MP_TEX_MAX_LEVELS];
@@ -225,7 +233,7 @@ __device__ __forceinline__ float normal_lut(float n) {
 
 // Texture sample (contract shared with oracle/raster.c): repeat wrap, texel centres at (i + .5) / size, bilinear, result on the
 // 0..255 scale per channel.
-__device__ __forceinline__ void tex_sample(const MeshDev& m, int level, float u, float v, float& r, float& g, float& b) {
+__device__ __forceinline__ void tex_sample(const TexDev& m, int level, float u, float v, float& r, float& g, float& b) {
   const int tw = max(1, m.tex_w >> level), th = max(1, m.tex_h >> level);
   const uint32_t* tx = m.texels + m.tex_off[level];
   const float fu = fmaf(u - floorf(u), (float)tw, -0.5f), fv = fmaf(v - floorf(v), (float)th, -0.5f);
@@ -250,7 +258,7 @@ __device__ __forceinline__ void tex_sample(const MeshDev& m, int level, float u,
 }
 
 // mip level of a triangle: texels per pixel r = |uv area| * w * h / (screen area); level = #thresholds {2, 8, 32, ...} below r
-__device__ __forceinline__ int tex_level(const MeshDev& m, const float* uv, float inv_area2) {
+__device__ __forceinline__ int tex_level(const TexDev& m, const float* uv, float inv_area2) {
   const float du1 = uv[2] - uv[0], dv1 = uv[3] - uv[1], du2 = uv[4] - uv[0], dv2 = uv[5] - uv[1];
   const float at = fabsf(du1 * dv2 - du2 * dv1) * ((float)m.tex_w * (float)m.tex_h);
   const float r = at * (inv_area2 * 65536.0f);   // inv_area2 = 1 / (2 * area in 1/256-px units)
@@ -267,20 +275,29 @@ __device__ __forceinline__ float quant8(float v255) {
 
 template <bool kUnused = false>
 __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
-    const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
+    const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const VtxRec* __restrict__ vtx, const unsigned* __restrict__ bounds, int max_verts, int max_faces, int h, int w, uint32_t flags,
-    LightsDev lights, float* __restrict__ out, long long stride_v, int views_per_item, long long stride_view, long long stride_y,
+    LightsDev lights, float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
     long long stride_x, int c_rgb, int c_normals, int c_depth) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];  // [BAND_H*w] + big-triangle queue
   int* big_queue = (int*)(zbuf + (size_t)BAND_H * w);
-  float* stage = (float*)(big_queue + BIG_QUEUE);  // [BAND_THREADS][STAGE_CH]
-  int* list = (int*)(stage + BAND_THREADS * STAGE_CH);  // [LIST_CAP]
+  int* list = big_queue + BIG_QUEUE;  // [LIST_CAP]
+  float* stage = (float*)big_queue;   // [BAND_THREADS][STAGE_CH]: resolve-phase staging, aliases the (then dead) queue + list
+  static_assert((BIG_QUEUE + LIST_CAP) * sizeof(int) >= BAND_THREADS * STAGE_CH * sizeof(float), "stage must fit in queue + list");
   __shared__ int list_n;
   __shared__ int q_head;
   __shared__ int big_count;
 
-  const int view = blockIdx.y;
-  const int band = blockIdx.x;
+  // Work-to-workgroup map: consecutive workgroup ids go round-robin to the 8 XCDs, and the `views_per_item` views of one
+  // (item, band) write interleaved channel slices of the SAME pixel lines of the CNN input.  Placing them in consecutive slots
+  // of one XCD lets its L2 merge the 24-byte slices into whole lines before they are written back (otherwise every slice is a
+  // partial-line write from a different L2).
+  const int n_bands = (h + BAND_H - 1) / BAND_H;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = (slot / views_per_item) * 8 + xcd;   // (item, band) index
+  if (q >= n_items * n_bands) return;
+  const int view = (q / n_bands) * views_per_item + slot % views_per_item;
+  const int band = q % n_bands;
   const int y0 = band * BAND_H;
   const int y1 = min(h, y0 + BAND_H) - 1;
   const int npix = (y1 - y0 + 1) * w;
@@ -293,31 +310,42 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
   __syncthreads();
 
   // ---- pass 1: triangle-parallel coverage + depth ------------------------------------------------
-  // Two steps per chunk of LIST_CAP triangles so that the expensive part runs on dense lanes: (a) scan the packed row
+  // Two steps so that the expensive part runs on dense lanes: (a) scan the packed row
   // bounds and compact the triangles overlapping this band into an LDS list (wave ballot + one LDS atomic per wave),
   // (b) every thread takes list entries.  (A plain "if (!overlap) continue" loop leaves ~1 lane in 9 active.)
   const int lane = threadIdx.x & 63;
-  for (int c0 = 0; c0 < ((flags & (1u << 16)) ? 0 : m.n_faces); c0 += LIST_CAP) {
-    if (threadIdx.x == 0) list_n = 0;
-    __syncthreads();
-    const int c1 = min(m.n_faces, c0 + LIST_CAP);
-    for (int tbase = c0 + (threadIdx.x & ~63); tbase < c1; tbase += BAND_THREADS) {
-      const int t = tbase + lane;
-      bool hit = false;
-      if (t < c1) {
-        const unsigned pb = tb[t];
-        hit = (int)(pb & 0xFFFFu) <= y1 && (int)(pb >> 16) >= y0;  // culled triangles carry ymin = 0xFFFF
-      }
+  // The list is only drained when the next scan chunk could overflow it (or at the end), so that the drain runs with (nearly)
+  // all 512 threads busy instead of once per scan chunk with a fifth of them.
+  const int n_faces_eff = (flags & (1u << 16)) ? 0 : m.n_faces;
+  if (threadIdx.x == 0) list_n = 0;
+  __syncthreads();
+  // scan: one 16-byte load = the packed bounds of 4 consecutive triangles per thread and chunk (the bounds array is padded to a
+  // multiple of 4 entries per view with "culled"), the next chunk's load is issued before the current one is compacted
+  const uint4* tb4 = reinterpret_cast<const uint4*>(tb);
+  const uint4 culled4 = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+  uint4 nxt = (4 * (int)threadIdx.x < n_faces_eff) ? tb4[threadIdx.x] : culled4;
+  for (int c0 = 0; c0 < n_faces_eff; c0 += SCAN_CHUNK) {
+    const int c1 = min(n_faces_eff, c0 + SCAN_CHUNK);
+    const uint4 cur = nxt;
+    const int tn = c0 + SCAN_CHUNK + 4 * (int)threadIdx.x;
+    nxt = (tn < n_faces_eff) ? tb4[tn >> 2] : culled4;
+    const int t0 = c0 + 4 * (int)threadIdx.x;
+    const unsigned pbs[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned pb = pbs[k];
+      const bool hit = (t0 + k < c1) && (int)(pb & 0xFFFFu) <= y1 && (int)(pb >> 16) >= y0;  // culled triangles carry ymin = 0xFFFF
       const unsigned long long mask = __ballot(hit);
       if (mask) {
         int wbase = 0;
         if (lane == 0) wbase = atomicAdd(&list_n, __popcll(mask));
         wbase = __shfl(wbase, 0);
-        if (hit) list[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+        if (hit) list[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = t0 + k;
       }
     }
     __syncthreads();
     const int n_list = list_n;
+    if (n_list + SCAN_CHUNK <= LIST_CAP && c1 < n_faces_eff) continue;   // room for another scan chunk: keep collecting
     for (int e = threadIdx.x; e < n_list; e += BAND_THREADS) {
       const int t = list[e];
       int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
@@ -336,6 +364,8 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
       for (int py = s.ymin; py <= s.ymax; ++py)
         for (int px = s.xmin; px <= s.xmax; ++px) raster_pixel(s, px, py, t, y0, w, zbuf);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) list_n = 0;
     __syncthreads();
   }
   // ---- pass 1b: larger triangles: waves pull them from the queue, 64 lanes share one bbox -----------------
@@ -397,7 +427,8 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
         const float u = fmaf(w2, uv[2 * k2], fmaf(w1, uv[2 * k1], w0 * uv[0])) * z;
         const float v = fmaf(w2, uv[2 * k2 + 1], fmaf(w1, uv[2 * k1 + 1], w0 * uv[1])) * z;
         float tr, tg, tb2;
-        tex_sample(m, tex_level(m, uv, s.inv_area), u, v, tr, tg, tb2);
+        const TexDev& tx = texs[mesh_ids[view]];
+        tex_sample(tx, tex_level(tx, uv, s.inv_area), u, v, tr, tg, tb2);
         ar *= tr / 255.0f; ag *= tg / 255.0f; ab *= tb2 / 255.0f;
       }
       const float* n0 = m.normals + 3 * i0; const float* n1 = m.normals + 3 * i1; const float* n2 = m.normals + 3 * i2;
@@ -469,7 +500,9 @@ struct mp_mesh_db {
   int n;
   int max_verts, max_faces;
   MeshDev* d_meshes;
+  TexDev* d_texs;
   std::vector<MeshDev> h_meshes;
+  std::vector<TexDev> h_texs;
   std::vector<void*> allocs;
 };
 
@@ -479,6 +512,7 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
   db->n = n;
   db->max_verts = db->max_faces = 0;
   db->d_meshes = nullptr;
+  db->d_texs = nullptr;
   for (int i = 0; i < n; ++i) {
     const mp_mesh_desc& d = hm[i];
     MP_REQUIRE(d.h_vertices && d.h_normals && d.h_colors && d.h_faces && d.n_vertices > 0 && d.n_faces > 0,
@@ -500,8 +534,7 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
     db->allocs.push_back(dv); db->allocs.push_back(dn); db->allocs.push_back(dc); db->allocs.push_back(df);
     m.verts = dv; m.normals = dn; m.colors = dc; m.faces = df;
     m.n_verts = d.n_vertices; m.n_faces = d.n_faces;
-    m.uvs = nullptr; m.texels = nullptr; m.tex_w = m.tex_h = m.tex_levels = 0;
-    for (int l = 0; l < MP_TEX_MAX_LEVELS; ++l) m.tex_off[l] = 0;
+    m.uvs = nullptr;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int v = 0; v < d.n_vertices; ++v)
       for (int k = 0; k < 3; ++k) {
@@ -525,6 +558,9 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
   }
   MP_CHECK_HIP(hipMalloc(&db->d_meshes, n * sizeof(MeshDev)));
   MP_CHECK_HIP(hipMemcpy(db->d_meshes, db->h_meshes.data(), n * sizeof(MeshDev), hipMemcpyHostToDevice));
+  db->h_texs.assign(n, TexDev{});
+  MP_CHECK_HIP(hipMalloc(&db->d_texs, n * sizeof(TexDev)));
+  MP_CHECK_HIP(hipMemcpy(db->d_texs, db->h_texs.data(), n * sizeof(TexDev), hipMemcpyHostToDevice));
   *out = db;
   return MP_OK;
 }
@@ -535,9 +571,10 @@ extern "C" int mp_mesh_db_set_texture(mp_mesh_db* db, int mesh_id, const float* 
   MP_REQUIRE(tex_w > 0 && tex_h > 0 && tex_w <= 16384 && tex_h <= 16384 && n_levels >= 1 && n_levels <= MP_TEX_MAX_LEVELS,
              "mp_mesh_db_set_texture: bad texture size %dx%d / %d levels", tex_w, tex_h, n_levels);
   MeshDev& m = db->h_meshes[mesh_id];
+  TexDev& tx = db->h_texs[mesh_id];
   size_t total = 0;
   for (int l = 0; l < n_levels; ++l) {
-    m.tex_off[l] = (int)total;
+    tx.tex_off[l] = (int)total;
     total += (size_t)std::max(1, tex_w >> l) * std::max(1, tex_h >> l);
   }
   float* duv;
@@ -547,7 +584,9 @@ extern "C" int mp_mesh_db_set_texture(mp_mesh_db* db, int mesh_id, const float* 
   MP_CHECK_HIP(hipMemcpy(duv, h_uvs, (size_t)m.n_faces * 6 * sizeof(float), hipMemcpyHostToDevice));
   MP_CHECK_HIP(hipMemcpy(dtex, h_texels, total * sizeof(uint32_t), hipMemcpyHostToDevice));
   db->allocs.push_back(duv); db->allocs.push_back(dtex);
-  m.uvs = duv; m.texels = dtex; m.tex_w = tex_w; m.tex_h = tex_h; m.tex_levels = n_levels;
+  m.uvs = duv;
+  tx.texels = dtex; tx.tex_w = tex_w; tx.tex_h = tex_h; tx.tex_levels = n_levels;
+  MP_CHECK_HIP(hipMemcpy(db->d_texs + mesh_id, &tx, sizeof(TexDev), hipMemcpyHostToDevice));
   MP_CHECK_HIP(hipMemcpy(db->d_meshes + mesh_id, &m, sizeof(MeshDev), hipMemcpyHostToDevice));
   return MP_OK;
 }
@@ -556,6 +595,7 @@ extern "C" int mp_mesh_db_destroy(mp_mesh_db* db) {
   if (!db) return MP_OK;
   for (void* p : db->allocs) (void)hipFree(p);
   if (db->d_meshes) (void)hipFree(db->d_meshes);
+  if (db->d_texs) (void)hipFree(db->d_texs);
   delete db;
   return MP_OK;
 }
@@ -565,8 +605,10 @@ extern "C" float mp_mesh_db_radius(const mp_mesh_db* db, int i) {
   return (db && i >= 0 && i < db->n) ? db->h_meshes[i].radius : 0.f;
 }
 
+static inline int faces_stride(const mp_mesh_db* db) { return (db->max_faces + 3) & ~3; }  // 16-byte aligned bounds rows
+
 extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views) {
-  return db ? (size_t)n_views * ((size_t)db->max_verts * sizeof(VtxRec) + (size_t)db->max_faces * sizeof(unsigned)) : 0;
+  return db ? (size_t)n_views * ((size_t)db->max_verts * sizeof(VtxRec) + (size_t)faces_stride(db) * sizeof(unsigned)) : 0;
 }
 
 extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
@@ -595,22 +637,23 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   {
     ProfScope prof("raster_tri_bounds", 0.0, (double)n_views * db->max_faces * (12.0 + 4.0), s);
     hipLaunchKernelGGL(raster_tri_bounds, dim3(ceil_div(db->max_faces, 256), n_views), dim3(256), 0, s, db->d_meshes, d_mesh_ids, vtx,
-                       db->max_verts, db->max_faces, h, tri_bounds);
+                       db->max_verts, faces_stride(db), h, tri_bounds);
   }
-  const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + BIG_QUEUE * sizeof(int) + (size_t)BAND_THREADS * STAGE_CH * sizeof(float) +
-                     LIST_CAP * sizeof(int);
+  const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + (BIG_QUEUE + LIST_CAP) * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bands<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_set = true;
   }
   MP_REQUIRE(lds <= 160 * 1024 - 64, "mp_raster_render: image too wide for the LDS z-buffer");
-  dim3 g2(ceil_div(h, BAND_H), n_views);
+  MP_REQUIRE(n_views % views_per_item == 0, "mp_raster_render: n_views (%d) must be a multiple of views_per_item (%d)", n_views, views_per_item);
+  const int n_items = n_views / views_per_item;
+  dim3 g2(ceil_div(n_items * ceil_div(h, BAND_H), 8) * 8 * views_per_item);
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (((flags & MP_RASTER_NORMALS) && c_normals >= 0) ? 3 : 0) + (((flags & MP_RASTER_DEPTH) && c_depth >= 0) ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   ProfScope prof("raster_bands", 0.0, (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces), s);
-  hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, vtx, tri_bounds,
-                     db->max_verts, db->max_faces, h, w, flags, L, d_out, (long long)stride_v, views_per_item, (long long)stride_view, (long long)stride_y,
+  hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, vtx, tri_bounds,
+                     db->max_verts, faces_stride(db), h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view, (long long)stride_y,
                      (long long)stride_x, c_rgb, c_normals, c_depth);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;

@@ -209,9 +209,13 @@ def conv_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray
 def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int, w_packed: torch.Tensor,
                 bias: Optional[torch.Tensor], Cout: int, K: int, stride: int, pad: int, y: Optional[torch.Tensor], out_border: int,
                 residual: Optional[torch.Tensor] = None, relu: bool = False, y_act: Optional[torch.Tensor] = None,
-                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None, split_products: int = 0) -> None:
+                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None, split_products: int = 0,
+                splitk_ws: Optional[torch.Tensor] = None) -> None:
+    """`splitk_ws` (fp32 scratch): lets launches whose tile grid cannot fill the chip split the K loop (deterministic two-pass)"""
     lib = _lib.load()
     d = ConvDesc()
+    if splitk_ws is not None:
+        d.d_splitk_ws, d.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
     d.d_x, d.N, d.H, d.W, d.C, d.in_border = x.data_ptr(), N, H, W, Cp, in_border
     d.d_w, d.d_bias = w_packed.data_ptr(), _ptr(bias)
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, stride, pad

@@ -98,7 +98,7 @@ def test_ragged_chunks_match_single_launch(multi_scene):
     finally:
         est.max_rows_per_launch, est.n_streams, est.min_rows_per_stream = old, 1, 64
     assert (e1["coarse"]["data"]["logits"] - e2["coarse"]["data"]["logits"]).abs().max().item() < 1e-4
-    assert (f1.poses - f2.poses).abs().max().item() < 1e-5 and (f1.poses - f3.poses).abs().max().item() < 1e-5
+    assert (f1.poses - f2.poses).abs().max().item() < 2e-5 and (f1.poses - f3.poses).abs().max().item() < 2e-5  # tiny launches take the split-K conv path: another summation order
 
 
 def test_coarse_estimates_entry_point_and_single_row(multi_scene):

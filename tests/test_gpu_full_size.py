@@ -80,8 +80,8 @@ def test_config4_64_detections_over_8_frames_multi_hypothesis():
     sub = PandasTensorCollection(det.infos.iloc[sel].assign(batch_im_id=0).reset_index(drop=True), bboxes=det.bboxes[sel])
     obs6 = ObservationTensor(obs.images[[6]].contiguous(), obs.K[[6]].contiguous())
     f6, _ = est.run_inference_pipeline(obs6, detections=sub, n_refiner_iterations=5, n_pose_hypotheses=5)
-    for (im, lab, inst), pose in _by_key(f6).items():
-        assert (pose - full[(6, lab, inst)]).abs().max().item() < 1e-5
+    for (im, lab, inst), pose in _by_key(f6).items():   # 40 refiner rows alone take the split-K conv path (other summation order)
+        assert (pose - full[(6, lab, inst)]).abs().max().item() < 5e-5
     # chunking: 36 864 coarse rows in launches of 1000 (ragged tail) == launches of 576
     old = est.max_rows_per_launch
     try:

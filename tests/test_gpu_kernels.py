@@ -50,7 +50,10 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("epi", ["plain", "bias_relu", "res_relu", "dual"])
-def test_conv_matches_torch_fp32(eng, case, epi):
+@pytest.mark.parametrize("splitk", [False, True])
+def test_conv_matches_torch_fp32(eng, case, epi, splitk):
+    """splitk=True hands the launch a scratch buffer: all of these cases have too few tiles to fill the chip, so they take the
+    split-K kernel + deterministic reduce (csrc/conv.hip) instead of the single-pass kernel"""
     N, Cin, H, W, Cout, K, s, p, ib = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -71,7 +74,8 @@ def test_conv_matches_torch_fp32(eng, case, epi):
     rb = _to_padded(eng, res, Cout, ob) if epi in ("res_relu", "dual") else None
     eng.conv2d_nhwc(xb, N, H, W, cp, ib, wp, bias.cuda() if use_scale else None, Cout, K, s, p, yb, ob,
                     residual=rb, relu=epi in ("bias_relu", "res_relu"), y_act=ya,
-                    act_scale=sc2.cuda() if ya is not None else None, act_shift=sh2.cuda() if ya is not None else None)
+                    act_scale=sc2.cuda() if ya is not None else None, act_shift=sh2.cuda() if ya is not None else None,
+                    splitk_ws=torch.empty(4 << 20, device="cuda") if splitk else None)
     torch.cuda.synchronize()
     ref = F.conv2d(x, w * (scale.view(-1, 1, 1, 1) if use_scale else 1.0), bias if use_scale else None, stride=s, padding=p)
     if epi in ("res_relu", "dual"):
@@ -88,6 +92,31 @@ def test_conv_matches_torch_fp32(eng, case, epi):
         ref_a = F.relu(ref * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1))
         got_a = _from_padded(eng, ya, N, Ho, Wo, Cout, ob)
         assert (got_a - ref_a).abs().max().item() < tol * 2
+
+
+def test_conv_splitk_is_taken_and_deterministic(eng):
+    """layer4-sized conv at batch 1 (M = 80 -> 4 tiles): the split-K path runs (profiler sees its kernels) and is bit-reproducible"""
+    g = torch.Generator().manual_seed(1)
+    N, Cin, H, W, Cout = 1, 512, 8, 10, 512
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02
+    xb = _to_padded(eng, x, Cin, 1)
+    wp = torch.from_numpy(eng.conv_pack_weights(w.numpy(), Cin, None)).cuda()
+    ws = torch.empty(4 << 20, device="cuda")
+    outs = []
+    eng.profile_begin()
+    for _ in range(2):
+        yb = eng.padded_nhwc(N, H, W, Cout, 1, "cuda")
+        eng.conv2d_nhwc(xb, N, H, W, Cin, 1, wp, None, Cout, 3, 1, 1, yb, 1, splitk_ws=ws)
+        outs.append(yb.clone())
+    prof = eng.profile_end()
+    assert "conv_splitk_reduce" in prof and any(k.endswith("/splitk") for k in prof)
+    assert torch.equal(outs[0], outs[1])
+    y0 = eng.padded_nhwc(N, H, W, Cout, 1, "cuda")
+    eng.conv2d_nhwc(xb, N, H, W, Cin, 1, wp, None, Cout, 3, 1, 1, y0, 1)          # single-pass kernel
+    ref = F.conv2d(x, w, padding=1)
+    assert (_from_padded(eng, outs[0], N, H, W, Cout, 1) - ref).abs().max() < 2e-4 * ref.abs().max()
+    assert (outs[0] - y0).abs().max() < 1e-4 * ref.abs().max()
 
 
 def test_maxpool_and_tail(eng):
