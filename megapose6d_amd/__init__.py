@@ -4,11 +4,12 @@ Only what the hot path needs: the HIP/C-ABI engine (`csrc/
 of the reference's renderer / PosePredictor / PoseEstimator interfaces.  Importing the package never touches the GPU; the
 first engine call loads `libmp_engine.so` and raises if it is missing (there is no CPU fallback).
 """
-from . import distributed, engine, icp_refiner, load_model, mesh_db, mesh_io, pose_estimator, pose_rigid, renderer, synthetic, tcoll, types  # noqa: F401
+from . import distributed, engine, icp_refiner, load_model, prediction_runner, mesh_db, mesh_io, pose_estimator, pose_rigid, renderer, synthetic, tcoll, types  # noqa: F401
 from .icp_refiner import DepthRefiner, ICPRefiner  # noqa: F401
 from .load_model import NAMED_MODELS, create_model_pose, load_named_model, load_pose_models  # noqa: F401
 from .pose_estimator import CoarseRefinePoseEstimator, PoseEstimator  # noqa: F401
 from .pose_rigid import PosePredictor  # noqa: F401
+from .prediction_runner import PredictionRunner  # noqa: F401
 from .renderer import Panda3dBatchRenderer  # noqa: F401
 from .types import BatchRenderOutput, ObservationTensor, Panda3dLightData, PosePredictorOutput  # noqa: F401
 

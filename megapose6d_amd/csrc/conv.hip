@@ -18,6 +18,8 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -92,17 +94,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
+// VARIANT bit 0: LDS store of the next chunk under the last MFMA group; bit 1: interleaved MFMA order; bit 2: SINGLE LDS buffer
+// (half the LDS -> 3+ workgroups per CU, two barriers per chunk) -- bit 2 excludes bit 0.
 template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, bool SPLITK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma(ConvParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 3 : 2, (VARIANT & 4) ? 3 : 2))) void conv_nhwc_f32_mfma(ConvParams p) {
+  constexpr bool SBUF = (VARIANT & 4) != 0;
+  constexpr int NBUF = SBUF ? 1 : 2;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
   constexpr int B_LD4 = BN / 32;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                          // [2][BM][LDS_LD]
-  float* Bs = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
-  int* row_off = (int*)(Bs + 2 * BN * LDS_LD);  // [BM] output element offset of each tile row (-1: none)
+  float* As = smem;                             // [NBUF][BM][LDS_LD]
+  float* Bs = smem + NBUF * BM * LDS_LD;        // [NBUF][BN][LDS_LD]
+  int* row_off = (int*)(Bs + NBUF * BN * LDS_LD);  // [BM] output element offset of each tile row (-1: none)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int frag_k = (lane >> 5) * 4;
   const int row_wrap = row_stride - p.run;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    const int buf = (chunk - c_begin) & 1;
+    const int buf = SBUF ? 0 : ((chunk - c_begin) & 1);
     if (chunk + 1 < c_end) {  // advance to the next chunk; the loads themselves are unconditional
       bp += BN * BK;
       aoff += BK;
@@ -283,7 +289,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
       }
     }
-    if constexpr ((VARIANT & 1) == 0) {
+    if constexpr (SBUF) {
+      __syncthreads();  // every wave is done reading this chunk
+      MP_CONV_STORE(0)
+    } else if constexpr ((VARIANT & 1) == 0) {
       __builtin_amdgcn_sched_barrier(0);
       MP_CONV_STORE(buf ^ 1)
     }
@@ -391,7 +400,8 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
   ConvParams q = p;
   q.n_mblocks = ceil_div(p.M, BM);
   q.n_nblocks = ceil_div(p.Cout, BN);
-  const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD) * sizeof(float) + BM * sizeof(int);
+  constexpr int NBUF = (VARIANT & 4) ? 1 : 2;
+  const size_t lds = (size_t)(NBUF * BM * LDS_LD + NBUF * BN * LDS_LD) * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>,
@@ -400,7 +410,17 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
   }
   dim3 grid(q.n_mblocks * q.n_nblocks);
   // algorithmic work of this launch: 2*MACs over the REAL (unpadded) reduction length; bytes = input + weights + output once
-  ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * (double)p.M * p.Cout * alg_k,
+  static const bool detail = getenv("MP_PROF_DETAIL") != nullptr;  // tuning aid: one profiler row per layer shape
+  const char* pname = BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>";
+  if (detail) {
+    static std::vector<std::string> names;  // stable storage for the profiler's name pointers
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s/k%d_c%d_s%d_n%d", pname, p.KH, p.C, p.stride, p.Cout);
+    bool found = false;
+    for (auto& n : names) if (n == buf) { pname = n.c_str(); found = true; break; }
+    if (!found) { names.reserve(64); names.emplace_back(buf); pname = names.back().c_str(); }
+  }
+  ProfScope prof(pname, 2.0 * (double)p.M * p.Cout * alg_k,
                  4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
   hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>), grid, dim3(256), lds, s, q);
   MP_CHECK_HIP(hipGetLastError());
@@ -521,6 +541,11 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   }
   switch (variant) {
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
+    case 2: return small ? launch<128, 64, 64, 32, 2>(p, s, alg_k) : launch<128, 128, 64, 64, 2>(p, s, alg_k);
+    case 3: return small ? launch<128, 64, 64, 32, 3>(p, s, alg_k) : launch<128, 128, 64, 64, 3>(p, s, alg_k);
+    case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
+    case 5: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
+    case 6: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
     default: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
   }
 }

@@ -236,3 +236,96 @@ def test_oracle_textured_quad_known_answer():
     rgb2, _, _ = orr.render(mesh, T[None], K2[None], 2, 2, 0)
     px = rgb2[0][rgb2[0].sum(-1) > 0]
     assert len(px) >= 1 and (np.abs(px[:, 0] - 0.5) < 0.02).all() and (np.abs(px[:, 2] - 0.5) < 0.02).all()
+
+
+class _FakeEstimator:
+    """Duck type of PoseEstimator.run_inference_pipeline for the PredictionRunner host-logic tests: the 'pose' of a detection encodes
+    (frame mean colour, bbox) so that mixing up frames / rows would show."""
+
+    def run_inference_pipeline(self, observation, detections=None, run_detector=False, coarse_estimates=None, n_refiner_iterations=5,
+                               n_pose_hypotheses=1, run_depth_refiner=False, bsz_images=None, bsz_objects=None):
+        from megapose6d_amd.tcoll import PandasTensorCollection
+
+        infos = detections.infos.copy().reset_index(drop=True)
+        infos["instance_id"] = infos.groupby(["batch_im_id", "label"]).cumcount()
+        im = torch.as_tensor(infos["batch_im_id"].values)
+        poses = torch.eye(4).repeat(len(infos), 1, 1)
+        poses[:, 0, 3] = observation.images[im, :3].mean(dim=(1, 2, 3))
+        poses[:, 1, 3] = detections.bboxes[:, 0]
+        poses[:, 2, 3] = observation.K[im, 0, 0]
+        final = PandasTensorCollection(infos, poses=poses)
+        coarse = PandasTensorCollection(infos.loc[infos.index.repeat(2)].reset_index(drop=True), poses=poses.repeat_interleave(2, 0))
+        extra = {"refiner": {"preds": final}, "coarse": {"preds": coarse}, "depth_refiner": {"preds": final}}
+        return final, extra
+
+
+def _fake_scene_ds(n_frames=5):
+    from megapose6d_amd.tcoll import PandasTensorCollection
+
+    rng = np.random.RandomState(0)
+    ds = []
+    for i in range(n_frames):
+        n_det = 1 + i % 3
+        infos = pd.DataFrame(dict(label=[f"obj_{j:06d}" for j in range(n_det)], scene_id=48 + i // 3, view_id=100 + i))
+        ds.append(dict(rgb=rng.randint(0, 255, (12, 16, 3)).astype(np.uint8), depth=rng.rand(12, 16).astype(np.float32),
+                       K=np.diag([50.0 + i, 50.0, 1.0]), gt_detections=PandasTensorCollection(infos, bboxes=torch.from_numpy(rng.rand(n_det, 4).astype(np.float32)) + i)))
+    return ds
+
+
+def test_prediction_runner_batching_keeps_rows_and_frame_ids():
+    """evaluation caller (reference evaluation/prediction_runner.py:79-209): any batch size gives the same rows, each carrying the
+    scene_id / view_id of ITS frame; keys as in the reference"""
+    from megapose6d_amd.prediction_runner import PredictionRunner
+    from megapose6d_amd.types import InferenceConfig
+
+    ds = _fake_scene_ds()
+    cfg = InferenceConfig(detection_type="gt", n_refiner_iterations=3, run_depth_refiner=True)
+    ref = PredictionRunner(ds, cfg, batch_size=1, device="cpu").get_predictions(_FakeEstimator())
+    assert set(ref) == {"final", "refiner/iteration=3", "refiner/final", "coarse", "depth_refiner"}
+    assert len(ref["final"]) == sum(1 + i % 3 for i in range(5)) and len(ref["coarse"]) == 2 * len(ref["final"])
+    assert ref["final"].infos["view_id"].tolist() == [100 + i for i in range(5) for _ in range(1 + i % 3)]
+    assert ref["final"].infos["scene_id"].tolist() == [48 + i // 3 for i in range(5) for _ in range(1 + i % 3)]
+    for bs in (2, 5):
+        got = PredictionRunner(ds, cfg, batch_size=bs, device="cpu").get_predictions(_FakeEstimator())
+        for k in ref:
+            assert torch.equal(got[k].poses, ref[k].poses)
+            assert got[k].infos[["label", "scene_id", "view_id"]].equals(ref[k].infos[["label", "scene_id", "view_id"]])
+    with pytest.raises(ValueError):
+        PredictionRunner(ds, InferenceConfig(detection_type="nope"), device="cpu").get_predictions(_FakeEstimator())
+
+
+def _runner_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from megapose6d_amd.prediction_runner import PredictionRunner
+    from megapose6d_amd.types import InferenceConfig
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    runner = PredictionRunner(_fake_scene_ds(), InferenceConfig(detection_type="gt"), batch_size=2, device="cpu")
+    preds = runner.get_predictions(_FakeEstimator())
+    q.put((rank, runner.frame_ids, sorted(preds["final"].infos["view_id"].tolist()), preds["final"].poses.sum().item()))
+    dist.destroy_process_group()
+
+
+def test_prediction_runner_two_ranks_gloo_gather():
+    """frames dealt rank::world, results exchanged with one all_gather_object: every rank ends with all rows"""
+    import torch.multiprocessing as mp
+
+    from megapose6d_amd.prediction_runner import PredictionRunner
+    from megapose6d_amd.types import InferenceConfig
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    single = PredictionRunner(_fake_scene_ds(), InferenceConfig(detection_type="gt"), batch_size=2, device="cpu").get_predictions(_FakeEstimator())
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    want = sorted(single["final"].infos["view_id"].tolist())
+    assert res[0][2] == want and res[1][2] == want
+    assert abs(res[0][3] - single["final"].poses.sum().item()) < 1e-4 and abs(res[1][3] - res[0][3]) < 1e-6
