@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   const int row_wrap = row_stride - p.run;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int buf = SBUF ? 0 : ((chunk - c_begin) & 1);
-    if (chunk + 1 < c_end) {  // advance to the next chunk; the loads themselves are unconditional
+    if (chunk + 1 < c_end && (VARIANT & 128) == 0) {  // advance to the next chunk; the loads themselves are unconditional
       bp += BN * BK;
       aoff += BK;
       if constexpr (RAGGED) {
@@ -253,19 +253,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         }
       }
     }
-    MP_CONV_LOAD(aoff, bp)
+    if constexpr ((VARIANT & 16) == 0) {  // (bits 4..6 are timing experiments only: wrong results)
+      MP_CONV_LOAD(aoff, bp)
+    }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
     const float* as = As + buf * BM * LDS_LD + (wm * WM + frag_row) * LDS_LD + frag_k;
     const float* bs = Bs + buf * BN * LDS_LD + (wn * WN + frag_row) * LDS_LD + frag_k;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
+      if constexpr ((VARIANT & 64) != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = a0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = b0;
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk * 8);
+      }
       if constexpr ((VARIANT & 1) != 0) {
-        if (kk == BK / 8 - 1) {  // write the prefetched chunk to the other buffer UNDER the last MFMA group
+        constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
+        if (kk == STORE_KK && (VARIANT & 16) == 0) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
           __builtin_amdgcn_sched_barrier(0);
           MP_CONV_STORE(buf ^ 1)
           __builtin_amdgcn_sched_barrier(0);
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       __builtin_amdgcn_sched_barrier(0);
       MP_CONV_STORE(buf ^ 1)
     }
-    __syncthreads();
+    if constexpr ((VARIANT & 32) == 0) __syncthreads();
   }
 #undef MP_CONV_LOAD
 #undef MP_CONV_STORE
@@ -520,7 +530,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
-  static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 1;  // tuning experiments only
+  static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 257;  // default: LDS store under the 3rd of 4 MFMA groups; others = tuning experiments
   const bool small = conv_bn_tile(d->Cout) == 64;
   // split-K when the tile grid cannot fill the chip (small batches: the released K = 1 / K = 5 refiner passes)
   static const int splitk_on = getenv("MP_CONV_SPLITK") ? atoi(getenv("MP_CONV_SPLITK")) : 1;
@@ -537,16 +547,23 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     }
   }
   if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
-    return small ? launch<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch<128, 128, 64, 64, 1, true>(p, s, alg_k);
+    return small ? launch<128, 64, 64, 32, 257, true>(p, s, alg_k) : launch<128, 128, 64, 64, 257, true>(p, s, alg_k);
   }
   switch (variant) {
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
+    case 513: return small ? launch<128, 64, 64, 32, 513>(p, s, alg_k) : launch<128, 128, 64, 64, 513>(p, s, alg_k);
+    case 129: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 129>(p, s, alg_k);
+    case 17: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 17>(p, s, alg_k);
+    case 33: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 33>(p, s, alg_k);
+    case 49: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 49>(p, s, alg_k);
+    case 113: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 113>(p, s, alg_k);
     case 2: return small ? launch<128, 64, 64, 32, 2>(p, s, alg_k) : launch<128, 128, 64, 64, 2>(p, s, alg_k);
     case 3: return small ? launch<128, 64, 64, 32, 3>(p, s, alg_k) : launch<128, 128, 64, 64, 3>(p, s, alg_k);
     case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
     case 5: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
     case 6: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
-    default: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
+    case 1: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
+    default: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);
   }
 }
 
