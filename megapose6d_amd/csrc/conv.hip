@@ -55,6 +55,8 @@ struct ConvParams {
   // sums to partial[y][M][Cout]; conv_splitk_reduce adds them in a fixed order and applies the epilogue (deterministic)
   float* partial;
   int k_split, chunks_per_split;
+  int tile_begin;    // first linear tile id of this launch (the tail launch of a "full rounds + split-K tail" pair starts later)
+  int m_part_begin;  // first output row held by `partial` (rows before it belong to the single-pass launch)
 };
 
 template <int TM, int TN, bool RES, bool RELU, bool ACT>
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   const int wm = wave / (BN / WN);
   const int wn = wave % (BN / WN);
 
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int lb = xcd_remap(blockIdx.x, gridDim.x) + p.tile_begin;
   const int nblk = lb % p.n_nblocks;
   const int mblk = lb / p.n_nblocks;
   const int m0 = mblk * BM;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   // (compile-time flags: one straight-line store loop per fused mode instead of four data-dependent branches per element)
   const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
   if constexpr (SPLITK) {
-    float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+    float* part = p.partial + (size_t)blockIdx.y * (p.M - p.m_part_begin) * p.Cout;
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       const int n = en0 + jn * 32;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + erow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (m < p.M) part[(size_t)m * p.Cout + n] = acc[i][jn][r];
+          if (m < p.M) part[(size_t)(m - p.m_part_begin) * p.Cout + n] = acc[i][jn][r];
         }
     }
     return;
@@ -349,11 +351,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 __global__ __launch_bounds__(256) void conv_splitk_reduce(ConvParams p) {
   const int c4 = p.Cout >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)p.M * c4) return;
-  const int m = (int)(idx / c4), n = (int)(idx % c4) * 4;
-  float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)m * p.Cout + n);
+  const int m_part = p.M - p.m_part_begin;
+  if (idx >= (long)m_part * c4) return;
+  const int mi = (int)(idx / c4), n = (int)(idx % c4) * 4;
+  const int m = p.m_part_begin + mi;
+  float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)mi * p.Cout + n);
   for (int z = 1; z < p.k_split; ++z) {
-    const float4 q = *reinterpret_cast<const float4*>(p.partial + ((size_t)z * p.M + m) * p.Cout + n);
+    const float4 q = *reinterpret_cast<const float4*>(p.partial + ((size_t)z * m_part + mi) * p.Cout + n);
     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
   }
   const int wo = m % p.Wo;
@@ -392,21 +396,22 @@ static int launch_splitk(const ConvParams& p, hipStream_t s, double alg_k) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  const double m_part = (double)(p.M - p.m_part_begin);
   {
     ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>/splitk" : "conv_nhwc_f32_mfma<128,128,64,64>/splitk",
-                   2.0 * (double)p.M * p.Cout * alg_k,
-                   4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
-    hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED, true>), dim3(q.n_mblocks * q.n_nblocks, q.k_split), dim3(256),
-                       lds, s, q);
+                   2.0 * m_part * p.Cout * alg_k,
+                   4.0 * (m_part * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + m_part * p.Cout), s);
+    hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED, true>),
+                       dim3(q.n_mblocks * q.n_nblocks - q.tile_begin, q.k_split), dim3(256), lds, s, q);
   }
-  ProfScope prof("conv_splitk_reduce", 0.0, 4.0 * (double)p.M * p.Cout * (q.k_split + 1), s);
-  hipLaunchKernelGGL(conv_splitk_reduce, dim3(ceil_div((long)p.M * (p.Cout / 4), 256L)), dim3(256), 0, s, q);
+  ProfScope prof("conv_splitk_reduce", 0.0, 4.0 * m_part * p.Cout * (q.k_split + 1), s);
+  hipLaunchKernelGGL(conv_splitk_reduce, dim3(ceil_div((long)m_part * (p.Cout / 4), 256L)), dim3(256), 0, s, q);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false>
-static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
+static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_main = 0) {
   ConvParams q = p;
   q.n_mblocks = ceil_div(p.M, BM);
   q.n_nblocks = ceil_div(p.Cout, BN);
@@ -418,7 +423,10 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid(q.n_mblocks * q.n_nblocks);
+  // n_tiles_main > 0: only the first n_tiles_main tiles (whole rounds of resident workgroups); a split-K launch covers the rest
+  const int n_tiles = n_tiles_main > 0 ? n_tiles_main : q.n_mblocks * q.n_nblocks;
+  const double m_here = n_tiles_main > 0 ? (double)(n_tiles_main / q.n_nblocks) * BM : (double)p.M;
+  dim3 grid(n_tiles);
   // algorithmic work of this launch: 2*MACs over the REAL (unpadded) reduction length; bytes = input + weights + output once
   static const bool detail = getenv("MP_PROF_DETAIL") != nullptr;  // tuning aid: one profiler row per layer shape
   const char* pname = BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>";
@@ -430,8 +438,8 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k) {
     for (auto& n : names) if (n == buf) { pname = n.c_str(); found = true; break; }
     if (!found) { names.reserve(64); names.emplace_back(buf); pname = names.back().c_str(); }
   }
-  ProfScope prof(pname, 2.0 * (double)p.M * p.Cout * alg_k,
-                 4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
+  ProfScope prof(pname, 2.0 * m_here * p.Cout * alg_k,
+                 4.0 * (m_here * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + m_here * p.Cout), s);
   hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>), grid, dim3(256), lds, s, q);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
@@ -521,6 +529,8 @@ static int make_params(const mp_conv_desc* d, ConvParams* p) {
   p->partial = nullptr;
   p->k_split = 1;
   p->chunks_per_split = p->n_chunks;
+  p->tile_begin = 0;
+  p->m_part_begin = 0;
   return MP_OK;
 }
 
@@ -546,17 +556,43 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
       return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
     }
   }
+  // Full rounds + split-K tail: with R resident workgroups (2 per CU) a grid of n_tiles runs ceil(n_tiles / R) rounds; when the
+  // last round is less than half full, its tiles are split along K over the idle slots instead (layer 3 at 576 rows: 2700 tiles =
+  // 5.27 rounds -> 5 rounds + a third of a round).  Same deterministic partial-sum reduce as the small-batch path.
+  static const int tail_on = getenv("MP_CONV_TAIL") ? atoi(getenv("MP_CONV_TAIL")) : 1;
+  static int resident = 0;
+  if (!resident) {
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    resident = 2 * n_cu;
+  }
+  const int n_nb = ceil_div(p.Cout, small ? 64 : 128);
+  const int n_tail = n_tiles % resident;
+  if (tail_on && splitk_on && d->d_splitk_ws && n_tiles > resident && n_tail > 0 && 2 * n_tail <= resident && (p.Cout % 4) == 0 &&
+      p.run % BK == 0 && resident % n_nb == 0) {
+    const int n_main = n_tiles - n_tail;
+    const int m_begin = (n_main / n_nb) * 128;
+    long S = std::min<long>(resident / n_tail, p.n_chunks / 6);
+    S = std::min<long>(S, d->splitk_ws_floats / ((long)(p.M - m_begin) * p.Cout));
+    if (S >= 2) {
+      int rc2 = small ? launch<128, 64, 64, 32, 257>(p, s, alg_k, n_main) : launch<128, 128, 64, 64, 257>(p, s, alg_k, n_main);
+      if (rc2) return rc2;
+      p.chunks_per_split = ceil_div(p.n_chunks, (int)S);
+      p.k_split = ceil_div(p.n_chunks, p.chunks_per_split);
+      p.partial = d->d_splitk_ws;
+      p.tile_begin = n_main;
+      p.m_part_begin = m_begin;
+      return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
+    }
+  }
   if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
     return small ? launch<128, 64, 64, 32, 257, true>(p, s, alg_k) : launch<128, 128, 64, 64, 257, true>(p, s, alg_k);
   }
   switch (variant) {
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
-    case 513: return small ? launch<128, 64, 64, 32, 513>(p, s, alg_k) : launch<128, 128, 64, 64, 513>(p, s, alg_k);
-    case 129: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 129>(p, s, alg_k);
     case 17: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 17>(p, s, alg_k);
     case 33: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 33>(p, s, alg_k);
-    case 49: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 49>(p, s, alg_k);
-    case 113: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 113>(p, s, alg_k);
     case 2: return small ? launch<128, 64, 64, 32, 2>(p, s, alg_k) : launch<128, 128, 64, 64, 2>(p, s, alg_k);
     case 3: return small ? launch<128, 64, 64, 32, 3>(p, s, alg_k) : launch<128, 128, 64, 64, 3>(p, s, alg_k);
     case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);

@@ -369,3 +369,35 @@ def test_backbone_bf16x9_matches_oracle(eng):
     ref = ob.net_forward(sd, "vanilla_resnet34", x)
     assert (feat.cpu() - ref["features"]).abs().max().item() < 2e-4 * max(1.0, ref["features"].abs().max().item())
     assert (out.cpu() - ref["pose"]).abs().max().item() < 2e-4
+
+
+def test_conv_full_rounds_plus_splitk_tail(eng):
+    """a grid of 600 tiles on 512 resident workgroups: the first 512 tiles run single-pass, the 88 tail tiles split K three ways and
+    are reduced deterministically; the result must equal the plain single launch up to summation order"""
+    n_cu = eng.device_info()[0]
+    g = torch.Generator().manual_seed(5)
+    Cin = Cout = 64
+    H, W = 60, 80
+    N = -(-(2 * n_cu + 88) * 128 // (H * W))      # enough rows for 2*n_cu + ~88 tiles of 128 pixels
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    res = torch.randn(N, Cout, H, W, generator=g)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xb = _to_padded(eng, x, Cin, 1)
+    rb = _to_padded(eng, res, Cout, 1)
+    wp = torch.from_numpy(eng.conv_pack_weights(w.numpy(), Cin, None)).cuda()
+    ws = torch.empty(12 << 20, device="cuda")
+    outs = []
+    for scratch in (None, ws, ws):
+        yb = eng.padded_nhwc(N, H, W, Cout, 1, "cuda")
+        eng.profile_begin()
+        eng.conv2d_nhwc(xb, N, H, W, Cin, 1, wp, bias.cuda(), Cout, 3, 1, 1, yb, 1, residual=rb, relu=True, splitk_ws=scratch)
+        prof = eng.profile_end()
+        outs.append((yb.clone(), prof))
+    assert not any(k.endswith("/splitk") for k in outs[0][1])
+    assert any(k.endswith("/splitk") for k in outs[1][1]) and "conv_splitk_reduce" in outs[1][1]
+    assert torch.equal(outs[1][0], outs[2][0])                                   # deterministic
+    ref = F.relu(F.conv2d(x, w, bias, padding=1) + res)
+    for yb, _ in outs[:2]:
+        assert (_from_padded(eng, yb, N, H, W, Cout, 1) - ref).abs().max() < 2e-4 * ref.abs().max()
+    assert (outs[0][0] - outs[1][0]).abs().max() < 1e-4 * ref.abs().max()

@@ -149,7 +149,7 @@ def test_full_grid_multi_object_invariants():
     # strict_batching (reference batch sizes) gives the same result as the large-launch schedule
     est.strict_batching = True
     f3, _ = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=5, bsz_images=128, bsz_objects=8)
-    assert (f3.poses - f1.poses).abs().max() < 1e-5
+    assert (f3.poses - f1.poses).abs().max() < 5e-5
 
 
 def test_rgbd_and_wide_resnet_pipeline_vs_oracle():
@@ -231,9 +231,9 @@ def test_row_sharded_pipeline_two_ranks_matches_single_rank():
     for p in procs:
         p.join(timeout=120)
     for rank, pose, logits, hyp in res:
-        assert np.abs(logits - ref_logits).max() < 1e-5 * max(1.0, np.abs(ref_logits).max())
+        assert np.abs(logits - ref_logits).max() < 5e-5 * max(1.0, np.abs(ref_logits).max())
         assert hyp == f1.infos["hypothesis_id"].tolist()
-        assert np.abs(pose - ref_pose).max() < 1e-5
+        assert np.abs(pose - ref_pose).max() < 5e-5
     assert np.array_equal(res[0][1], res[1][1])  # every rank returns the identical full result
 
 
