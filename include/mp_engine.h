@@ -110,6 +110,18 @@ int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const floa
                      int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb, int c_normals,
                      int c_depth, void* d_workspace, size_t workspace_bytes, mp_stream stream);
 
+/* mp_raster_render + the observation crop of every item (mp_crop_roi_align semantics, boxes / im_ids per ITEM = n_views /
+ * views_per_item) written by the same launch into channels c0_crop.. of the item's pixels: what PosePredictor.forward does per
+ * iteration with crop_inputs (models/pose_rigid.py:180-247) + render_images_multiview (:336-408) + torch.cat (:567).  One extra
+ * workgroup per (item, band) does the roi_align, co-located on the XCD of the views' workgroups so that the L2 merges the channel
+ * slices of a pixel line. */
+int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K, int n_views,
+                          int h, int w, uint32_t flags, const mp_lights* lights, float* d_out, int64_t stride_v,
+                          int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb,
+                          int c_normals, int c_depth, void* d_workspace, size_t workspace_bytes,
+                          const float* d_images /*[n_im,C,H,W]*/, int n_im, int C, int H, int W, const int32_t* d_im_ids,
+                          const float* d_boxes, int c0_crop, mp_stream stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Crop: replaces lib3d/cropping.py:113-144 crop_images (torchvision.ops.roi_align,       */
 /* sampling_ratio=4, aligned=False) incl. the RGBD validity rule (:131-142), reading the  */

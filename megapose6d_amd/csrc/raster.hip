@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include "crop_device.h"
 
 namespace mp {
 
@@ -69,6 +70,15 @@ struct VtxRec {
   int X, Y;     // fixed-point screen coordinates (1/256 px)
   float invz;   // 1 / camera z
   int valid;
+};
+
+// optional fused crop role (one extra workgroup per (item, band)): roi_align of the observation into channels c0.. of the same
+// pixel lines the views write, so that the XCD's L2 merges all slices of a line (see the work-to-workgroup map in raster_bands)
+struct CropArgs {
+  const float* images;     // [n_im][C][H][W], NULL = no crop role
+  const int32_t* im_ids;   // [n_items]
+  const float* boxes;      // [n_items][4]
+  int C, H, W, c0;
 };
 
 struct LightsDev {
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const VtxRec* __restrict__ vtx, const unsigned* __restrict__ bounds, int max_verts, int max_faces, int h, int w, uint32_t flags,
     LightsDev lights, float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
-    long long stride_x, int c_rgb, int c_normals, int c_depth) {
+    long long stride_x, int c_rgb, int c_normals, int c_depth, CropArgs crop) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];  // [BAND_H*w] + big-triangle queue
   int* big_queue = (int*)(zbuf + (size_t)BAND_H * w);
   int* list = big_queue + BIG_QUEUE;  // [LIST_CAP]
@@ -293,12 +303,30 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
   // of one XCD lets its L2 merge the 24-byte slices into whole lines before they are written back (otherwise every slice is a
   // partial-line write from a different L2).
   const int n_bands = (h + BAND_H - 1) / BAND_H;
+  const int roles = views_per_item + (crop.images ? 1 : 0);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int q = (slot / views_per_item) * 8 + xcd;   // (item, band) index
+  const int q = (slot / roles) * 8 + xcd;   // (item, band) index
   if (q >= n_items * n_bands) return;
-  const int view = (q / n_bands) * views_per_item + slot % views_per_item;
   const int band = q % n_bands;
   const int y0 = band * BAND_H;
+  if (slot % roles == views_per_item) {  // crop role (whole workgroup): the band's rows of the observation crop
+    const int item = q / n_bands;
+    const int yl = min(h, y0 + BAND_H) - 1;
+    const float* bx = crop.boxes + (size_t)item * 4;
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
+    const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
+    const float* img = crop.images + (size_t)crop.im_ids[item] * crop.C * crop.H * crop.W;
+    float* o_item = out + (size_t)item * stride_v + crop.c0;
+    for (int i = threadIdx.x; i < (yl - y0 + 1) * w; i += BAND_THREADS) {
+      const int py = y0 + i / w, px = i % w;
+      float* o = o_item + (size_t)py * stride_y + (size_t)px * stride_x;
+      if (crop.C == 4) crop_pixel<4>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+      else crop_pixel<3>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+    }
+    return;
+  }
+  const int view = (q / n_bands) * views_per_item + slot % roles;
   const int y1 = min(h, y0 + BAND_H) - 1;
   const int npix = (y1 - y0 + 1) * w;
   const MeshDev m = meshes[mesh_ids[view]];
@@ -611,10 +639,10 @@ extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views) {
   return db ? (size_t)n_views * ((size_t)db->max_verts * sizeof(VtxRec) + (size_t)faces_stride(db) * sizeof(unsigned)) : 0;
 }
 
-extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
-                                int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
-                                int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
-                                int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream) {
+static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
+                              int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
+                              int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
+                              int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream, const CropArgs& crop) {
   MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
   MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && views_per_item >= 1, "mp_raster_render: bad size");
   MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
@@ -648,13 +676,42 @@ extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids,
   MP_REQUIRE(lds <= 160 * 1024 - 64, "mp_raster_render: image too wide for the LDS z-buffer");
   MP_REQUIRE(n_views % views_per_item == 0, "mp_raster_render: n_views (%d) must be a multiple of views_per_item (%d)", n_views, views_per_item);
   const int n_items = n_views / views_per_item;
-  dim3 g2(ceil_div(n_items * ceil_div(h, BAND_H), 8) * 8 * views_per_item);
+  const int roles = views_per_item + (crop.images ? 1 : 0);
+  dim3 g2(ceil_div(n_items * ceil_div(h, BAND_H), 8) * 8 * roles);
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (((flags & MP_RASTER_NORMALS) && c_normals >= 0) ? 3 : 0) + (((flags & MP_RASTER_DEPTH) && c_depth >= 0) ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
-  ProfScope prof("raster_bands", 0.0, (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces), s);
+  // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
+  const double crop_bytes = crop.images ? (double)n_items * 2.0 * crop.C * 4.0 * h * w : 0.0;
+  ProfScope prof("raster_bands", 0.0,
+                 (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) + crop_bytes, s);
   hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, vtx, tri_bounds,
                      db->max_verts, faces_stride(db), h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view, (long long)stride_y,
-                     (long long)stride_x, c_rgb, c_normals, c_depth);
+                     (long long)stride_x, c_rgb, c_normals, c_depth, crop);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
+}
+
+extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
+                                int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
+                                int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
+                                int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  CropArgs none;
+  memset(&none, 0, sizeof(none));
+  return raster_render_impl(db, d_mesh_ids, d_TCO, d_K, n_views, h, w, flags, lights, d_out, stride_v, views_per_item, stride_view, stride_y,
+                            stride_x, c_rgb, c_normals, c_depth, d_ws, ws_bytes, stream, none);
+}
+
+extern "C" int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
+                                     int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
+                                     int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
+                                     int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes,
+                                     const float* d_images, int n_im, int C, int H, int W, const int32_t* d_im_ids,
+                                     const float* d_boxes, int c0_crop, mp_stream stream) {
+  MP_REQUIRE(d_images && d_im_ids && d_boxes && n_im > 0 && (C == 3 || C == 4) && H > 0 && W > 0 && c0_crop >= 0,
+             "mp_raster_render_crop: bad crop arguments");
+  CropArgs crop;
+  crop.images = d_images; crop.im_ids = d_im_ids; crop.boxes = d_boxes;
+  crop.C = C; crop.H = H; crop.W = W; crop.c0 = c0_crop;
+  return raster_render_impl(db, d_mesh_ids, d_TCO, d_K, n_views, h, w, flags, lights, d_out, stride_v, views_per_item, stride_view, stride_y,
+                            stride_x, c_rgb, c_normals, c_depth, d_ws, ws_bytes, stream, crop);
 }

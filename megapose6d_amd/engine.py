@@ -146,8 +146,11 @@ def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()) -> Ligh
 
 def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, h: int, w: int, flags: int,
                   lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
-                  c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0, slot: int = 0) -> None:
-    """Render n views into `out` (float32 device tensor) at the given element strides."""
+                  c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0, slot: int = 0,
+                  crop=None) -> None:
+    """Render n views into `out` (float32 device tensor) at the given element strides.
+    crop = (images [n_im,C,H,W], im_ids [n_items], boxes [n_items,4], c0): also roi_align-crop every item's observation into channels
+    c0.. of its pixels in the same launch (mp_raster_render_crop)."""
     lib = _lib.load()
     n = int(TCO.shape[0])
     mesh_ids = _dev_i32(mesh_ids)
@@ -155,6 +158,17 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     K = _dev_f32(K)
     assert out.dtype == torch.float32 and out.is_cuda
     ws = db.workspace(n, out.device, slot)
+    if crop is not None:
+        images, im_ids, boxes, c0 = crop
+        images = _dev_f32(images)
+        n_im, Cc, H, W = images.shape
+        im_ids, boxes = _dev_i32(im_ids), _dev_f32(boxes)
+        assert boxes.shape[0] * views_per_item == n and im_ids.shape[0] == boxes.shape[0]
+        check(lib.mp_raster_render_crop(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
+                                        out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x,
+                                        c_rgb, c_normals, c_depth, ws.data_ptr(), ws.numel(), images.data_ptr(), n_im, Cc, H, W,
+                                        im_ids.data_ptr(), boxes.data_ptr(), c0, _stream()))
+        return
     check(lib.mp_raster_render(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
                                out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x, c_rgb,
                                c_normals, c_depth, ws.data_ptr(), ws.numel(), _stream()))

@@ -212,14 +212,14 @@ class PosePredictor(nn.Module):
             TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode, (H, W), (h, w), 1.4)
         x = self._x_buffer(b, device, slot)
         s_row, s_y, s_x, off = self._x_geometry()
-        eng.crop_roi_align(images, im_ids, boxes_crop, h, w, x, s_row, s_y, s_x, 0, off)
+        # the observation crop (channels 0..nin-1) is written by the rasteriser launch below (one launch fills the whole CNN input)
         nin, nper = self._n_input_channels, self._n_single_render_channels
         t0 = time.time()
         view_ids = ren_ids.repeat_interleave(V) if V > 1 else ren_ids
         self.renderer.render_into(view_ids, TCV_O.view(b * V, 4, 4), KV_crop.view(b * V, 3, 3), self._lights(), (h, w), x, s_row,
                                   s_y, s_x, nin, nin + 3 if self.render_normals else -1,
                                   nin + (6 if self.render_normals else 3) if self.render_depth else -1, off,
-                                  views_per_item=V, stride_view=nper, slot=slot)
+                                  views_per_item=V, stride_view=nper, slot=slot, crop=(images, im_ids, boxes_crop, 0))
         render_time = time.time() - t0
         mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
         bb = self._backbone_engine()

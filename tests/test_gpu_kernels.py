@@ -401,3 +401,34 @@ def test_conv_full_rounds_plus_splitk_tail(eng):
     for yb, _ in outs[:2]:
         assert (_from_padded(eng, yb, N, H, W, Cout, 1) - ref).abs().max() < 2e-4 * ref.abs().max()
     assert (outs[0][0] - outs[1][0]).abs().max() < 1e-4 * ref.abs().max()
+
+
+@pytest.mark.parametrize("C", [3, 4])
+def test_fused_crop_in_raster_launch_equals_standalone_crop(eng, engine_meshes, C):
+    """mp_raster_render_crop: the crop role of the band kernel writes exactly what mp_crop_roi_align writes, and leaves the views alone"""
+    from megapose6d_amd import synthetic as syn
+
+    db = _mesh_db(eng, engine_meshes)
+    rng = np.random.RandomState(7)
+    n_items, V, h, w, Cp = 3, 4, 240, 320, 32
+    g = torch.Generator().manual_seed(0)
+    images = torch.rand(2, C, 480, 640, generator=g).cuda()
+    if C == 4:
+        images[:, 3] = torch.where(images[:, 3] < 0.1, torch.zeros_like(images[:, 3]), images[:, 3])   # invalid depth pixels
+    im_ids = torch.tensor([1, 0, 1], dtype=torch.int32).cuda()
+    boxes = torch.tensor([[100.0, 80, 400, 305], [-40.0, -30, 300, 225], [500.0, 300, 700, 450]]).cuda()
+    T = torch.from_numpy(np.stack([syn.random_pose(rng, z_range=(0.3, 0.6)) for _ in range(n_items * V)])).cuda()
+    K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None].astype(np.float32), n_items * V, 0)).cuda()
+    K[:, :2] *= 0.5
+    ids = torch.tensor([0, 1, 2], dtype=torch.int32).repeat_interleave(V).cuda()
+    nin = C
+    outs = []
+    for fused in (False, True):
+        x = torch.full((n_items, h, w, Cp), -3.0, device="cuda")
+        if not fused:
+            eng.crop_roi_align(images, im_ids, boxes, h, w, x, h * w * Cp, w * Cp, Cp, 0)
+        eng.raster_render(db, ids, T, K, h, w, 1, eng.make_lights(), x, h * w * Cp, w * Cp, Cp, nin, nin + 3, -1, views_per_item=V,
+                          stride_view=6, crop=(images, im_ids, boxes, 0) if fused else None)
+        outs.append(x)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[1][..., :nin] != -3.0).all() and (outs[1][..., nin + 6 * V:] == -3.0).all()   # crop written, padding untouched
