@@ -102,15 +102,21 @@ template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 3 : 2, (VARIANT & 4) ? 3 : 2))) void conv_nhwc_f32_mfma(ConvParams p) {
   constexpr bool SBUF = (VARIANT & 4) != 0;
   constexpr int NBUF = SBUF ? 1 : 2;
+  // bit 10: global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write).  The instruction writes lane l's 16 bytes
+  // at M0 + 16*l, so tile rows are UNPADDED (32 floats) and bank conflicts are avoided by an XOR swizzle instead: the 16-byte
+  // column c of row r is stored at column c ^ (r & 7), applied on the global side (lane (r, c) fetches column c ^ (r & 7)).
+  constexpr bool LDSD = (VARIANT & 1024) != 0;
+  constexpr int LDT = LDSD ? BK : LDS_LD;
+  static_assert(!(LDSD && SBUF), "LDS-direct staging uses both buffers");
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
   constexpr int B_LD4 = BN / 32;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                             // [NBUF][BM][LDS_LD]
-  float* Bs = smem + NBUF * BM * LDS_LD;        // [NBUF][BN][LDS_LD]
-  int* row_off = (int*)(Bs + NBUF * BN * LDS_LD);  // [BM] output element offset of each tile row (-1: none)
+  float* As = smem;                          // [NBUF][BM][LDT]
+  float* Bs = smem + NBUF * BM * LDT;        // [NBUF][BN][LDT]
+  int* row_off = (int*)(Bs + NBUF * BN * LDT);  // [BM] output element offset of each tile row (-1: none)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     row_off[r] = off;
   }
 
-  const float* b_ptr = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + tid * 4;
+  const int a_col = LDSD ? (((tid & 7) ^ ((tid >> 3) & 7)) * 4) : a_c4 * 4;  // this thread's (swizzled) float offset in a chunk row
+  const float* b_ptr = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;
   const int row_stride = p.Wp * p.C;  // floats between successive kh rows
 
   f32x16 acc[TM][TN];
@@ -184,17 +191,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 #define MP_ST4(P, V) (*reinterpret_cast<float4*>(P) = (V))
 #define MP_CONV_STORE(BUF)                                                        \
   {                                                                               \
-    float* as_w = As + (BUF) * BM * LDS_LD + a_r0 * LDS_LD + a_c4 * 4;            \
-    float* bs_w = Bs + (BUF) * BN * LDS_LD + (tid >> 3) * LDS_LD + (tid & 7) * 4; \
+    float* as_w = As + (BUF) * BM * LDT + a_r0 * LDT + a_c4 * 4;            \
+    float* bs_w = Bs + (BUF) * BN * LDT + (tid >> 3) * LDT + (tid & 7) * 4; \
     MP_ST4(as_w, a0);                                                             \
-    MP_ST4(as_w + 32 * LDS_LD, a1);                                               \
-    MP_ST4(as_w + 64 * LDS_LD, a2);                                               \
-    MP_ST4(as_w + 96 * LDS_LD, a3);                                               \
+    MP_ST4(as_w + 32 * LDT, a1);                                               \
+    MP_ST4(as_w + 64 * LDT, a2);                                               \
+    MP_ST4(as_w + 96 * LDT, a3);                                               \
     MP_ST4(bs_w, b0);                                                             \
-    MP_ST4(bs_w + 32 * LDS_LD, b1);                                               \
+    MP_ST4(bs_w + 32 * LDT, b1);                                               \
     if constexpr (B_LD4 > 2) {                                                    \
-      MP_ST4(bs_w + 64 * LDS_LD, b2);                                             \
-      MP_ST4(bs_w + 96 * LDS_LD, b3);                                             \
+      MP_ST4(bs_w + 64 * LDT, b2);                                             \
+      MP_ST4(bs_w + 96 * LDT, b3);                                             \
     }                                                                             \
   }
   static_assert(A_LD4 == 4 && (B_LD4 == 2 || B_LD4 == 4), "staging code is written for BM = 128, BN in {64, 128}");
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   // aoff = element offset from the pixel's first tap (run % 4 == 0, so a float4 never straddles two rows)
   // RAGGED (run % 32 != 0, the 7x7 / 5x5 stems): per-lane bookkeeping.  Otherwise chunks never straddle kernel rows and
   // the bump is wave-uniform (scalar registers), which is what the 3x3 / 1x1 layers use.
-  int j = a_c4 * 4, aoff = a_c4 * 4;
+  int j = a_col, aoff = a_col;
   int ju = 0;  // uniform run position (non-RAGGED)
   const float* bp = b_ptr;
   int c_begin = 0, c_end = p.n_chunks;
@@ -217,20 +224,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     c_end = min(p.n_chunks, c_begin + p.chunks_per_split);
     bp += (size_t)c_begin * (BN * BK);
     if constexpr (RAGGED) {
-      const int jj = a_c4 * 4 + c_begin * BK;
+      const int jj = a_col + c_begin * BK;
       const int kh = jj / p.run;
       j = jj - kh * p.run;
       aoff = kh * row_stride + j;
     } else {
       const int kh = (c_begin * BK) / p.run;
       ju = c_begin * BK - kh * p.run;
-      aoff = a_c4 * 4 + kh * row_stride + ju;
+      aoff = a_col + kh * row_stride + ju;
     }
   } else if constexpr (RAGGED) {
     while (j >= p.run) { j -= p.run; aoff += row_stride - p.run; }
   }
-  MP_CONV_LOAD(aoff, bp)
-  MP_CONV_STORE(0)
+#define MP_GPTR(P) ((const void __attribute__((address_space(1)))*)(P))
+#define MP_LPTR(P) ((void __attribute__((address_space(3)))*)(P))
+#define MP_CONV_LOAD_LDS(BUF, AOFF, BP)                                                                         \
+  {                                                                                                             \
+    float* as_d = As + (BUF) * BM * LDT + (wave * 8) * LDT; /* wave-uniform: lanes land at +16 B * lane */      \
+    float* bs_d = Bs + (BUF) * BN * LDT + (wave * 8) * LDT;                                                     \
+    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr0 + (AOFF)), MP_LPTR(as_d), 16, 0, 0);                        \
+    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr1 + (AOFF)), MP_LPTR(as_d + 32 * LDT), 16, 0, 0);             \
+    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr2 + (AOFF)), MP_LPTR(as_d + 64 * LDT), 16, 0, 0);             \
+    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr3 + (AOFF)), MP_LPTR(as_d + 96 * LDT), 16, 0, 0);             \
+    __builtin_amdgcn_global_load_lds(MP_GPTR(BP), MP_LPTR(bs_d), 16, 0, 0);                                     \
+    __builtin_amdgcn_global_load_lds(MP_GPTR((BP) + 1024), MP_LPTR(bs_d + 32 * LDT), 16, 0, 0);                 \
+    if constexpr (B_LD4 > 2) {                                                                                  \
+      __builtin_amdgcn_global_load_lds(MP_GPTR((BP) + 2048), MP_LPTR(bs_d + 64 * LDT), 16, 0, 0);               \
+      __builtin_amdgcn_global_load_lds(MP_GPTR((BP) + 3072), MP_LPTR(bs_d + 96 * LDT), 16, 0, 0);               \
+    }                                                                                                           \
+  }
+  if constexpr (LDSD) {
+    MP_CONV_LOAD_LDS(0, aoff, bp)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    MP_CONV_LOAD(aoff, bp)
+    MP_CONV_STORE(0)
+  }
   __syncthreads();
 
   const int frag_row = lane & 31;
@@ -255,12 +284,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         }
       }
     }
-    if constexpr ((VARIANT & 16) == 0) {  // (bits 4..6 are timing experiments only: wrong results)
+    if constexpr (LDSD) {
+      MP_CONV_LOAD_LDS(buf ^ 1, aoff, bp)  // straight into the buffer every wave finished reading at the last barrier
+    } else if constexpr ((VARIANT & 16) == 0) {  // (bits 4..6 are timing experiments only: wrong results)
       MP_CONV_LOAD(aoff, bp)
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
-    const float* as = As + buf * BM * LDS_LD + (wm * WM + frag_row) * LDS_LD + frag_k;
-    const float* bs = Bs + buf * BN * LDS_LD + (wn * WN + frag_row) * LDS_LD + frag_k;
+    const float* as = As + buf * BM * LDT + (LDSD ? 0 : (wm * WM + frag_row) * LDT + frag_k);
+    const float* bs = Bs + buf * BN * LDT + (LDSD ? 0 : (wn * WN + frag_row) * LDT + frag_k);
+    // LDS-direct layout: 16-byte column (2*kk + lane/32) of row R sits at column ^ (R & 7); (R + 32*i) & 7 == R & 7
+    const int swz = ((lane >> 5) ^ (frag_row & 7)) * 4;
+    const int a_idx = (wm * WM + frag_row) * BK + swz, b_idx = (wn * WN + frag_row) * BK + swz;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
@@ -269,15 +303,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         for (int i = 0; i < TM; ++i) af[i] = a0;
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = b0;
+      } else if constexpr (LDSD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + ((a_idx ^ (kk * 8)) + i * 32 * BK));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + ((b_idx ^ (kk * 8)) + j * 32 * BK));
       } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk * 8);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT + kk * 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk * 8);
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT + kk * 8);
       }
       if constexpr ((VARIANT & 1) != 0) {
         constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
-        if (kk == STORE_KK && (VARIANT & 16) == 0) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
+        if (kk == STORE_KK && (VARIANT & 16) == 0 && !LDSD) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
           __builtin_amdgcn_sched_barrier(0);
           MP_CONV_STORE(buf ^ 1)
           __builtin_amdgcn_sched_barrier(0);
@@ -301,7 +340,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
           }
       }
     }
-    if constexpr (SBUF) {
+    if constexpr (LDSD) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next chunk has landed in LDS
+    } else if constexpr (SBUF) {
       __syncthreads();  // every wave is done reading this chunk
       MP_CONV_STORE(0)
     } else if constexpr ((VARIANT & 1) == 0) {
@@ -311,6 +352,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     if constexpr ((VARIANT & 32) == 0) __syncthreads();
   }
 #undef MP_CONV_LOAD
+#undef MP_CONV_LOAD_LDS
+#undef MP_GPTR
+#undef MP_LPTR
 #undef MP_CONV_STORE
 #undef MP_LD4
 #undef MP_ST4
@@ -345,6 +389,207 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
     default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LDS-direct variant: global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write, no vmcnt waits inside the MFMA
+// stream).  The instruction writes lane l's 16 bytes at M0 + 16*l, so tile rows are UNPADDED (32 floats) and bank conflicts are
+// avoided by an XOR swizzle instead: the 16-byte column c of row r lives at column c ^ (r & 7); it is applied on the global side
+// (lane (r, c) fetches column c ^ (r & 7)) and undone in the fragment reads.  The two stages are separate __shared__ objects and
+// the chunk body takes them as __restrict__ pointers: that is what lets the compiler prove that the ds_reads of one stage do not
+// depend on the LDS-DMA writes into the other (otherwise it inserts s_waitcnt vmcnt(0) in front of every fragment read).
+#define MP_GPTR(P) ((const void __attribute__((address_space(1)))*)(P))
+#define MP_LPTR(P) ((void __attribute__((address_space(3)))*)(P))
+template <int BN, int TM, int TN, int SPREAD>
+__device__ __forceinline__ void ldsd_chunk(const float* __restrict__ a_rd, const float* __restrict__ b_rd, float* __restrict__ a_wr,
+                                           float* __restrict__ b_wr, const float* ga0, const float* ga1, const float* ga2,
+                                           const float* ga3, const float* gb, int a_idx, int b_idx, f32x16 (&acc)[TM][TN]) {
+  // SPREAD = 0: all loads of the next chunk up front; 1: two per MFMA group (a burst of 8 vector-memory instructions otherwise
+  // holds up the wave's in-order issue while the texture-address unit drains it)
+#define MP_LDSD_A01 __builtin_amdgcn_global_load_lds(MP_GPTR(ga0), MP_LPTR(a_wr), 16, 0, 0); \
+                    __builtin_amdgcn_global_load_lds(MP_GPTR(ga1), MP_LPTR(a_wr + 32 * BK), 16, 0, 0);
+#define MP_LDSD_A23 __builtin_amdgcn_global_load_lds(MP_GPTR(ga2), MP_LPTR(a_wr + 64 * BK), 16, 0, 0); \
+                    __builtin_amdgcn_global_load_lds(MP_GPTR(ga3), MP_LPTR(a_wr + 96 * BK), 16, 0, 0);
+#define MP_LDSD_B01 __builtin_amdgcn_global_load_lds(MP_GPTR(gb), MP_LPTR(b_wr), 16, 0, 0); \
+                    __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 1024), MP_LPTR(b_wr + 32 * BK), 16, 0, 0);
+#define MP_LDSD_B23 if constexpr (BN > 64) { \
+                      __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 2048), MP_LPTR(b_wr + 64 * BK), 16, 0, 0); \
+                      __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 3072), MP_LPTR(b_wr + 96 * BK), 16, 0, 0); }
+  if constexpr (SPREAD == 0) {
+    MP_LDSD_A01 MP_LDSD_A23 MP_LDSD_B01 MP_LDSD_B23
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int kk = 0; kk < BK / 8; ++kk) {
+    if constexpr (SPREAD == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) { MP_LDSD_A01 }
+      if (kk == 1) { MP_LDSD_A23 }
+      if (kk == 2) { MP_LDSD_B01 }
+      if (kk == 3) { MP_LDSD_B23 }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_rd + ((a_idx ^ (kk * 8)) + i * 32 * BK));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_rd + ((b_idx ^ (kk * 8)) + j * 32 * BK));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+#undef MP_LDSD_A01
+#undef MP_LDSD_A23
+#undef MP_LDSD_B01
+#undef MP_LDSD_B23
+}
+
+template <int BN, int WM, int WN, bool RAGGED, int SPREAD = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma_ldsd(ConvParams p) {
+  constexpr int BM = 128;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  constexpr int TM = WM / 32, TN = WN / 32;
+  __shared__ __attribute__((aligned(16))) float As0[BM * BK];
+  __shared__ __attribute__((aligned(16))) float As1[BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
+  __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
+  __shared__ int row_off[BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / (BN / WN);
+  const int wn = wave % (BN / WN);
+  const int lb = xcd_remap(blockIdx.x, gridDim.x) + p.tile_begin;
+  const int nblk = lb % p.n_nblocks;
+  const int mblk = lb / p.n_nblocks;
+  const int m0 = mblk * BM;
+  const int n0 = nblk * BN;
+
+  const int a_r0 = tid >> 3;                                   // 0..31 (+32 i)
+  const int a_col = ((tid & 7) ^ ((tid >> 3) & 7)) * 4;        // swizzled float offset inside the 32-float chunk row
+  const float* a_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + a_r0 + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int wo = m % p.Wo;
+    const int t = m / p.Wo;
+    const int ho = t % p.Ho;
+    const int n = t / p.Ho;
+    const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
+    a_ptr[i] = p.x + pix * p.C;
+  }
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < p.M) {
+      const int wo = m % p.Wo;
+      const int t = m / p.Wo;
+      const int ho = t % p.Ho;
+      const int n = t / p.Ho;
+      off = (((n * p.Hop) + ho + p.out_border) * p.Wop + wo + p.out_border) * p.Cout;
+    }
+    row_off[r] = off;
+  }
+  const float* bp = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;
+  const int row_stride = p.Wp * p.C;
+  const int row_wrap = row_stride - p.run;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int j = a_col, aoff = a_col, ju = 0;
+  if constexpr (RAGGED) {
+    while (j >= p.run) { j -= p.run; aoff += row_wrap; }
+  }
+  // wave-uniform LDS destinations of this wave's 8-row slabs
+  float* aw0 = As0 + wave * 8 * BK;
+  float* aw1 = As1 + wave * 8 * BK;
+  float* bw0 = Bs0 + wave * 8 * BK;
+  float* bw1 = Bs1 + wave * 8 * BK;
+  // prologue: chunk 0 -> stage 0
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[0] + aoff), MP_LPTR(aw0), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[1] + aoff), MP_LPTR(aw0 + 32 * BK), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[2] + aoff), MP_LPTR(aw0 + 64 * BK), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[3] + aoff), MP_LPTR(aw0 + 96 * BK), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(bp), MP_LPTR(bw0), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 1024), MP_LPTR(bw0 + 32 * BK), 16, 0, 0);
+  if constexpr (BN > 64) {
+    __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 2048), MP_LPTR(bw0 + 64 * BK), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 3072), MP_LPTR(bw0 + 96 * BK), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frag_row = lane & 31;
+  const int swz = ((lane >> 5) ^ (frag_row & 7)) * 4;   // (R + 32 i) & 7 == R & 7
+  const int a_idx = (wm * WM + frag_row) * BK + swz, b_idx = (wn * WN + frag_row) * BK + swz;
+
+#define MP_LDSD_ADVANCE(CH)                       \
+  if ((CH) + 1 < p.n_chunks) {                    \
+    bp += BN * BK;                                \
+    aoff += BK;                                   \
+    if constexpr (RAGGED) {                       \
+      j += BK;                                    \
+      while (j >= p.run) { j -= p.run; aoff += row_wrap; } \
+    } else {                                      \
+      ju += BK;                                   \
+      if (ju == p.run) { ju = 0; aoff += row_wrap; } \
+    }                                             \
+  }
+  for (int chunk = 0; chunk < p.n_chunks; chunk += 2) {
+    MP_LDSD_ADVANCE(chunk)   // chunk + 1 -> stage 1 while stage 0 is consumed (the last chunk harmlessly re-loads itself)
+    ldsd_chunk<BN, TM, TN, SPREAD>(As0, Bs0, aw1, bw1, a_ptr[0] + aoff, a_ptr[1] + aoff, a_ptr[2] + aoff, a_ptr[3] + aoff, bp, a_idx, b_idx, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (chunk + 1 >= p.n_chunks) break;
+    MP_LDSD_ADVANCE(chunk + 1)
+    ldsd_chunk<BN, TM, TN, SPREAD>(As1, Bs1, aw0, bw0, a_ptr[0] + aoff, a_ptr[1] + aoff, a_ptr[2] + aoff, a_ptr[3] + aoff, bp, a_idx, b_idx, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef MP_LDSD_ADVANCE
+
+  const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
+  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
+  switch (emode) {
+    case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
+    case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
+    case 2: conv_epilogue<TM, TN, false, true, false>(p, acc, row_off, erow0, en0); break;
+    case 3: conv_epilogue<TM, TN, true, true, false>(p, acc, row_off, erow0, en0); break;
+    case 4: conv_epilogue<TM, TN, false, false, true>(p, acc, row_off, erow0, en0); break;
+    case 5: conv_epilogue<TM, TN, true, false, true>(p, acc, row_off, erow0, en0); break;
+    case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
+    default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
+  }
+}
+#undef MP_GPTR
+#undef MP_LPTR
+
+template <int BN, int WM, int WN, bool RAGGED, int SPREAD = 0>
+static int launch_ldsd(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_main = 0) {
+  ConvParams q = p;
+  q.n_mblocks = ceil_div(p.M, 128);
+  q.n_nblocks = ceil_div(p.Cout, BN);
+  const int n_tiles = n_tiles_main > 0 ? n_tiles_main : q.n_mblocks * q.n_nblocks;
+  const double m_here = n_tiles_main > 0 ? (double)(n_tiles_main / q.n_nblocks) * 128 : (double)p.M;
+  ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * m_here * p.Cout * alg_k,
+                 4.0 * (m_here * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + m_here * p.Cout), s);
+  hipLaunchKernelGGL((conv_nhwc_f32_mfma_ldsd<BN, WM, WN, RAGGED, SPREAD>), dim3(n_tiles), dim3(256), 0, s, q);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
 }
 
 // sum of the k_split partial tiles in ascending split order + the fused epilogue (bias, residual, ReLU, pre-activation output)
@@ -416,7 +661,8 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   q.n_mblocks = ceil_div(p.M, BM);
   q.n_nblocks = ceil_div(p.Cout, BN);
   constexpr int NBUF = (VARIANT & 4) ? 1 : 2;
-  const size_t lds = (size_t)(NBUF * BM * LDS_LD + NBUF * BN * LDS_LD) * sizeof(float) + BM * sizeof(int);
+  constexpr int LDT = (VARIANT & 1024) ? BK : LDS_LD;
+  const size_t lds = (size_t)(NBUF * BM * LDT + NBUF * BN * LDT) * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>,
@@ -586,8 +832,14 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
       return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
     }
   }
+  static const int ldsd = getenv("MP_CONV_LDSD") ? atoi(getenv("MP_CONV_LDSD")) : 0;  // bit 0: 128x128 layers, bit 1: 128x64, bit 2: stems
   if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
+    if (ldsd & 4) return small ? launch_ldsd<64, 64, 32, true>(p, s, alg_k) : launch_ldsd<128, 64, 64, true>(p, s, alg_k);
     return small ? launch<128, 64, 64, 32, 257, true>(p, s, alg_k) : launch<128, 128, 64, 64, 257, true>(p, s, alg_k);
+  }
+  if (small ? (ldsd & 2) : (ldsd & 1)) {
+    if (ldsd & 8) return small ? launch_ldsd<64, 64, 32, false, 1>(p, s, alg_k) : launch_ldsd<128, 64, 64, false, 1>(p, s, alg_k);
+    return small ? launch_ldsd<64, 64, 32, false>(p, s, alg_k) : launch_ldsd<128, 64, 64, false>(p, s, alg_k);
   }
   switch (variant) {
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
