@@ -102,12 +102,7 @@ template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 3 : 2, (VARIANT & 4) ? 3 : 2))) void conv_nhwc_f32_mfma(ConvParams p) {
   constexpr bool SBUF = (VARIANT & 4) != 0;
   constexpr int NBUF = SBUF ? 1 : 2;
-  // bit 10: global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write).  The instruction writes lane l's 16 bytes
-  // at M0 + 16*l, so tile rows are UNPADDED (32 floats) and bank conflicts are avoided by an XOR swizzle instead: the 16-byte
-  // column c of row r is stored at column c ^ (r & 7), applied on the global side (lane (r, c) fetches column c ^ (r & 7)).
-  constexpr bool LDSD = (VARIANT & 1024) != 0;
-  constexpr int LDT = LDSD ? BK : LDS_LD;
-  static_assert(!(LDSD && SBUF), "LDS-direct staging uses both buffers");
+  constexpr int LDT = LDS_LD;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
@@ -159,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     row_off[r] = off;
   }
 
-  const int a_col = LDSD ? (((tid & 7) ^ ((tid >> 3) & 7)) * 4) : a_c4 * 4;  // this thread's (swizzled) float offset in a chunk row
+  const int a_col = a_c4 * 4;  // this thread's float offset in a chunk row
   const float* b_ptr = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;
   const int row_stride = p.Wp * p.C;  // floats between successive kh rows
 
@@ -236,30 +231,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   } else if constexpr (RAGGED) {
     while (j >= p.run) { j -= p.run; aoff += row_stride - p.run; }
   }
-#define MP_GPTR(P) ((const void __attribute__((address_space(1)))*)(P))
-#define MP_LPTR(P) ((void __attribute__((address_space(3)))*)(P))
-#define MP_CONV_LOAD_LDS(BUF, AOFF, BP)                                                                         \
-  {                                                                                                             \
-    float* as_d = As + (BUF) * BM * LDT + (wave * 8) * LDT; /* wave-uniform: lanes land at +16 B * lane */      \
-    float* bs_d = Bs + (BUF) * BN * LDT + (wave * 8) * LDT;                                                     \
-    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr0 + (AOFF)), MP_LPTR(as_d), 16, 0, 0);                        \
-    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr1 + (AOFF)), MP_LPTR(as_d + 32 * LDT), 16, 0, 0);             \
-    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr2 + (AOFF)), MP_LPTR(as_d + 64 * LDT), 16, 0, 0);             \
-    __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr3 + (AOFF)), MP_LPTR(as_d + 96 * LDT), 16, 0, 0);             \
-    __builtin_amdgcn_global_load_lds(MP_GPTR(BP), MP_LPTR(bs_d), 16, 0, 0);                                     \
-    __builtin_amdgcn_global_load_lds(MP_GPTR((BP) + 1024), MP_LPTR(bs_d + 32 * LDT), 16, 0, 0);                 \
-    if constexpr (B_LD4 > 2) {                                                                                  \
-      __builtin_amdgcn_global_load_lds(MP_GPTR((BP) + 2048), MP_LPTR(bs_d + 64 * LDT), 16, 0, 0);               \
-      __builtin_amdgcn_global_load_lds(MP_GPTR((BP) + 3072), MP_LPTR(bs_d + 96 * LDT), 16, 0, 0);               \
-    }                                                                                                           \
-  }
-  if constexpr (LDSD) {
-    MP_CONV_LOAD_LDS(0, aoff, bp)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    MP_CONV_LOAD(aoff, bp)
-    MP_CONV_STORE(0)
-  }
+  MP_CONV_LOAD(aoff, bp)
+  MP_CONV_STORE(0)
   __syncthreads();
 
   const int frag_row = lane & 31;
@@ -267,7 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   const int row_wrap = row_stride - p.run;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int buf = SBUF ? 0 : ((chunk - c_begin) & 1);
-    if (chunk + 1 < c_end && (VARIANT & 128) == 0) {  // advance to the next chunk; the loads themselves are unconditional
+    if (chunk + 1 < c_end) {  // advance to the next chunk; the loads themselves are unconditional
       bp += BN * BK;
       aoff += BK;
       if constexpr (RAGGED) {
@@ -284,17 +257,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         }
       }
     }
-    if constexpr (LDSD) {
-      MP_CONV_LOAD_LDS(buf ^ 1, aoff, bp)  // straight into the buffer every wave finished reading at the last barrier
-    } else if constexpr ((VARIANT & 16) == 0) {  // (bits 4..6 are timing experiments only: wrong results)
+    if constexpr ((VARIANT & 16) == 0) {  // (bits 4..6 are timing experiments only: wrong results)
       MP_CONV_LOAD(aoff, bp)
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
-    const float* as = As + buf * BM * LDT + (LDSD ? 0 : (wm * WM + frag_row) * LDT + frag_k);
-    const float* bs = Bs + buf * BN * LDT + (LDSD ? 0 : (wn * WN + frag_row) * LDT + frag_k);
-    // LDS-direct layout: 16-byte column (2*kk + lane/32) of row R sits at column ^ (R & 7); (R + 32*i) & 7 == R & 7
-    const int swz = ((lane >> 5) ^ (frag_row & 7)) * 4;
-    const int a_idx = (wm * WM + frag_row) * BK + swz, b_idx = (wn * WN + frag_row) * BK + swz;
+    const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
+    const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
@@ -303,11 +271,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         for (int i = 0; i < TM; ++i) af[i] = a0;
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = b0;
-      } else if constexpr (LDSD) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + ((a_idx ^ (kk * 8)) + i * 32 * BK));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + ((b_idx ^ (kk * 8)) + j * 32 * BK));
       } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT + kk * 8);
@@ -316,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       }
       if constexpr ((VARIANT & 1) != 0) {
         constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
-        if (kk == STORE_KK && (VARIANT & 16) == 0 && !LDSD) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
+        if (kk == STORE_KK && (VARIANT & 16) == 0) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
           __builtin_amdgcn_sched_barrier(0);
           MP_CONV_STORE(buf ^ 1)
           __builtin_amdgcn_sched_barrier(0);
@@ -340,9 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
           }
       }
     }
-    if constexpr (LDSD) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next chunk has landed in LDS
-    } else if constexpr (SBUF) {
+    if constexpr (SBUF) {
       __syncthreads();  // every wave is done reading this chunk
       MP_CONV_STORE(0)
     } else if constexpr ((VARIANT & 1) == 0) {
@@ -352,9 +313,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     if constexpr ((VARIANT & 32) == 0) __syncthreads();
   }
 #undef MP_CONV_LOAD
-#undef MP_CONV_LOAD_LDS
-#undef MP_GPTR
-#undef MP_LPTR
 #undef MP_CONV_STORE
 #undef MP_LD4
 #undef MP_ST4
@@ -661,7 +619,7 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   q.n_mblocks = ceil_div(p.M, BM);
   q.n_nblocks = ceil_div(p.Cout, BN);
   constexpr int NBUF = (VARIANT & 4) ? 1 : 2;
-  constexpr int LDT = (VARIANT & 1024) ? BK : LDS_LD;
+  constexpr int LDT = LDS_LD;
   const size_t lds = (size_t)(NBUF * BM * LDT + NBUF * BN * LDT) * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
