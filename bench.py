@@ -105,6 +105,11 @@ def extras(est, obs, det, steps: int) -> dict:
         dt = timed(k)
         out[f"n_pose_hypotheses={k}"] = {"ms_per_call": dt * 1e3, "coarse_hypotheses_per_s": N_HYP / dt,
                                          "note": "576 coarse rows + K x 5 refine rows + K score rows (megapose-1.0-RGB[-multi-hypothesis] defaults)"}
+    est.n_streams = 3  # chunk interleave on 3 HIP streams: fills the tails of the conv grids and overlaps raster with MFMA work; not the
+    dt = timed(N_HYP)  # default because overlapping kernels distort the per-kernel event timing the roofline figures rest on
+    est.n_streams = 1
+    out["three_stream_interleave"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
+                                      "note": "same fp32 path, PoseEstimator.n_streams=3 (MP_N_STREAMS); not used for `value`"}
     for prec in (9, 6):
         for m in (est.coarse_model, est.refiner_model):
             m.conv_precision = prec
