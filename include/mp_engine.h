@@ -119,8 +119,11 @@ int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh_ids, const
                           int h, int w, uint32_t flags, const mp_lights* lights, float* d_out, int64_t stride_v,
                           int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb,
                           int c_normals, int c_depth, void* d_workspace, size_t workspace_bytes,
-                          const float* d_images /*[n_im,C,H,W]*/, int n_im, int C, int H, int W, const int32_t* d_im_ids,
-                          const float* d_boxes, int c0_crop, mp_stream stream);
+                          const float* d_images /*[n_im,C,H,W], or [n_im,H,W,4] if images_nhwc4*/, int images_nhwc4, int n_im,
+                          int C, int H, int W, const int32_t* d_im_ids, const float* d_boxes, int c0_crop, mp_stream stream);
+/* observation frames [n_im,C,H,W] (C = 3 | 4) -> [n_im,H,W,4] (4th channel 0 for RGB): one 16-byte load per roi_align tap in the
+ * fused crop; done once per observation, not per step */
+int mp_pack_observation_nhwc4(const float* d_images, int n_im, int C, int H, int W, float* d_out, mp_stream stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Crop: replaces lib3d/cropping.py:113-144 crop_images (torchvision.ops.roi_align,       */

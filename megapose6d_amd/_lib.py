@@ -81,7 +81,8 @@ SIGNATURES = {
     "mp_raster_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
                               _vp, _sz, _vp]),
     "mp_raster_render_crop": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
-                                   _vp, _sz, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+                                   _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mp_pack_observation_nhwc4": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mp_crop_roi_align": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _i, _vp]),
     "mp_normalize_depth": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),
     "mp_conv_packed_floats": (_sz, [_i, _i, _i, _i]),

@@ -32,6 +32,18 @@ __global__ __launch_bounds__(256) void crop_roi_align_kernel(const float* __rest
                 out + (size_t)row * stride_b + (size_t)py * stride_y + (size_t)px * stride_x + c0);
 }
 
+// [n_im][C][H][W] -> [n_im][H][W][4] (channel 3 = 0 for RGB): the layout the fused crop role of the rasteriser reads
+__global__ void pack_nhwc4_kernel(const float* __restrict__ in, int C, int HW, float4* __restrict__ out) {
+  const int im = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HW) return;
+  const float* p = in + (size_t)im * C * HW + i;
+  float4 v;
+  v.x = p[0]; v.y = p[HW]; v.z = p[2 * (size_t)HW];
+  v.w = C == 4 ? p[3 * (size_t)HW] : 0.f;
+  out[(size_t)im * HW + i] = v;
+}
+
 __global__ void normalize_depth_kernel(float* __restrict__ x, int h, int w, int border, int C, int ch,
                                        const float* __restrict__ tCR, int mode) {
   const int row = blockIdx.y;
@@ -81,6 +93,15 @@ extern "C" int mp_normalize_depth(float* d_x, int b, int h, int w, int border, i
   for (int i = 0; i < n_ch; ++i)
     hipLaunchKernelGGL(normalize_depth_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_x, h, w, border, C, h_channels[i],
                        d_tCR, mode);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}
+
+extern "C" int mp_pack_observation_nhwc4(const float* d_images, int n_im, int C, int H, int W, float* d_out, mp_stream stream) {
+  MP_REQUIRE(d_images && d_out && n_im > 0 && (C == 3 || C == 4) && H > 0 && W > 0, "mp_pack_observation_nhwc4: bad arguments");
+  ProfScope prof("pack_observation_nhwc4", 0.0, (double)n_im * H * W * (C + 4) * 4.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(pack_nhwc4_kernel, dim3(ceil_div((long)H * W, 256L), n_im), dim3(256), 0, (hipStream_t)stream, d_images, C, H * W,
+                     (float4*)d_out);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

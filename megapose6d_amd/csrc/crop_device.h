@@ -32,8 +32,22 @@ __device__ __forceinline__ Tap make_tap(float c, int size) {
   return t;
 }
 
-// one output pixel (px, py) of the roi [x1, y1, x1 + out_w * bin_w, y1 + out_h * bin_h] of `img` ([C][H][W]); writes C floats to o
-template <int C>
+// source pixel o = y * W + x of an image stored [C][H][W] (NHWC4 = false) or [H][W][4] (true: one 16-byte load per tap instead of C
+// 4-byte loads -- the fused crop role is bound by the number of vector-memory instructions)
+template <int C, bool NHWC4>
+__device__ __forceinline__ void crop_fetch(const float* __restrict__ img, size_t plane, size_t o, float (&v)[C]) {
+  if constexpr (NHWC4) {
+    const float4 t = reinterpret_cast<const float4*>(img)[o];
+    v[0] = t.x; v[1] = t.y; v[2] = t.z;
+    if constexpr (C == 4) v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = img[c * plane + o];
+  }
+}
+
+// one output pixel (px, py) of the roi [x1, y1, x1 + out_w * bin_w, y1 + out_h * bin_h] of `img`; writes C floats to o
+template <int C, bool NHWC4 = false>
 __device__ __forceinline__ void crop_pixel(const float* __restrict__ img, int H, int W, float x1, float y1, float bin_w, float bin_h,
                                            int px, int py, float* __restrict__ o) {
   const size_t plane = (size_t)H * W;
@@ -74,9 +88,11 @@ __device__ __forceinline__ void crop_pixel(const float* __restrict__ img, int H,
       for (int cc = 0; cc < P; ++cc) {
         const float wgt = wy[r] * wx[cc];
         const size_t o = (size_t)rr * W + min(c0p + cc, W - 1);
+        float vv[C];
+        crop_fetch<C, NHWC4>(img, plane, o, vv);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const float v = img[c * plane + o];
+          const float v = vv[c];
           acc[c] = fmaf(wgt, v, acc[c]);
           if (C == 4 && c == 3) acc_valid = fmaf(wgt, v > 0.f ? 1.f : 0.f, acc_valid);
         }
@@ -91,10 +107,14 @@ __device__ __forceinline__ void crop_pixel(const float* __restrict__ img, int H,
         const float w1 = ty[iy].h * tx[ix].h, w2 = ty[iy].h * tx[ix].l, w3 = ty[iy].l * tx[ix].h, w4 = ty[iy].l * tx[ix].l;
         const size_t o1 = (size_t)ty[iy].lo * W + tx[ix].lo, o2 = (size_t)ty[iy].lo * W + tx[ix].hi;
         const size_t o3 = (size_t)ty[iy].hi * W + tx[ix].lo, o4 = (size_t)ty[iy].hi * W + tx[ix].hi;
+        float q1[C], q2[C], q3[C], q4[C];
+        crop_fetch<C, NHWC4>(img, plane, o1, q1);
+        crop_fetch<C, NHWC4>(img, plane, o2, q2);
+        crop_fetch<C, NHWC4>(img, plane, o3, q3);
+        crop_fetch<C, NHWC4>(img, plane, o4, q4);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const float* p = img + c * plane;
-          const float v1 = p[o1], v2 = p[o2], v3 = p[o3], v4 = p[o4];
+          const float v1 = q1[c], v2 = q2[c], v3 = q3[c], v4 = q4[c];
           acc[c] += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
           if (C == 4 && c == 3) {
             const float m1 = v1 > 0.f ? 1.f : 0.f, m2 = v2 > 0.f ? 1.f : 0.f, m3 = v3 > 0.f ? 1.f : 0.f,

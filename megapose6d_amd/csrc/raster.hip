@@ -75,10 +75,10 @@ struct VtxRec {
 // optional fused crop role (one extra workgroup per (item, band)): roi_align of the observation into channels c0.. of the same
 // pixel lines the views write, so that the XCD's L2 merges all slices of a line (see the work-to-workgroup map in raster_bands)
 struct CropArgs {
-  const float* images;     // [n_im][C][H][W], NULL = no crop role
+  const float* images;     // [n_im][C][H][W], or [n_im][H][W][4] when nhwc4; NULL = no crop role
   const int32_t* im_ids;   // [n_items]
   const float* boxes;      // [n_items][4]
-  int C, H, W, c0;
+  int C, H, W, c0, nhwc4;
 };
 
 struct LightsDev {
@@ -316,13 +316,18 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
     const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
     const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
-    const float* img = crop.images + (size_t)crop.im_ids[item] * crop.C * crop.H * crop.W;
+    const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
     float* o_item = out + (size_t)item * stride_v + crop.c0;
     for (int i = threadIdx.x; i < (yl - y0 + 1) * w; i += BAND_THREADS) {
       const int py = y0 + i / w, px = i % w;
       float* o = o_item + (size_t)py * stride_y + (size_t)px * stride_x;
-      if (crop.C == 4) crop_pixel<4>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
-      else crop_pixel<3>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+      if (crop.nhwc4) {
+        if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+        else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+      } else {
+        if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+        else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+      }
     }
     return;
   }
@@ -705,13 +710,13 @@ extern "C" int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh
                                      int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
                                      int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
                                      int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes,
-                                     const float* d_images, int n_im, int C, int H, int W, const int32_t* d_im_ids,
-                                     const float* d_boxes, int c0_crop, mp_stream stream) {
+                                     const float* d_images, int images_nhwc4, int n_im, int C, int H, int W,
+                                     const int32_t* d_im_ids, const float* d_boxes, int c0_crop, mp_stream stream) {
   MP_REQUIRE(d_images && d_im_ids && d_boxes && n_im > 0 && (C == 3 || C == 4) && H > 0 && W > 0 && c0_crop >= 0,
              "mp_raster_render_crop: bad crop arguments");
   CropArgs crop;
   crop.images = d_images; crop.im_ids = d_im_ids; crop.boxes = d_boxes;
-  crop.C = C; crop.H = H; crop.W = W; crop.c0 = c0_crop;
+  crop.C = C; crop.H = H; crop.W = W; crop.c0 = c0_crop; crop.nhwc4 = images_nhwc4 ? 1 : 0;
   return raster_render_impl(db, d_mesh_ids, d_TCO, d_K, n_views, h, w, flags, lights, d_out, stride_v, views_per_item, stride_view, stride_y,
                             stride_x, c_rgb, c_normals, c_depth, d_ws, ws_bytes, stream, crop);
 }

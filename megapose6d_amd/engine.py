@@ -144,6 +144,16 @@ def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()) -> Ligh
     return L
 
 
+class PackedObservation:
+    """Observation frames repacked [n_im,H,W,4] on the device (mp_pack_observation_nhwc4) for the fused crop of raster_render."""
+
+    def __init__(self, images: torch.Tensor):
+        images = _dev_f32(images)
+        self.n_im, self.C, self.H, self.W = (int(v) for v in images.shape)
+        self.data = torch.empty(self.n_im, self.H, self.W, 4, dtype=torch.float32, device=images.device)
+        check(_lib.load().mp_pack_observation_nhwc4(images.data_ptr(), self.n_im, self.C, self.H, self.W, self.data.data_ptr(), _stream()))
+
+
 def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, h: int, w: int, flags: int,
                   lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
                   c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0, slot: int = 0,
@@ -160,13 +170,17 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     ws = db.workspace(n, out.device, slot)
     if crop is not None:
         images, im_ids, boxes, c0 = crop
-        images = _dev_f32(images)
-        n_im, Cc, H, W = images.shape
+        if isinstance(images, PackedObservation):
+            nhwc4, n_im, Cc, H, W, images = 1, images.n_im, images.C, images.H, images.W, images.data
+        else:
+            images = _dev_f32(images)
+            nhwc4 = 0
+            n_im, Cc, H, W = images.shape
         im_ids, boxes = _dev_i32(im_ids), _dev_f32(boxes)
         assert boxes.shape[0] * views_per_item == n and im_ids.shape[0] == boxes.shape[0]
         check(lib.mp_raster_render_crop(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
                                         out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x,
-                                        c_rgb, c_normals, c_depth, ws.data_ptr(), ws.numel(), images.data_ptr(), n_im, Cc, H, W,
+                                        c_rgb, c_normals, c_depth, ws.data_ptr(), ws.numel(), images.data_ptr(), nhwc4, n_im, Cc, H, W,
                                         im_ids.data_ptr(), boxes.data_ptr(), c0, _stream()))
         return
     check(lib.mp_raster_render(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),

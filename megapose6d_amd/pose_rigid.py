@@ -196,6 +196,15 @@ class PosePredictor(nn.Module):
         h, w = self.render_size
         return eng.padded_view(self._x[slot], self._x_rows[slot], h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
 
+    def _packed(self, images: torch.Tensor) -> "eng.PackedObservation":
+        """[n_im,C,H,W] frames -> NHWC4 copy for the fused crop, cached while the same (unmodified) tensor keeps coming in"""
+        key = (images.untyped_storage().data_ptr(), images.storage_offset(), tuple(images.shape), tuple(images.stride()), images._version,
+               images.device)  # a fresh `images[:, :3]` view of the same frame maps to the same key
+        if getattr(self, "_packed_key", None) != key:
+            self._packed_obs = eng.PackedObservation(images)
+            self._packed_key = key
+        return self._packed_obs
+
     # -- the fused step ------------------------------------------------------------------------------------------
     def _step(self, images: torch.Tensor, im_ids: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO_in: torch.Tensor,
               want_sigmoid: bool, slot: int = 0):
@@ -219,7 +228,7 @@ class PosePredictor(nn.Module):
         self.renderer.render_into(view_ids, TCV_O.view(b * V, 4, 4), KV_crop.view(b * V, 3, 3), self._lights(), (h, w), x, s_row,
                                   s_y, s_x, nin, nin + 3 if self.render_normals else -1,
                                   nin + (6 if self.render_normals else 3) if self.render_depth else -1, off,
-                                  views_per_item=V, stride_view=nper, slot=slot, crop=(images, im_ids, boxes_crop, 0))
+                                  views_per_item=V, stride_view=nper, slot=slot, crop=(self._packed(images), im_ids, boxes_crop, 0))
         render_time = time.time() - t0
         mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
         bb = self._backbone_engine()

@@ -432,3 +432,8 @@ def test_fused_crop_in_raster_launch_equals_standalone_crop(eng, engine_meshes, 
         outs.append(x)
     assert torch.equal(outs[0], outs[1])
     assert (outs[1][..., :nin] != -3.0).all() and (outs[1][..., nin + 6 * V:] == -3.0).all()   # crop written, padding untouched
+    # NHWC4-packed observation (what the pipeline passes): same values
+    x = torch.full((n_items, h, w, Cp), -3.0, device="cuda")
+    eng.raster_render(db, ids, T, K, h, w, 1, eng.make_lights(), x, h * w * Cp, w * Cp, Cp, nin, nin + 3, -1, views_per_item=V,
+                      stride_view=6, crop=(eng.PackedObservation(images), im_ids, boxes, 0))
+    assert torch.equal(x, outs[0])
