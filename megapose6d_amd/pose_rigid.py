@@ -203,6 +203,7 @@ class PosePredictor(nn.Module):
         if getattr(self, "_packed_key", None) != key:
             self._packed_obs = eng.PackedObservation(images)
             self._packed_key = key
+            self._packed_src = images  # keeps the storage alive: a freed frame's address could otherwise be reused by a new frame
         return self._packed_obs
 
     # -- the fused step ------------------------------------------------------------------------------------------
