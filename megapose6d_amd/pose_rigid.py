@@ -204,6 +204,10 @@ class PosePredictor(nn.Module):
             self._packed_obs = eng.PackedObservation(images)
             self._packed_key = key
             self._packed_src = images  # keeps the storage alive: a freed frame's address could otherwise be reused by a new frame
+            self._packed_event = torch.cuda.Event()
+            self._packed_event.record()
+        else:
+            torch.cuda.current_stream().wait_event(self._packed_event)  # another slot's stream may have done the packing
         return self._packed_obs
 
     # -- the fused step ------------------------------------------------------------------------------------------
