@@ -533,6 +533,179 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
   }
 }
+// s_waitcnt vmcnt(6) (expcnt / lgkmcnt untouched) + s_barrier as builtins, so that the compiler's own wait-count bookkeeping sees them
+// (an inline-asm wait is opaque to it and it re-inserts vmcnt(0) at the loop header); the empty asms are compiler-only memory fences
+#define MP_WAIT6_BARRIER()                     \
+  do {                                         \
+    asm volatile("" ::: "memory");             \
+    __builtin_amdgcn_s_waitcnt(0x0F76);        \
+    __builtin_amdgcn_s_barrier();              \
+    asm volatile("" ::: "memory");             \
+  } while (0)
+
+// 256 x 128 tile, 8 waves (4 x 2, each 64 x 64), THREE LDS-direct stages (prefetch distance 2 chunks, 145 KB LDS, one workgroup per
+// CU = 2 waves per SIMD as before) and 25 % fewer loads per MFMA than the 128 x 128 tile.  Cout >= 128, chunk-aligned K only.
+template <int TM, int TN>
+__device__ __forceinline__ void ldsd256_chunk(const float* __restrict__ a_rd, const float* __restrict__ b_rd, float* __restrict__ a_wr,
+                                              float* __restrict__ b_wr, const float* ga0, const float* ga1, const float* ga2,
+                                              const float* ga3, const float* gb, int a_idx, int b_idx, f32x16 (&acc)[TM][TN]) {
+  __builtin_amdgcn_global_load_lds(MP_GPTR(ga0), MP_LPTR(a_wr), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(ga1), MP_LPTR(a_wr + 64 * BK), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(ga2), MP_LPTR(a_wr + 128 * BK), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(ga3), MP_LPTR(a_wr + 192 * BK), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(gb), MP_LPTR(b_wr), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 2048), MP_LPTR(b_wr + 64 * BK), 16, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < BK / 8; ++kk) {
+    float4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_rd + ((a_idx ^ (kk * 8)) + i * 32 * BK));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_rd + ((b_idx ^ (kk * 8)) + j * 32 * BK));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma_ldsd256(ConvParams p) {
+  constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
+  __shared__ __attribute__((aligned(16))) float As0[BM * BK];
+  __shared__ __attribute__((aligned(16))) float As1[BM * BK];
+  __shared__ __attribute__((aligned(16))) float As2[BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
+  __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
+  __shared__ __attribute__((aligned(16))) float Bs2[BN * BK];
+  __shared__ int row_off[BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;      // 0..7
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int nblk = lb % p.n_nblocks;
+  const int mblk = lb / p.n_nblocks;
+  const int m0 = mblk * BM;
+  const int n0 = nblk * BN;
+
+  const int a_r0 = tid >> 3;                              // 0..63 (+64 i)
+  const int a_col = ((tid & 7) ^ ((tid >> 3) & 7)) * 4;   // swizzled float offset inside the 32-float chunk row
+  const float* a_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + a_r0 + 64 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int wo = m % p.Wo;
+    const int t = m / p.Wo;
+    const int ho = t % p.Ho;
+    const int n = t / p.Ho;
+    const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
+    a_ptr[i] = p.x + pix * p.C;
+  }
+  for (int r = tid; r < BM; r += 512) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < p.M) {
+      const int wo = m % p.Wo;
+      const int t = m / p.Wo;
+      const int ho = t % p.Ho;
+      const int n = t / p.Ho;
+      off = (((n * p.Hop) + ho + p.out_border) * p.Wop + wo + p.out_border) * p.Cout;
+    }
+    row_off[r] = off;
+  }
+  const float* bp = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;  // rows tid>>3 (+64): +2048 floats
+  const int row_stride = p.Wp * p.C;
+  const int row_wrap = row_stride - p.run;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int aoff = a_col, ju = 0;
+  float* aw0 = As0 + wave * 8 * BK;
+  float* aw1 = As1 + wave * 8 * BK;
+  float* aw2 = As2 + wave * 8 * BK;
+  float* bw0 = Bs0 + wave * 8 * BK;
+  float* bw1 = Bs1 + wave * 8 * BK;
+  float* bw2 = Bs2 + wave * 8 * BK;
+#define MP_LDSD_ADVANCE()                           \
+  if (loaded + 1 < p.n_chunks) {                    \
+    ++loaded;                                       \
+    bp += BN * BK;                                  \
+    aoff += BK;                                     \
+    ju += BK;                                       \
+    if (ju == p.run) { ju = 0; aoff += row_wrap; }  \
+  }
+#define MP_LDSD_ISSUE(AW, BW)                                                                     \
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[0] + aoff), MP_LPTR(AW), 16, 0, 0);              \
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[1] + aoff), MP_LPTR(AW + 64 * BK), 16, 0, 0);    \
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[2] + aoff), MP_LPTR(AW + 128 * BK), 16, 0, 0);   \
+  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[3] + aoff), MP_LPTR(AW + 192 * BK), 16, 0, 0);   \
+  __builtin_amdgcn_global_load_lds(MP_GPTR(bp), MP_LPTR(BW), 16, 0, 0);                           \
+  __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 2048), MP_LPTR(BW + 64 * BK), 16, 0, 0);
+  int loaded = 0;  // index of the chunk the (aoff, bp) cursor points at; past the end it harmlessly re-loads the last chunk
+  MP_LDSD_ISSUE(aw0, bw0)
+  MP_LDSD_ADVANCE()
+  MP_LDSD_ISSUE(aw1, bw1)
+  // (not __syncthreads(): its release fence would wait for ALL vector-memory operations, i.e. also for the chunk just issued)
+  MP_WAIT6_BARRIER();  // chunk 0 has landed everywhere; chunk 1 may still be in flight
+
+  const int frag_row = lane & 31;
+  const int swz = ((lane >> 5) ^ (frag_row & 7)) * 4;
+  const int a_idx = (wm * 64 + frag_row) * BK + swz, b_idx = (wn * 64 + frag_row) * BK + swz;
+#define MP_LDSD_STEP(ARD, BRD, AWR, BWR)                                                                                              \
+  MP_LDSD_ADVANCE()                                                                                                                   \
+  ldsd256_chunk<TM, TN>(ARD, BRD, AWR, BWR, a_ptr[0] + aoff, a_ptr[1] + aoff, a_ptr[2] + aoff, a_ptr[3] + aoff, bp, a_idx, b_idx, acc); \
+  MP_WAIT6_BARRIER(); /* next chunk landed in every wave; the newest may be in flight */     \
+
+  for (int chunk = 0; chunk < p.n_chunks; chunk += 3) {
+    MP_LDSD_STEP(As0, Bs0, aw2, bw2)   // consume stage 0 (chunk), prefetch chunk + 2 into stage 2
+    if (chunk + 1 >= p.n_chunks) break;
+    MP_LDSD_STEP(As1, Bs1, aw0, bw0)
+    if (chunk + 2 >= p.n_chunks) break;
+    MP_LDSD_STEP(As2, Bs2, aw1, bw1)
+  }
+#undef MP_LDSD_STEP
+#undef MP_LDSD_ISSUE
+#undef MP_LDSD_ADVANCE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int erow0 = wm * 64 + (lane >> 5) * 4, en0 = n0 + wn * 64 + (lane & 31);
+  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
+  switch (emode) {
+    case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
+    case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
+    case 2: conv_epilogue<TM, TN, false, true, false>(p, acc, row_off, erow0, en0); break;
+    case 3: conv_epilogue<TM, TN, true, true, false>(p, acc, row_off, erow0, en0); break;
+    case 4: conv_epilogue<TM, TN, false, false, true>(p, acc, row_off, erow0, en0); break;
+    case 5: conv_epilogue<TM, TN, true, false, true>(p, acc, row_off, erow0, en0); break;
+    case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
+    default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
+  }
+}
+
+static int launch_ldsd256(const ConvParams& p, hipStream_t s, double alg_k) {
+  ConvParams q = p;
+  q.n_mblocks = ceil_div(p.M, 256);
+  q.n_nblocks = ceil_div(p.Cout, 128);
+  ProfScope prof("conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * (double)p.M * p.Cout * alg_k,
+                 4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
+  hipLaunchKernelGGL(conv_nhwc_f32_mfma_ldsd256, dim3(q.n_mblocks * q.n_nblocks), dim3(512), 0, s, q);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}
 #undef MP_GPTR
 #undef MP_LPTR
 
@@ -795,6 +968,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     if (ldsd & 4) return small ? launch_ldsd<64, 64, 32, true>(p, s, alg_k) : launch_ldsd<128, 64, 64, true>(p, s, alg_k);
     return small ? launch<128, 64, 64, 32, 257, true>(p, s, alg_k) : launch<128, 128, 64, 64, 257, true>(p, s, alg_k);
   }
+  if ((ldsd & 16) && !small && p.run % BK == 0) return launch_ldsd256(p, s, alg_k);
   if (small ? (ldsd & 2) : (ldsd & 1)) {
     if (ldsd & 8) return small ? launch_ldsd<64, 64, 32, false, 1>(p, s, alg_k) : launch_ldsd<128, 64, 64, false, 1>(p, s, alg_k);
     return small ? launch_ldsd<64, 64, 32, false>(p, s, alg_k) : launch_ldsd<128, 64, 64, false>(p, s, alg_k);
