@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import time
 from collections import defaultdict
+from types import SimpleNamespace
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -141,6 +142,14 @@ class PosePredictor(nn.Module):
             raise ValueError(f"backbone has {backbone.n_inputs} input channels, configuration needs {n_in}")
         self.debug = False
         self.timing_dict: Dict[str, float] = defaultdict(float)
+        # channel index helpers of the reference (models/pose_rigid.py:132-158) + its debug container (:69-78, filled when debug=True)
+        self._input_rgb_dims = [0, 1, 2]
+        self._input_depth_dims = [3] if input_depth else []
+        self._render_rgb_dims = [0, 1, 2]
+        self._render_normal_dims = [3, 4, 5] if render_normals else []
+        self._render_depth_dims = [3 + len(self._render_normal_dims)] if render_depth else []
+        self.debug_data = SimpleNamespace(output=None, images=None, origin_uv=None, ref_point_uv=None, origin_uv_crop=None,
+                                          pose_predictor_outputs=None)
         self._engine_bb: Optional[eng.Backbone] = None
         self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
         self._x_rows: Dict[int, int] = {}
@@ -361,6 +370,68 @@ class PosePredictor(nn.Module):
         out = torch.empty(bsz, h, w, C, dtype=torch.float32, device=TCO.device)
         eng.crop_roi_align(images, torch.arange(bsz, dtype=torch.int32, device=TCO.device), bcrop, h, w, out, h * w * C, w * C, C, 0)
         return out.permute(0, 3, 1, 2), KV[:, 0], brend, bcrop
+
+    @property
+    def input_rgb_dims(self) -> List[int]:
+        return self._input_rgb_dims
+
+    @property
+    def input_depth_dims(self) -> List[int]:
+        return self._input_depth_dims
+
+    @property
+    def render_rgb_dims(self) -> List[int]:
+        return self._render_rgb_dims
+
+    @property
+    def render_depth_dims(self) -> List[int]:
+        return self._render_depth_dims
+
+    @torch.no_grad()
+    def compute_crops_multiview(self, images: torch.Tensor, K: torch.Tensor, TCV_O: torch.Tensor, tCR: torch.Tensor,
+                                labels: List[str]) -> torch.Tensor:
+        """pose_rigid.py:249-303 -> K_crop [bsz, n_views, 3, 3] of the virtual cameras (200 sampled points per view).  On the hot path
+        this is part of pose_prepare; the stand-alone call requires tCR == translation of TCV_O, which is how the reference calls it."""
+        bsz, n_views = TCV_O.shape[:2]
+        assert tCR.shape == (bsz, n_views, 3) and TCV_O.shape == (bsz, n_views, 4, 4) and K.shape == (bsz, 3, 3)
+        if (tCR - TCV_O[..., :3, 3]).abs().max().item() > 1e-6:
+            raise NotImplementedError("compute_crops_multiview: anchor points other than the views' translations")
+        pts_ids, _ = self._ids([l for l in labels for _ in range(n_views)], TCV_O.device)
+        _, _, _, KV, _, _ = eng.pose_prepare(TCV_O.flatten(0, 1), K.unsqueeze(1).repeat(1, n_views, 1, 1).flatten(0, 1), pts_ids,
+                                             self.mesh_db.sampled_points(2000), 200, 200, 1, 0, tuple(images.shape[-2:]), self.render_size, 1.4)
+        return KV[:, 0].reshape(bsz, n_views, 3, 3)
+
+    @torch.no_grad()
+    def normalize_depth(self, depth: torch.Tensor, tCR: torch.Tensor) -> torch.Tensor:
+        """pose_rigid.py:466-496: depth [B, ..., H, W] normalised by the anchor depth tCR[:, 2]; returns a new tensor"""
+        mode_name = self.depth_normalization_type
+        if mode_name == "tCR_center_obj_diam":
+            raise NotImplementedError("Not yet implemented")
+        if mode_name not in eng.DEPTH_NORM_MODES:
+            raise ValueError(f"Unknown depth_normalization_type = {mode_name}")
+        out = depth.detach().to(dtype=torch.float32).contiguous().clone()
+        mode = eng.DEPTH_NORM_MODES[mode_name]
+        if mode and out.numel():
+            B, H, W = out.shape[0], out.shape[-2], out.shape[-1]
+            k = out.numel() // (B * H * W)
+            eng.normalize_depth(out, B * k, H, W, 0, 1, [0], tCR.to(out.device, torch.float32).repeat_interleave(k, dim=0), mode)
+        return out
+
+    @torch.no_grad()
+    def normalize_images(self, images: torch.Tensor, renders: torch.Tensor, tCR: torch.Tensor, images_inplace: bool = False,
+                         renders_inplace: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """pose_rigid.py:410-464 (the hot path normalises in place inside the CNN input buffer instead)"""
+        if not images_inplace:
+            images = images.clone()
+        if not renders_inplace:
+            renders = renders.clone()
+        if self.input_depth:
+            assert images.shape[1] == 4, "images must have C=4 channels if input_depth=True"
+            images[:, self._input_depth_dims] = self.normalize_depth(images[:, self._input_depth_dims], tCR)
+        if self.render_depth:
+            dims = [self._render_depth_dims[0] + self._n_single_render_channels * v for v in range(self.n_rendered_views)]
+            renders[:, dims] = self.normalize_depth(renders[:, dims], tCR)
+        return images, renders
 
     @torch.no_grad()
     def update_pose(self, TCO: torch.Tensor, K_crop: torch.Tensor, pose_outputs: torch.Tensor, tCR: torch.Tensor) -> torch.Tensor:
