@@ -10,18 +10,20 @@
 //     differences of the back-projected measured points),
 //   * data association is PROJECTIVE (transform the source point, project it with K, take the target pixel it lands on)
 //     instead of OpenCV's kd-tree search -- fully parallel, no host involvement,
-//   * each iteration accumulates the 6x6 point-to-plane normal equations per object with block reductions + atomics and a
-//     one-thread Cholesky solve updates the increment; levels subsample the mask pixels (stride 8,4,2,1) and tighten the
+//   * each iteration accumulates the 6x6 point-to-plane normal equations per object with block reductions into per-block partial
+//     slots that the one-thread Cholesky solve adds up in a fixed order (no float atomics: results are bit-reproducible); levels subsample the mask pixels (stride 8,4,2,1) and tighten the
 //     rejection distance (0.20, 0.15, 0.10, 0.05 m).
 // The CPU oracle of THIS algorithm is oracle/icp.py.  Roofline: latency-bound (200 tiny launches), negligible next to the CNN.
 #include "common.h"
 
 namespace mp {
 
+constexpr int ICP_ACC_BLOCKS = 16, ICP_STAT_BLOCKS = 32;
+
 struct IcpRow {        // per object state, device resident
   float T[12];         // current increment [R|t] (row-major 3x4) applied to camera-frame source points
-  float acc[29];       // 21 upper-triangular JtJ, 6 Jtr, sum r^2, inlier count
-  float stats[8];      // n_mask, (unused), centroid_tgt xyz, centroid_src xyz
+  float acc_part[ICP_ACC_BLOCKS][29];   // per-block partials of: 21 upper-triangular JtJ, 6 Jtr, sum r^2, inlier count
+  float stat_part[ICP_STAT_BLOCKS][8];  // per-block partials of: n_mask, (unused), centroid_tgt xyz, centroid_src xyz
   int status;          // 1 = running/ok, 0 = failed (too few points / singular / diverged)
   float residual;      // RMS point-to-plane residual of the last iteration
 };
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void icp_stats(const float* __restrict__ depth
   }
   for (int k = 0; k < 7; ++k) {
     const float s = block_sum(v[k], red);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(&rows[n].stats[k == 0 ? 0 : k + 1], s);
+    if (threadIdx.x == 0) rows[n].stat_part[blockIdx.x][k == 0 ? 0 : k + 1] = s;
   }
 }
 
@@ -99,15 +101,17 @@ __global__ void icp_init(IcpRow* __restrict__ rows, int N, int n_min_points) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   IcpRow& r = rows[n];
-  const float cnt = r.stats[0];
+  float stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < ICP_STAT_BLOCKS; ++b)   // fixed order
+    for (int k = 0; k < 8; ++k) stats[k] += r.stat_part[b][k];
+  const float cnt = stats[0];
   for (int k = 0; k < 12; ++k) r.T[k] = (k == 0 || k == 5 || k == 10) ? 1.f : 0.f;
-  for (int k = 0; k < 29; ++k) r.acc[k] = 0.f;
   r.residual = -1.f;
   if (cnt < (float)n_min_points) { r.status = 0; return; }
   r.status = 1;
-  r.T[3] = (r.stats[2] - r.stats[5]) / cnt;   // centroid_tgt - centroid_src
-  r.T[7] = (r.stats[3] - r.stats[6]) / cnt;
-  r.T[11] = (r.stats[4] - r.stats[7]) / cnt;
+  r.T[3] = (stats[2] - stats[5]) / cnt;   // centroid_tgt - centroid_src
+  r.T[7] = (stats[3] - stats[6]) / cnt;
+  r.T[11] = (stats[4] - stats[7]) / cnt;
 }
 
 __global__ __launch_bounds__(256) void icp_accumulate(const float* __restrict__ depth_meas, const float* __restrict__ normals,
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void icp_accumulate(const float* __restrict__ 
   }
   for (int k = 0; k < 29; ++k) {
     const float s = block_sum(a[k], red);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(&rows[n].acc[k], s);
+    if (threadIdx.x == 0) rows[n].acc_part[blockIdx.x][k] = s;
   }
 }
 
@@ -171,14 +175,17 @@ __global__ void icp_solve(IcpRow* __restrict__ rows, int N, float min_inliers) {
   if (n >= N) return;
   IcpRow& r = rows[n];
   if (r.status == 0) return;
+  float acc[29];
+  for (int q = 0; q < 29; ++q) acc[q] = 0.f;
+  for (int blk = 0; blk < ICP_ACC_BLOCKS; ++blk)   // fixed order
+    for (int q = 0; q < 29; ++q) acc[q] += r.acc_part[blk][q];
   double A[6][6], b[6];
   int k = 0;
   for (int p = 0; p < 6; ++p)
-    for (int c = p; c < 6; ++c) { A[p][c] = r.acc[k]; A[c][p] = r.acc[k]; ++k; }
-  for (int p = 0; p < 6; ++p) b[p] = -(double)r.acc[21 + p];
-  const float cnt = r.acc[28];
-  const float res = cnt > 0.f ? sqrtf(r.acc[27] / cnt) : -1.f;
-  for (int q = 0; q < 29; ++q) r.acc[q] = 0.f;
+    for (int c = p; c < 6; ++c) { A[p][c] = acc[k]; A[c][p] = acc[k]; ++k; }
+  for (int p = 0; p < 6; ++p) b[p] = -(double)acc[21 + p];
+  const float cnt = acc[28];
+  const float res = cnt > 0.f ? sqrtf(acc[27] / cnt) : -1.f;
   if (cnt < min_inliers) { r.status = 0; r.residual = -1.f; return; }
   r.residual = res;
   for (int p = 0; p < 6; ++p) A[p][p] += 1e-9 * (double)cnt;  // Levenberg damping against rank deficiency (planar / symmetric views)
@@ -261,19 +268,19 @@ extern "C" int mp_icp_refine(const float* d_depth_meas, int n_images, const int3
   MP_CHECK_HIP(hipMemsetAsync(rows, 0, (size_t)n_rows * sizeof(IcpRow), s));
   ProfScope prof("icp_refine", 0.0, (double)n_rows * H * W * 8.0 * n_iterations, s);
   hipLaunchKernelGGL(icp_target_normals, dim3(ceil_div((long)H * W, 256), n_images), dim3(256), 0, s, d_depth_meas, d_K_images, H, W, normals);
-  hipLaunchKernelGGL(icp_stats, dim3(32, n_rows), dim3(256), 0, s, d_depth_meas, d_im_ids, d_depth_rend, d_K_rows, H, W, rows);
+  hipLaunchKernelGGL(icp_stats, dim3(ICP_STAT_BLOCKS, n_rows), dim3(256), 0, s, d_depth_meas, d_im_ids, d_depth_rend, d_K_rows, H, W, rows);
   hipLaunchKernelGGL(icp_init, dim3(ceil_div(n_rows, 64)), dim3(64), 0, s, rows, n_rows, n_min_points);
   const int per_level = ceil_div(n_iterations, n_levels);
   for (int l = 0; l < n_levels; ++l) {
     const int stride = 1 << (n_levels - 1 - l);
     const float d_max = tolerance * (float)(n_levels - l);  // 0.20, 0.15, 0.10, 0.05 for the reference's (0.05, 4 levels)
     for (int it = 0; it < per_level; ++it) {
-      hipLaunchKernelGGL(icp_accumulate, dim3(16, n_rows), dim3(256), 0, s, d_depth_meas, normals, d_im_ids, d_depth_rend, d_K_rows, H, W,
+      hipLaunchKernelGGL(icp_accumulate, dim3(ICP_ACC_BLOCKS, n_rows), dim3(256), 0, s, d_depth_meas, normals, d_im_ids, d_depth_rend, d_K_rows, H, W,
                          stride, d_max, rows);
       hipLaunchKernelGGL(icp_solve, dim3(ceil_div(n_rows, 64)), dim3(64), 0, s, rows, n_rows, 50.0f);
     }
   }
-  // residual of the final pose at the finest level (no update: min_inliers huge would fail the row, so re-use accumulate + a read-only pass)
+  // (the reported residual is the RMS point-to-plane error measured by the last accumulation, i.e. before the last increment)
   hipLaunchKernelGGL(icp_finalize, dim3(ceil_div(n_rows, 64)), dim3(64), 0, s, rows, d_TCO, n_rows, tolerance, d_TCO_out, d_retval, d_residual);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;

@@ -56,6 +56,8 @@ def test_icp_refiner_vs_oracle_and_ground_truth():
     assert torch.equal(out.poses_input, preds.poses)
     retval = extra["retval"].cpu().numpy()
     assert retval.tolist() == [0, 0, -1]
+    out2, _ = ref.refine_poses(preds, depth=depth[None], K=K[None])
+    assert torch.equal(out.poses, out2.poses)   # per-block partial sums added in a fixed order: bit-reproducible
     assert torch.equal(out.poses[2], preds.poses[2])  # rejected -> input pose kept (icp_refiner.py:257-258)
     # oracle of the same algorithm on the same rendered depth
     amb = [[Panda3dLightData("ambient")]] * 3
