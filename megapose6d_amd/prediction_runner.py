@@ -57,6 +57,8 @@ class PredictionRunner:
         self.n_workers = n_workers  # kept for signature compatibility: frames are staged by the caller's dataset object
         self.load_depth = bool(getattr(scene_ds, "load_depth", False))
         self.frame_ids = list(range(self.rank, len(scene_ds), self.world_size))  # DistributedSceneSampler: rank::world
+        self.sampler = self.frame_ids   # reference attribute names (prediction_runner.py:60-76)
+        self.tmp_dir = None             # no filesystem hand-off: results travel through the process group
         self.timings: List[Dict[str, float]] = []
 
     # ------------------------------------------------------------------ batching
@@ -130,6 +132,11 @@ class PredictionRunner:
                 v.delete_tensor("mask")
             out[k] = v
         return out
+
+    @property
+    def dataloader(self):
+        """iterable of collated batches (observation, detections, initial estimates, frame table), like the reference's DataLoader"""
+        return (self._collate(self.frame_ids[i : i + self.batch_size]) for i in range(0, len(self.frame_ids), self.batch_size))
 
     def _sync(self) -> None:
         if self.device.type == "cuda":
