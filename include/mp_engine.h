@@ -174,6 +174,10 @@ typedef struct {
 } mp_conv_desc;
 
 int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);
+/* Host-side launch plan of mp_conv2d_nhwc for a device with n_cu compute units (no GPU work; pointers in `desc` are only tested
+ * for NULL): out5 = {mode, k_split, chunks_per_split, n_main_tiles, first_row_of_the_split_part}; mode 0 = one single-pass launch,
+ * 1 = small grid, every tile split along K, 2 = whole rounds single-pass + split-K for the tiles of a half-empty last round. */
+int mp_conv2d_plan(const mp_conv_desc* desc, int n_cu, int32_t* out5);
 
 /* OPTIONAL fast mode: the same fp32 convolution evaluated with bf16 MFMA through an EXACT 3-way split of every operand
  * (x = hi + mid + lo, 3 x 8 mantissa bits; every partial product is exact in fp32, only the accumulation order differs from

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mp_conv_packed_floats": (_sz, [_i, _i, _i, _i]),
     "mp_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "mp_conv2d_plan": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(C.c_int32)]),
     "mp_conv_packed_split_bytes": (_sz, [_i, _i, _i, _i]),
     "mp_conv_pack_weights_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv2d_nhwc_split": (_i, [C.POINTER(ConvDesc), _i, _vp]),

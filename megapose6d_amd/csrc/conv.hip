@@ -867,6 +867,49 @@ extern "C" int mp_conv_pack_weights(const float* w, int Cout, int Cin, int KH, i
   return MP_OK;
 }
 
+// How a conv launch is laid out on the chip (host-side decision, exposed through mp_conv2d_plan for the CPU tests):
+//   mode 0: one single-pass launch;
+//   mode 1: small grid (< 192 tiles: the released K = 1 / K = 5 refiner passes) -- every tile's K loop is split over k_split
+//           workgroups and reduced deterministically;
+//   mode 2: full rounds + split-K tail -- with `resident` workgroups (2 per CU) a grid of n_tiles runs ceil(n_tiles / resident)
+//           rounds; when the last round is less than half full, its tiles are split along K over the idle slots instead
+//           (layer 3 at 576 rows: 2700 tiles = 5.27 rounds -> 5 rounds + a third of a round).
+struct ConvPlan {
+  int mode, k_split, chunks_per_split, n_main, m_begin;
+};
+
+static ConvPlan plan_conv(const ConvParams& p, bool small, long ws_floats, int resident, bool splitk_on, bool tail_on) {
+  ConvPlan pl = {0, 1, p.n_chunks, 0, 0};
+  const int n_nb = ceil_div(p.Cout, small ? 64 : 128);
+  const int n_tiles = ceil_div(p.M, 128) * n_nb;
+  if (!splitk_on || ws_floats <= 0 || (p.Cout % 4) != 0) return pl;
+  if (n_tiles < 192 && p.n_chunks >= 8) {
+    long S = std::min<long>(ceil_div(512, n_tiles), p.n_chunks / 4);
+    S = std::min<long>(S, ws_floats / ((long)p.M * p.Cout));
+    if (S >= 2) {
+      pl.mode = 1;
+      pl.chunks_per_split = ceil_div(p.n_chunks, (int)S);
+      pl.k_split = ceil_div(p.n_chunks, pl.chunks_per_split);
+      return pl;
+    }
+  }
+  const int n_tail = n_tiles % resident;
+  if (tail_on && n_tiles > resident && n_tail > 0 && 2 * n_tail <= resident && p.run % BK == 0 && resident % n_nb == 0) {
+    const int n_main = n_tiles - n_tail;
+    const int m_begin = (n_main / n_nb) * 128;
+    long S = std::min<long>(resident / n_tail, p.n_chunks / 6);
+    S = std::min<long>(S, ws_floats / ((long)(p.M - m_begin) * p.Cout));
+    if (S >= 2) {
+      pl.mode = 2;
+      pl.chunks_per_split = ceil_div(p.n_chunks, (int)S);
+      pl.k_split = ceil_div(p.n_chunks, pl.chunks_per_split);
+      pl.n_main = n_main;
+      pl.m_begin = m_begin;
+    }
+  }
+  return pl;
+}
+
 static int make_params(const mp_conv_desc* d, ConvParams* p) {
   MP_REQUIRE(d && d->d_x && d->d_w && (d->d_y || d->d_y_act), "mp_conv2d_nhwc: null pointer");
   MP_REQUIRE(d->C % 4 == 0, "mp_conv2d_nhwc: C (%d) must be a multiple of 4", d->C);
@@ -919,23 +962,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
   static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 257;  // default: LDS store under the 3rd of 4 MFMA groups; others = tuning experiments
   const bool small = conv_bn_tile(d->Cout) == 64;
-  // split-K when the tile grid cannot fill the chip (small batches: the released K = 1 / K = 5 refiner passes)
   static const int splitk_on = getenv("MP_CONV_SPLITK") ? atoi(getenv("MP_CONV_SPLITK")) : 1;
-  const int n_tiles = ceil_div(p.M, 128) * ceil_div(p.Cout, small ? 64 : 128);
-  if (splitk_on && d->d_splitk_ws && n_tiles < 192 && (p.Cout % 4) == 0 && p.n_chunks >= 8) {
-    long S = std::min<long>(ceil_div(512, n_tiles), p.n_chunks / 4);
-    S = std::min<long>(S, d->splitk_ws_floats / ((long)p.M * p.Cout));
-    if (S >= 2) {
-      p.chunks_per_split = ceil_div(p.n_chunks, (int)S);
-      p.k_split = ceil_div(p.n_chunks, p.chunks_per_split);
-      p.partial = d->d_splitk_ws;
-      if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1, true>(p, s, alg_k);
-      return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
-    }
-  }
-  // Full rounds + split-K tail: with R resident workgroups (2 per CU) a grid of n_tiles runs ceil(n_tiles / R) rounds; when the
-  // last round is less than half full, its tiles are split along K over the idle slots instead (layer 3 at 576 rows: 2700 tiles =
-  // 5.27 rounds -> 5 rounds + a third of a round).  Same deterministic partial-sum reduce as the small-batch path.
   static const int tail_on = getenv("MP_CONV_TAIL") ? atoi(getenv("MP_CONV_TAIL")) : 1;
   static int resident = 0;
   if (!resident) {
@@ -944,24 +971,23 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     resident = 2 * n_cu;
   }
-  const int n_nb = ceil_div(p.Cout, small ? 64 : 128);
-  const int n_tail = n_tiles % resident;
-  if (tail_on && splitk_on && d->d_splitk_ws && n_tiles > resident && n_tail > 0 && 2 * n_tail <= resident && (p.Cout % 4) == 0 &&
-      p.run % BK == 0 && resident % n_nb == 0) {
-    const int n_main = n_tiles - n_tail;
-    const int m_begin = (n_main / n_nb) * 128;
-    long S = std::min<long>(resident / n_tail, p.n_chunks / 6);
-    S = std::min<long>(S, d->splitk_ws_floats / ((long)(p.M - m_begin) * p.Cout));
-    if (S >= 2) {
-      int rc2 = small ? launch<128, 64, 64, 32, 257>(p, s, alg_k, n_main) : launch<128, 128, 64, 64, 257>(p, s, alg_k, n_main);
-      if (rc2) return rc2;
-      p.chunks_per_split = ceil_div(p.n_chunks, (int)S);
-      p.k_split = ceil_div(p.n_chunks, p.chunks_per_split);
-      p.partial = d->d_splitk_ws;
-      p.tile_begin = n_main;
-      p.m_part_begin = m_begin;
-      return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
-    }
+  const ConvPlan plan = plan_conv(p, small, d->d_splitk_ws ? d->splitk_ws_floats : 0, resident, splitk_on != 0, tail_on != 0);
+  if (plan.mode == 1) {  // small grid: every tile split along K
+    p.chunks_per_split = plan.chunks_per_split;
+    p.k_split = plan.k_split;
+    p.partial = d->d_splitk_ws;
+    if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1, true>(p, s, alg_k);
+    return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
+  }
+  if (plan.mode == 2) {  // whole rounds single-pass, the tiles of the half-empty last round split along K
+    int rc2 = small ? launch<128, 64, 64, 32, 257>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 257>(p, s, alg_k, plan.n_main);
+    if (rc2) return rc2;
+    p.chunks_per_split = plan.chunks_per_split;
+    p.k_split = plan.k_split;
+    p.partial = d->d_splitk_ws;
+    p.tile_begin = plan.n_main;
+    p.m_part_begin = plan.m_begin;
+    return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
   }
   static const int ldsd = getenv("MP_CONV_LDSD") ? atoi(getenv("MP_CONV_LDSD")) : 0;  // bit 0: 128x128 layers, bit 1: 128x64, bit 2: stems
   if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
@@ -985,6 +1011,16 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     case 1: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
     default: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);
   }
+}
+
+extern "C" int mp_conv2d_plan(const mp_conv_desc* d, int n_cu, int32_t* out5) {
+  MP_REQUIRE(out5 && n_cu > 0, "mp_conv2d_plan: bad arguments");
+  ConvParams p;
+  int rc = make_params(d, &p);
+  if (rc) return rc;
+  const ConvPlan pl = plan_conv(p, conv_bn_tile(d->Cout) == 64, d->d_splitk_ws ? d->splitk_ws_floats : 0, 2 * n_cu, true, true);
+  out5[0] = pl.mode; out5[1] = pl.k_split; out5[2] = pl.chunks_per_split; out5[3] = pl.n_main; out5[4] = pl.m_begin;
+  return MP_OK;
 }
 
 extern "C" const char* mp_conv2d_kernel_name(const mp_conv_desc* d) {

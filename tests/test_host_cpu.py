@@ -329,3 +329,40 @@ def test_prediction_runner_two_ranks_gloo_gather():
     want = sorted(single["final"].infos["view_id"].tolist())
     assert res[0][2] == want and res[1][2] == want
     assert abs(res[0][3] - single["final"].poses.sum().item()) < 1e-4 and abs(res[1][3] - res[0][3]) < 1e-6
+
+
+def _plan(N, H, W, C, Cout, K, stride, ws_floats=12 << 20, n_cu=256):
+    import ctypes as C_
+
+    from megapose6d_amd import _lib
+
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    dummy = 0x1000  # pointers are only tested for NULL by the planner
+    d.d_x, d.N, d.H, d.W, d.C, d.in_border = dummy, N, H, W, C, K // 2
+    d.d_w, d.Cout, d.KH, d.KW, d.stride, d.pad = dummy, Cout, K, K, stride, K // 2
+    d.d_y, d.out_border = dummy, 1
+    if ws_floats:
+        d.d_splitk_ws, d.splitk_ws_floats = dummy, ws_floats
+    out = (C_.c_int32 * 5)()
+    assert lib.mp_conv2d_plan(C_.byref(d), n_cu, out) == 0, lib.mp_last_error()
+    return tuple(out)
+
+
+def test_conv_launch_plan_small_grids_and_half_empty_last_rounds():
+    """host-side planner of mp_conv2d_nhwc (no GPU work): which launches split K, and how"""
+    # layer 3 at 576 rows: 1350 x 2 = 2700 tiles on 512 resident workgroups = 5 rounds + 140 tiles -> tail split 3 ways
+    mode, S, cps, n_main, m_begin = _plan(576, 15, 20, 256, 256, 3, 1)
+    assert (mode, S, n_main, m_begin) == (2, 3, 2560, 1280 * 128) and cps == 24
+    # layer 2 (5400 tiles = 10 rounds + 280: more than half a round) and layer 4 (1440 = 2 rounds + 416): single pass
+    assert _plan(576, 30, 40, 128, 128, 3, 1)[0] == 0 and _plan(576, 8, 10, 512, 512, 3, 1)[0] == 0
+    # layer 1 (21 600 tiles of 128 x 64 = 42 rounds + 96 tiles, 18 chunks): tail split 3 ways
+    assert _plan(576, 60, 80, 64, 64, 3, 1)[:2] == (2, 3)
+    # batch 1: layer 4 has 4 tiles -> every tile split (144 chunks / 4 = 36 ways at most, 128 wanted -> 36)
+    mode, S, cps, n_main, _ = _plan(1, 8, 10, 512, 512, 3, 1)
+    assert mode == 1 and n_main == 0 and S * cps >= 144 and S <= 36 and cps >= 4
+    # no scratch -> never split; tiny K (1x1 conv with 2 chunks) -> never split
+    assert _plan(1, 8, 10, 512, 512, 3, 1, ws_floats=0)[0] == 0
+    assert _plan(1, 30, 40, 64, 128, 1, 2)[0] == 0
+    # scratch too small for two partial copies -> single pass
+    assert _plan(1, 8, 10, 512, 512, 3, 1, ws_floats=80 * 512)[0] == 0
