@@ -1,20 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- pose-hypotheses/sec of the hot path (render + coarse + refine + score) on N MI355X.
 
-One "step" = one `PoseEstimator.run_inference_pipeline` call over a synthetic 640x480 frame resident in HBM:
-BASELINE.json configs[1] = megapose-1.0-RGB structure (coarse 9-ch + refiner 27-ch vanilla ResNet-34, fp32),
+One "step" = one `PoseEstimator.run_inference_pipeline` call over synthetic 640x480 frame(s) resident in HBM.
+Default workload = BASELINE.json configs[1]: megapose-1.0-RGB structure (coarse 9-ch + refiner 27-ch vanilla ResNet-34, fp32),
 1 object x 576 SO(3)-grid hypotheses, ALL 576 refined for 5 iterations (n_pose_hypotheses=576), then re-scored:
 576 coarse + 2880 refine + 576 score CNN rows and 12 672 rendered views per object.
-With N > 1 (torchrun, one rank per GPU, RCCL): N objects in the frame, rows sharded rank::world, all-gathers of
-the packed logits/poses per stage (weak scaling: 1 object x 576 hypotheses per GPU).
+`--config 3|4|5` run the other BASELINE.json configurations (their lines are informational; the driver reads config 2).
+
+N > 1: `python bench.py --gpus N` re-launches itself through `python -m torch.distributed.run` (one rank per GPU, backend
+"nccl" = RCCL) unless it already runs under torchrun (WORLD_SIZE set).  Weak scaling: config 2 puts one object x 576
+hypotheses per GPU; rows are sharded rank::world and the packed logits/poses are all-gathered once per stage.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline":     the dominant kernel (fp32-MFMA implicit-GEMM conv) measured live with HIP events on its launch stream
-  "cpu_baseline": the oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample.
+  "cpu_baseline": the oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample
+  "parity":       the rows the cpu_baseline leg computed, compared with the same rows of the timed GPU call (N = 1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -26,65 +32,99 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-METRIC = "pose-hypotheses/sec (render+coarse+refine), 640x480, megapose-1.0-RGB"
+METRIC = json.loads((ROOT / "BASELINE.json").read_text())["metric"] if (ROOT / "BASELINE.json").is_file() else \
+    "pose-hypotheses/sec (render+coarse+refine), 640×480, megapose-1.0-RGB"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
 N_HYP, N_ITERS = 576, 5
+PARITY_TOL = 1e-4  # BASELINE.json north_star: poses within 1e-4; logits 1e-4 relative to the logit scale
 
 
-def cpu_baseline(tmp_dir: str, obs_images: torch.Tensor, K: torch.Tensor, bboxes: torch.Tensor, budget_s: float = 20.0,
-                 threads: int = 0) -> dict:
+def _best_cpu_threads() -> int:
+    """thread count of the committed host sweep (profiles/r02_cpu_thread_sweep.json) if there is one for this core count"""
+    f = ROOT / "profiles" / "r02_cpu_thread_sweep.json"
+    try:
+        j = json.loads(f.read_text())
+        if j.get("host_cores") == os.cpu_count():
+            return int(j["best_threads"])
+    except Exception:
+        pass
+    return min(os.cpu_count() or 1, 32)
+
+
+def cpu_baseline(ds, obs_images: torch.Tensor, K: torch.Tensor, bboxes: torch.Tensor, budget_s: float = 20.0, threads: int = 0,
+                 n_max: int = 48) -> dict:
     """Oracle (port of the reference CPU path: reference orchestration + torch-CPU fp32 CNN + C software rasteriser standing in
-    for Panda3D, which cannot be installed offline) on a bounded sample of the same workload.  Threads: min(host cores, 32)
-    -- more threads only add OpenMP overhead at these batch sizes (the reference itself pins 1 thread, __init__.py:39-40).
-    The sample is sized adaptively from a 4-row probe so that it stays within `budget_s` seconds of CPU work."""
-    from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.mesh_db import MeshDataBase
-    from megapose6d_amd.pose_estimator import load_SO3_grid
+    for Panda3D, which cannot be installed offline) on a bounded sample of the config-2 workload: the first `n_coarse` coarse rows
+    and the 5-iteration refiner chains + re-score of the first `n_refine` hypotheses of object 0.  The sample is sized from a
+    4-row probe so that it stays within `budget_s` seconds of CPU work.  Returns the timing AND the computed values (the parity
+    leg compares them with the GPU's rows)."""
     from oracle import geometry as og
-    from oracle import pipeline as op
-    from oracle import raster as orr
+    from oracle import harness
 
-    threads = threads or min(os.cpu_count() or 1, 32)
+    threads = threads or _best_cpu_threads()
     torch.set_num_threads(threads)
-    ds = syn.make_object_dataset(tmp_dir, n_objects=1, seed=0)
-    meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}
-    db = MeshDataBase.from_object_ds(ds).batched()
-    rend = orr.OracleBatchRenderer(meshes)
-    preds = {}
-    for role, seed in (("coarse", 11), ("refiner", 12)):
-        cfg = syn.make_cfg(role)
-        head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
-        preds[role] = op.OraclePosePredictor(cfg, syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), head, n_out, seed=seed),
-                                             db.labels.tolist(), db.points, rend)
-    grid = load_SO3_grid(N_HYP)
+    oest, db = harness.make_oracle_estimator(ds, N_HYP)
+    cpred, rpred = oest.coarse, oest.refiner
+    grid = oest.grid
     images, Kc = obs_images.cpu(), K.cpu()
     label = ds[0].label
-    n_max = 48
     with torch.no_grad():
         T = og.TCO_init_from_boxes_autodepth_with_R(bboxes[:1].cpu().float().repeat(n_max, 1), db.points[:1].repeat(n_max, 1, 1),
-                                                   Kc.repeat(n_max, 1, 1), grid[:n_max])
+                                                   Kc[:1].repeat(n_max, 1, 1), grid[:n_max])
         im = torch.zeros(n_max, dtype=torch.long)
 
         def coarse(n, poses):
             t0 = time.perf_counter()
-            preds["coarse"].forward_coarse(images, im[:n], Kc.repeat(n, 1, 1), [label] * n, poses[:n])
-            return time.perf_counter() - t0
+            o = cpred.forward_coarse(images, im[:n], Kc[:1].repeat(n, 1, 1), [label] * n, poses[:n])
+            return time.perf_counter() - t0, o["logits"].flatten()
 
         coarse(2, T)  # warm-up
-        t_row = coarse(4, T) / 4  # probe
+        t_row = coarse(4, T)[0] / 4  # probe
         n_coarse = int(max(4, min(n_max, 0.35 * budget_s / max(t_row, 1e-4))))
         n_refine = int(max(1, min(8, 0.65 * budget_s / max(t_row * 4.5 * (N_ITERS + 1), 1e-4))))
-        t_coarse = coarse(n_coarse, T)
+        t_coarse, coarse_logits = coarse(n_coarse, T)
         t0 = time.perf_counter()
-        outs = preds["refiner"].forward(images, im[:n_refine], Kc.repeat(n_refine, 1, 1), [label] * n_refine, T[:n_refine], N_ITERS)
+        outs = rpred.forward(images, im[:n_refine], Kc[:1].repeat(n_refine, 1, 1), [label] * n_refine, T[:n_refine], N_ITERS)
         t_refine = time.perf_counter() - t0
-        t_score = coarse(n_refine, outs[-1]["TCO_output"])
+        t_score, score_logits = coarse(n_refine, outs[-1]["TCO_output"])
     t_full = t_coarse * (N_HYP / n_coarse) + (t_refine + t_score) * (N_HYP / n_refine)
     return {"value": N_HYP / t_full, "unit": "pose-hypotheses/s", "cores": threads, "kind": "port",
             "sample": f"{n_coarse} of 576 coarse rows + {n_refine} of 576 hypotheses x {N_ITERS} refine iters + {n_refine} score rows, "
                       f"{t_coarse + t_refine + t_score:.1f} s of CPU work on {threads} threads ({os.cpu_count()} host cores), extrapolated "
-                      "linearly per stage; Panda3D replaced by the oracle's C rasteriser"}
+                      "linearly per stage; Panda3D replaced by the oracle's C rasteriser",
+            "_values": {"coarse_TCO": T[:n_coarse], "coarse_logits": coarse_logits, "refine_poses": [o["TCO_output"] for o in outs],
+                        "refine_pose_out": [o["net"]["pose"] for o in outs], "score_logits": score_logits}}
+
+
+def parity_block(vals: dict, extra: dict) -> dict:
+    """oracle rows of the cpu_baseline leg vs the SAME rows of the timed 576-row GPU call (object 0: hypotheses 0..n-1)"""
+    cd = extra["coarse"]
+    n_c = vals["coarse_logits"].numel()
+    lo = vals["coarse_logits"]
+    scale = max(1.0, lo.abs().max().item())
+    out = {"rows": {"coarse": n_c, "refine_chains": len(vals["score_logits"]), "iterations": len(vals["refine_poses"])},
+           "tolerance": PARITY_TOL, "logit_scale": scale}
+    out["coarse_TCO_max_err"] = (cd["preds"].poses[:n_c].cpu() - vals["coarse_TCO"]).abs().max().item()
+    out["coarse_logit_max_err"] = (cd["data"]["logits"].flatten()[:n_c].cpu() - lo).abs().max().item()
+    # the GPU call refined the hypotheses in top-K order: find hypotheses 0..n-1 of detection 0 in its filtered table
+    dff = extra["coarse_filter"]["preds"].infos.reset_index(drop=True)
+    first_det = dff["bbox_id"].iloc[0] if len(dff) else None
+    n_r = len(vals["score_logits"])
+    pos = [int(np.nonzero((dff["hypothesis_id"].values == h) & (dff["bbox_id"].values == dff["bbox_id"].values.min()))[0][0]) for h in range(n_r)]
+    preds = extra["refiner_all_hypotheses"]["preds"]
+    pouts = extra["refiner_all_hypotheses"]["data"]["pose_outputs"]
+    out["pose_max_err_per_iter"] = [(preds[f"iteration={n + 1}"].poses[pos].cpu() - vals["refine_poses"][n]).abs().max().item()
+                                    for n in range(len(vals["refine_poses"]))]
+    out["pose_out_max_err_per_iter"] = [(pouts[f"iteration={n + 1}"][pos].cpu() - vals["refine_pose_out"][n]).abs().max().item()
+                                        for n in range(len(vals["refine_pose_out"]))]
+    sl = vals["score_logits"]
+    scale = max(scale, sl.abs().max().item())
+    out["logit_scale"] = scale
+    out["score_logit_max_err"] = (extra["scoring"]["data"]["logits"].flatten()[pos].cpu() - sl).abs().max().item()
+    out["ok"] = bool(out["coarse_TCO_max_err"] < PARITY_TOL and out["coarse_logit_max_err"] < PARITY_TOL * scale
+                     and out["score_logit_max_err"] < PARITY_TOL * scale and all(e < PARITY_TOL for e in out["pose_max_err_per_iter"]))
+    return out
 
 
 def extras(est, obs, det, steps: int) -> dict:
@@ -117,11 +157,64 @@ def extras(est, obs, det, steps: int) -> dict:
         dt = timed(N_HYP)
         out[f"conv_bf16x{prec}_split"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
                                           "note": "optional mode: fp32 operands split exactly into 3 bf16 pieces, bf16 MFMA, fp32 accumulate; "
-                                                  "meets the same parity bounds (tests/test_gpu_pipeline.py), not used for `value`"}
+                                                  "narrower than the reference's fp32 when product terms are dropped (x6) -- never `value`"}
     for m in (est.coarse_model, est.refiner_model):
         m.conv_precision = 0
         m._engine_bb = None
     return out
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _relaunch(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: spawn one rank per GPU through torch.distributed.run (RCCL rendezvous on 127.0.0.1)"""
+    n_dev = torch.cuda.device_count()
+    if n_dev < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def build_workload(cfg_id: int, world: int, backbone: str, tmp: str, precision: int, k_hyp: int):
+    """-> (estimator, observation, detections, object dataset, description dict, n_objects, run kwargs)"""
+    from megapose6d_amd.scene import make_multi_frame_scene, make_scene
+    from megapose6d_amd import synthetic as syn
+
+    common = dict(SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1, n_streams=int(os.environ.get("MP_N_STREAMS", "1")), precision=precision)
+    run = dict(n_refiner_iterations=N_ITERS, n_pose_hypotheses=k_hyp)
+    if cfg_id == 2:
+        n_obj = world  # weak scaling: one object x 576 hypotheses per GPU
+        est, obs, det, _ = make_scene(n_objects=n_obj, seed=0, backbone=backbone, **common)
+        ds = syn.make_object_dataset(tmp, n_objects=n_obj, seed=0)
+        desc = f"configs[1]: megapose-1.0-RGB structure ({backbone} coarse 9ch + refiner 27ch), {n_obj} object(s) x 576 hypotheses"
+    elif cfg_id == 3:
+        n_obj = 8 * world
+        est, obs, det, _ = make_scene(n_objects=n_obj, seed=7, backbone=backbone, rgbd=True, **common)
+        ds = syn.make_object_dataset(tmp, n_objects=n_obj, seed=7)
+        desc = f"configs[2]: megapose-1.0-RGBD structure ({backbone} coarse 9ch + RGBD refiner 32ch), {n_obj} objects x 576 hypotheses"
+    elif cfg_id in (4, 5):
+        n_obj = 64
+        est, obs, det, ds = make_multi_frame_scene(8, 8, 16, backbone=backbone, rgbd=(cfg_id == 5), **common)
+        desc = (f"configs[{cfg_id - 1}]: megapose-1.0-RGB-multi-hypothesis structure ({backbone}), 64 detections over 8 frames / 16 meshes x 576 "
+                "hypotheses" + (", + depth refiner (ICP) on the RGBD frames" if cfg_id == 5 else ""))
+        if cfg_id == 5:
+            from megapose6d_amd.icp_refiner import ICPRefiner
+
+            est.depth_refiner = ICPRefiner(est.mesh_db, est.coarse_model.renderer)
+            run["run_depth_refiner"] = True
+    else:
+        raise SystemExit(f"unknown --config {cfg_id}")
+    desc += f" x {N_ITERS} refine iters (n_pose_hypotheses={k_hyp}) + re-score, 640x480 frames, 240x320 crops, 10k-triangle meshes"
+    return est, obs, det, ds, desc, n_obj, run
 
 
 def main():
@@ -129,32 +222,53 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json configuration (1-based, as SURVEY.md 8d numbers them); 2 = headline")
+    ap.add_argument("--k-hyp", type=int, default=0, help="n_pose_hypotheses (default: 576 for configs 2/3, 5 for configs 4/5)")
     ap.add_argument("--backbone", default="vanilla_resnet34")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-thread-sweep", default="", help="comma list of thread counts: time the cpu_baseline sample at each, write "
+                                                          "gpurun_out/cpu_thread_sweep.json and exit")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (faithful K=1/K=5 configs, optional split-precision modes)")
     ap.add_argument("--precision", type=int, default=0, help="0 = native fp32 MFMA (default, what `value` is quoted on); 9 / 6 = optional bf16 split modes")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_relaunch(a.gpus))
+
     from megapose6d_amd import distributed as mpd
     from megapose6d_amd import engine as eng
-    from megapose6d_amd.scene import make_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` (WORLD_SIZE={world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     if world > 1:
         mpd.init_from_env("nccl")
+        mpd.stats.timing = True
     n_cu, lds, arch = eng.device_info()
 
     tmp = tempfile.mkdtemp(prefix=f"mp_bench_r{rank}_")
-    n_obj = world  # weak scaling: one object x 576 hypotheses per GPU
-    est, obs, det, _ = make_scene(n_objects=n_obj, seed=0, backbone=a.backbone, SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1,
-                                   n_streams=int(os.environ.get("MP_N_STREAMS", "1")), precision=a.precision)
+    k_hyp = a.k_hyp or (N_HYP if a.config in (2, 3) else 5)
+    est, obs, det, ds, desc, n_obj, run = build_workload(a.config, world, a.backbone, tmp, a.precision, k_hyp)
 
-    def step():
-        return est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=N_HYP)
+    if a.cpu_thread_sweep:
+        res = {"host_cores": os.cpu_count(), "runs": []}
+        for t in [int(v) for v in a.cpu_thread_sweep.split(",")]:
+            r = cpu_baseline(ds, obs.images, obs.K, det.bboxes, budget_s=12.0, threads=t)
+            r.pop("_values")
+            res["runs"].append(r)
+            print(f"[sweep] {t} threads: {r['value']:.3f} hyp/s", file=sys.stderr)
+        best = max(res["runs"], key=lambda r: r["value"])
+        res["best_threads"], res["best_value"] = best["cores"], best["value"]
+        out_dir = ROOT / "gpurun_out"
+        out_dir.mkdir(exist_ok=True)
+        (out_dir / "cpu_thread_sweep.json").write_text(json.dumps(res, indent=1))
+        print(json.dumps(res))
+        return
+
+    def step(**kw):
+        return est.run_inference_pipeline(obs, detections=det, **run, **kw)
 
     def fence():
         torch.cuda.synchronize()
@@ -165,6 +279,7 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    mpd.stats.reset()
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -172,58 +287,86 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
+    gather_ms = mpd.stats.ms() if world > 1 else 0.0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     assert len(final) == n_obj and torch.isfinite(final.poses).all()
+    # stage times from HIP events: one extra, untimed call with cuda_timer=True (each stage fenced, DEVICE render/model times)
+    _, extra_t = step(cuda_timer=True)
 
+    rc = 0
     if rank == 0:
         conv = {k: v for k, v in prof.items() if k.startswith("conv_nhwc_f32")}
         dom_name = max(conv, key=lambda k: conv[k]["ms"])
         dom = conv[dom_name]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         all_conv_tf = sum(v["flops"] for v in conv.values()) / (sum(v["ms"] for v in conv.values()) * 1e-3) / 1e12
+        conv_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in conv.items() if v["ms"] > 0}
         kernel_ms = {k: round(v["ms"] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-        rb = prof.get("raster_bands")
-        traffic, traffic_src = None, None
-        tfile = ROOT / "profiles" / "r01_conv_traffic.json"  # PMC cannot be sampled from inside the process: committed rocprofv3 summary
-        if tfile.is_file():
+        rb = next((v for k, v in prof.items() if k.startswith("raster_")
+                   and v["ms"] == max(vv["ms"] for kk, vv in prof.items() if kk.startswith("raster_"))), None)
+        rb_name = next((k for k, v in prof.items() if v is rb), None)
+        traffic, traffic_src, r_traffic = None, None, None
+        tfile = next((f for f in (ROOT / "profiles" / "r02_traffic.json", ROOT / "profiles" / "r01_conv_traffic.json") if f.is_file()), None)
+        if tfile is not None:  # PMC cannot be sampled from inside the process: committed rocprofv3 --pmc summary of the same command
             tj = json.loads(tfile.read_text())
             k = tj["kernels"].get(dom_name.replace(" ", ""))
             if k:
                 traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], tj["source"]
+            k = tj["kernels"].get(rb_name or "")
+            if k:
+                r_traffic = k["hbm_bytes_per_launch_corrected"]
+        rows_per_obj = N_HYP + k_hyp * N_ITERS + k_hyp
+        views_per_obj = N_HYP + 4 * k_hyp * N_ITERS + k_hyp
+        sd = {s: extra_t[s]["data"] for s in ("coarse", "refiner", "scoring")}
         out = {
             "metric": METRIC, "value": n_obj * N_HYP * a.steps / dt, "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == 0 else f"f32 via exact bf16x{a.precision} operand split (bf16 MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"megapose-1.0-RGB structure ({a.backbone} coarse 9ch + refiner 27ch), {n_obj} object(s) x 576 hypotheses x 5 refine "
-                                   "iters (n_pose_hypotheses=576) + re-score, 640x480 frame, 240x320 crops, 10k-triangle meshes",
-                       "rows_per_step": n_obj * (2 * N_HYP + N_HYP * N_ITERS),
-                       "evals_per_s": n_obj * (2 * N_HYP + N_HYP * N_ITERS) * a.steps / dt, "views_per_step": n_obj * (2 * N_HYP + 4 * N_HYP * N_ITERS),
+            "config": {"workload": desc, "baseline_config": a.config, "objects": n_obj, "n_pose_hypotheses": k_hyp,
+                       "rows_per_step": n_obj * rows_per_obj, "evals_per_s": n_obj * rows_per_obj * a.steps / dt,
+                       "views_per_step": n_obj * views_per_obj,
                        "parallelism": f"rows sharded rank::world over {world} GPU(s)", "arch": arch, "cus": n_cu},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": dom["bytes"] / dom["launches"], "launches": dom["launches"],
                          "avg_launch_ms": dom["ms"] / dom["launches"], "avg_launch_gflop": dom["flops"] / dom["launches"] / 1e9,
-                         "all_conv_kernels_tflops": all_conv_tf},
-            "raster": None if rb is None else {"bound": "hbm", "kernel": "raster_bands", "achieved_GBps": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9,
-                                               "peak_GBps": 8000.0, "avg_launch_ms": rb["ms"] / rb["launches"]},
+                         "all_conv_kernels_tflops": all_conv_tf, "per_kernel_tflops": conv_tf},
+            "raster": None if rb is None else {"bound": "hbm", "kernel": rb_name, "achieved": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9,
+                                               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                               "traffic": r_traffic, "alg_bytes_per_launch": rb["bytes"] / rb["launches"],
+                                               "avg_launch_ms": rb["ms"] / rb["launches"], "ms_per_step": rb["ms"] / a.steps},
             "kernel_ms_per_step": kernel_ms,
-            "stage_s": {"coarse": extra["coarse"]["data"]["time"], "refiner": extra["refiner"]["data"]["time"],
-                        "scoring": extra["scoring"]["data"]["time"], "total": extra["time"]},
+            "stage_s": {"source": "HIP events, one extra call with cuda_timer=True (stages fenced)",
+                        **{s: {"time": sd[s]["time"], "render_time": sd[s]["render_time"], "model_time": sd[s]["model_time"]} for s in sd},
+                        "total": extra_t["time"]},
         }
-        if world == 1 and not a.no_extras:
+        if world > 1:
+            out["rccl"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                           "all_gathers_per_step": mpd.stats.calls / a.steps, "all_gather_bytes_per_step": mpd.stats.bytes / a.steps,
+                           "all_gather_ms_per_step": gather_ms / a.steps}
+        if world == 1 and a.config == 2 and not a.no_extras:
             out["extras"] = extras(est, obs, det, a.steps)
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tmp, obs.images, obs.K, det.bboxes)
-            out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if not a.no_cpu_baseline and world == 1 and a.config == 2 and k_hyp == N_HYP:
+            cb = cpu_baseline(ds, obs.images, obs.K, det.bboxes)
+            out["parity"] = parity_block(cb.pop("_values"), extra)
+            out["cpu_baseline"] = cb
+            out["vs_cpu_baseline"] = out["value"] / cb["value"]
             # the thread setting `import megapose` itself enforces (reference src/megapose/__init__.py:39-40), smaller sample
-            out["cpu_baseline_1thread"] = cpu_baseline(tmp, obs.images, obs.K, det.bboxes, budget_s=8.0, threads=1)
+            cb1 = cpu_baseline(ds, obs.images, obs.K, det.bboxes, budget_s=8.0, threads=1)
+            cb1.pop("_values")
+            out["cpu_baseline_1thread"] = cb1
+            if not out["parity"]["ok"]:
+                rc = 3
         print(json.dumps(out))
+        if rc:
+            print(f"bench.py: PARITY FAILED (tolerance {PARITY_TOL}): {out['parity']}", file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

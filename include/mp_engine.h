@@ -227,6 +227,10 @@ int mp_backbone_destroy(mp_backbone* bb);
 int mp_backbone_input_channels_padded(const mp_backbone* bb);
 int mp_backbone_input_border(const mp_backbone* bb);
 size_t mp_backbone_workspace_bytes(const mp_backbone* bb, int batch, int h, int w);
+/* The executor zeroes a workspace's borders once per (pointer, batch, h, w) and then trusts them.  Call this whenever the
+ * memory behind `d_workspace` is a NEW allocation (the owner knows; an allocator may hand an old address back after foreign
+ * writes): the next forward on it re-zeroes.                                                                            */
+int mp_backbone_workspace_reset(mp_backbone* bb, const void* d_workspace);
 /* d_x: padded NHWC [batch, h, w, Cp] with border mp_backbone_input_border().                */
 int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out,
                         float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mp_backbone_input_channels_padded": (_i, [_vp]),
     "mp_backbone_input_border": (_i, [_vp]),
     "mp_backbone_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mp_backbone_workspace_reset": (_i, [_vp, _vp]),
     "mp_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_flops": (C.c_double, [_vp, _i, _i, _i]),
     "mp_normalize_T": (_i, [_vp, _i, _vp, _vp]),

@@ -270,6 +270,13 @@ extern "C" size_t mp_backbone_workspace_bytes(const mp_backbone* bb, int batch, 
   return fl * sizeof(float);
 }
 
+extern "C" int mp_backbone_workspace_reset(mp_backbone* bb, const void* d_ws) {
+  MP_REQUIRE(bb, "mp_backbone_workspace_reset: null handle");
+  for (size_t i = 0; i < bb->ws_known.size();)
+    if (bb->ws_known[i].ptr == d_ws) bb->ws_known.erase(bb->ws_known.begin() + i); else ++i;
+  return MP_OK;
+}
+
 extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out, float* d_sigmoid,
                                    float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
   MP_REQUIRE(bb && d_x && d_out && d_ws, "mp_backbone_forward: null pointer");

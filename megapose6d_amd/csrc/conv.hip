@@ -96,7 +96,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
-// VARIANT bit 0: LDS store of the next chunk under the last MFMA group; bit 1: interleaved MFMA order; bit 2: SINGLE LDS buffer
+// VARIANT bit 0: LDS store of the next chunk under an MFMA group (bit 8: the 3rd of 4); bit 1: interleaved MFMA order; bit 2: SINGLE LDS buffer
 // (half the LDS -> 3+ workgroups per CU, two barriers per chunk) -- bit 2 excludes bit 0.
 template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, bool SPLITK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 3 : 2, (VARIANT & 4) ? 3 : 2))) void conv_nhwc_f32_mfma(ConvParams p) {
@@ -257,29 +257,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         }
       }
     }
-    if constexpr ((VARIANT & 16) == 0) {  // (bits 4..6 are timing experiments only: wrong results)
-      MP_CONV_LOAD(aoff, bp)
-    }
+    MP_CONV_LOAD(aoff, bp)
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
     const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
     const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
-      if constexpr ((VARIANT & 64) != 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = a0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = b0;
-      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT + kk * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT + kk * 8);
-      }
       if constexpr ((VARIANT & 1) != 0) {
         constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
-        if (kk == STORE_KK && (VARIANT & 16) == 0) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
+        if (kk == STORE_KK) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
           __builtin_amdgcn_sched_barrier(0);
           MP_CONV_STORE(buf ^ 1)
           __builtin_amdgcn_sched_barrier(0);
@@ -310,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       __builtin_amdgcn_sched_barrier(0);
       MP_CONV_STORE(buf ^ 1)
     }
-    if constexpr ((VARIANT & 32) == 0) __syncthreads();
+    __syncthreads();
   }
 #undef MP_CONV_LOAD
 #undef MP_CONV_STORE
@@ -347,380 +338,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
     default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// LDS-direct variant: global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write, no vmcnt waits inside the MFMA
-// stream).  The instruction writes lane l's 16 bytes at M0 + 16*l, so tile rows are UNPADDED (32 floats) and bank conflicts are
-// avoided by an XOR swizzle instead: the 16-byte column c of row r lives at column c ^ (r & 7); it is applied on the global side
-// (lane (r, c) fetches column c ^ (r & 7)) and undone in the fragment reads.  The two stages are separate __shared__ objects and
-// the chunk body takes them as __restrict__ pointers: that is what lets the compiler prove that the ds_reads of one stage do not
-// depend on the LDS-DMA writes into the other (otherwise it inserts s_waitcnt vmcnt(0) in front of every fragment read).
-#define MP_GPTR(P) ((const void __attribute__((address_space(1)))*)(P))
-#define MP_LPTR(P) ((void __attribute__((address_space(3)))*)(P))
-template <int BN, int TM, int TN, int SPREAD>
-__device__ __forceinline__ void ldsd_chunk(const float* __restrict__ a_rd, const float* __restrict__ b_rd, float* __restrict__ a_wr,
-                                           float* __restrict__ b_wr, const float* ga0, const float* ga1, const float* ga2,
-                                           const float* ga3, const float* gb, int a_idx, int b_idx, f32x16 (&acc)[TM][TN]) {
-  // SPREAD = 0: all loads of the next chunk up front; 1: two per MFMA group (a burst of 8 vector-memory instructions otherwise
-  // holds up the wave's in-order issue while the texture-address unit drains it)
-#define MP_LDSD_A01 __builtin_amdgcn_global_load_lds(MP_GPTR(ga0), MP_LPTR(a_wr), 16, 0, 0); \
-                    __builtin_amdgcn_global_load_lds(MP_GPTR(ga1), MP_LPTR(a_wr + 32 * BK), 16, 0, 0);
-#define MP_LDSD_A23 __builtin_amdgcn_global_load_lds(MP_GPTR(ga2), MP_LPTR(a_wr + 64 * BK), 16, 0, 0); \
-                    __builtin_amdgcn_global_load_lds(MP_GPTR(ga3), MP_LPTR(a_wr + 96 * BK), 16, 0, 0);
-#define MP_LDSD_B01 __builtin_amdgcn_global_load_lds(MP_GPTR(gb), MP_LPTR(b_wr), 16, 0, 0); \
-                    __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 1024), MP_LPTR(b_wr + 32 * BK), 16, 0, 0);
-#define MP_LDSD_B23 if constexpr (BN > 64) { \
-                      __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 2048), MP_LPTR(b_wr + 64 * BK), 16, 0, 0); \
-                      __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 3072), MP_LPTR(b_wr + 96 * BK), 16, 0, 0); }
-  if constexpr (SPREAD == 0) {
-    MP_LDSD_A01 MP_LDSD_A23 MP_LDSD_B01 MP_LDSD_B23
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int kk = 0; kk < BK / 8; ++kk) {
-    if constexpr (SPREAD == 1) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk == 0) { MP_LDSD_A01 }
-      if (kk == 1) { MP_LDSD_A23 }
-      if (kk == 2) { MP_LDSD_B01 }
-      if (kk == 3) { MP_LDSD_B23 }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    float4 af[TM], bf[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_rd + ((a_idx ^ (kk * 8)) + i * 32 * BK));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_rd + ((b_idx ^ (kk * 8)) + j * 32 * BK));
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-      }
-  }
-#undef MP_LDSD_A01
-#undef MP_LDSD_A23
-#undef MP_LDSD_B01
-#undef MP_LDSD_B23
-}
-
-template <int BN, int WM, int WN, bool RAGGED, int SPREAD = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma_ldsd(ConvParams p) {
-  constexpr int BM = 128;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-  constexpr int TM = WM / 32, TN = WN / 32;
-  __shared__ __attribute__((aligned(16))) float As0[BM * BK];
-  __shared__ __attribute__((aligned(16))) float As1[BM * BK];
-  __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
-  __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
-  __shared__ int row_off[BM];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / (BN / WN);
-  const int wn = wave % (BN / WN);
-  const int lb = xcd_remap(blockIdx.x, gridDim.x) + p.tile_begin;
-  const int nblk = lb % p.n_nblocks;
-  const int mblk = lb / p.n_nblocks;
-  const int m0 = mblk * BM;
-  const int n0 = nblk * BN;
-
-  const int a_r0 = tid >> 3;                                   // 0..31 (+32 i)
-  const int a_col = ((tid & 7) ^ ((tid >> 3) & 7)) * 4;        // swizzled float offset inside the 32-float chunk row
-  const float* a_ptr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + a_r0 + 32 * i;
-    m = m < p.M ? m : p.M - 1;
-    const int wo = m % p.Wo;
-    const int t = m / p.Wo;
-    const int ho = t % p.Ho;
-    const int n = t / p.Ho;
-    const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
-    a_ptr[i] = p.x + pix * p.C;
-  }
-  for (int r = tid; r < BM; r += 256) {
-    const int m = m0 + r;
-    int off = -1;
-    if (m < p.M) {
-      const int wo = m % p.Wo;
-      const int t = m / p.Wo;
-      const int ho = t % p.Ho;
-      const int n = t / p.Ho;
-      off = (((n * p.Hop) + ho + p.out_border) * p.Wop + wo + p.out_border) * p.Cout;
-    }
-    row_off[r] = off;
-  }
-  const float* bp = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;
-  const int row_stride = p.Wp * p.C;
-  const int row_wrap = row_stride - p.run;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int j = a_col, aoff = a_col, ju = 0;
-  if constexpr (RAGGED) {
-    while (j >= p.run) { j -= p.run; aoff += row_wrap; }
-  }
-  // wave-uniform LDS destinations of this wave's 8-row slabs
-  float* aw0 = As0 + wave * 8 * BK;
-  float* aw1 = As1 + wave * 8 * BK;
-  float* bw0 = Bs0 + wave * 8 * BK;
-  float* bw1 = Bs1 + wave * 8 * BK;
-  // prologue: chunk 0 -> stage 0
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[0] + aoff), MP_LPTR(aw0), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[1] + aoff), MP_LPTR(aw0 + 32 * BK), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[2] + aoff), MP_LPTR(aw0 + 64 * BK), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[3] + aoff), MP_LPTR(aw0 + 96 * BK), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(bp), MP_LPTR(bw0), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 1024), MP_LPTR(bw0 + 32 * BK), 16, 0, 0);
-  if constexpr (BN > 64) {
-    __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 2048), MP_LPTR(bw0 + 64 * BK), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 3072), MP_LPTR(bw0 + 96 * BK), 16, 0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int frag_row = lane & 31;
-  const int swz = ((lane >> 5) ^ (frag_row & 7)) * 4;   // (R + 32 i) & 7 == R & 7
-  const int a_idx = (wm * WM + frag_row) * BK + swz, b_idx = (wn * WN + frag_row) * BK + swz;
-
-#define MP_LDSD_ADVANCE(CH)                       \
-  if ((CH) + 1 < p.n_chunks) {                    \
-    bp += BN * BK;                                \
-    aoff += BK;                                   \
-    if constexpr (RAGGED) {                       \
-      j += BK;                                    \
-      while (j >= p.run) { j -= p.run; aoff += row_wrap; } \
-    } else {                                      \
-      ju += BK;                                   \
-      if (ju == p.run) { ju = 0; aoff += row_wrap; } \
-    }                                             \
-  }
-  for (int chunk = 0; chunk < p.n_chunks; chunk += 2) {
-    MP_LDSD_ADVANCE(chunk)   // chunk + 1 -> stage 1 while stage 0 is consumed (the last chunk harmlessly re-loads itself)
-    ldsd_chunk<BN, TM, TN, SPREAD>(As0, Bs0, aw1, bw1, a_ptr[0] + aoff, a_ptr[1] + aoff, a_ptr[2] + aoff, a_ptr[3] + aoff, bp, a_idx, b_idx, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (chunk + 1 >= p.n_chunks) break;
-    MP_LDSD_ADVANCE(chunk + 1)
-    ldsd_chunk<BN, TM, TN, SPREAD>(As1, Bs1, aw0, bw0, a_ptr[0] + aoff, a_ptr[1] + aoff, a_ptr[2] + aoff, a_ptr[3] + aoff, bp, a_idx, b_idx, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-#undef MP_LDSD_ADVANCE
-
-  const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
-  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
-  switch (emode) {
-    case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
-    case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
-    case 2: conv_epilogue<TM, TN, false, true, false>(p, acc, row_off, erow0, en0); break;
-    case 3: conv_epilogue<TM, TN, true, true, false>(p, acc, row_off, erow0, en0); break;
-    case 4: conv_epilogue<TM, TN, false, false, true>(p, acc, row_off, erow0, en0); break;
-    case 5: conv_epilogue<TM, TN, true, false, true>(p, acc, row_off, erow0, en0); break;
-    case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
-    default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
-  }
-}
-// s_waitcnt vmcnt(6) (expcnt / lgkmcnt untouched) + s_barrier as builtins, so that the compiler's own wait-count bookkeeping sees them
-// (an inline-asm wait is opaque to it and it re-inserts vmcnt(0) at the loop header); the empty asms are compiler-only memory fences
-#define MP_WAIT6_BARRIER()                     \
-  do {                                         \
-    asm volatile("" ::: "memory");             \
-    __builtin_amdgcn_s_waitcnt(0x0F76);        \
-    __builtin_amdgcn_s_barrier();              \
-    asm volatile("" ::: "memory");             \
-  } while (0)
-
-// 256 x 128 tile, 8 waves (4 x 2, each 64 x 64), THREE LDS-direct stages (prefetch distance 2 chunks, 145 KB LDS, one workgroup per
-// CU = 2 waves per SIMD as before) and 25 % fewer loads per MFMA than the 128 x 128 tile.  Cout >= 128, chunk-aligned K only.
-template <int TM, int TN>
-__device__ __forceinline__ void ldsd256_chunk(const float* __restrict__ a_rd, const float* __restrict__ b_rd, float* __restrict__ a_wr,
-                                              float* __restrict__ b_wr, const float* ga0, const float* ga1, const float* ga2,
-                                              const float* ga3, const float* gb, int a_idx, int b_idx, f32x16 (&acc)[TM][TN]) {
-  __builtin_amdgcn_global_load_lds(MP_GPTR(ga0), MP_LPTR(a_wr), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(ga1), MP_LPTR(a_wr + 64 * BK), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(ga2), MP_LPTR(a_wr + 128 * BK), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(ga3), MP_LPTR(a_wr + 192 * BK), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(gb), MP_LPTR(b_wr), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(MP_GPTR(gb + 2048), MP_LPTR(b_wr + 64 * BK), 16, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int kk = 0; kk < BK / 8; ++kk) {
-    float4 af[TM], bf[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_rd + ((a_idx ^ (kk * 8)) + i * 32 * BK));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_rd + ((b_idx ^ (kk * 8)) + j * 32 * BK));
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-      }
-  }
-}
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma_ldsd256(ConvParams p) {
-  constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
-  __shared__ __attribute__((aligned(16))) float As0[BM * BK];
-  __shared__ __attribute__((aligned(16))) float As1[BM * BK];
-  __shared__ __attribute__((aligned(16))) float As2[BM * BK];
-  __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
-  __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
-  __shared__ __attribute__((aligned(16))) float Bs2[BN * BK];
-  __shared__ int row_off[BM];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;      // 0..7
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int nblk = lb % p.n_nblocks;
-  const int mblk = lb / p.n_nblocks;
-  const int m0 = mblk * BM;
-  const int n0 = nblk * BN;
-
-  const int a_r0 = tid >> 3;                              // 0..63 (+64 i)
-  const int a_col = ((tid & 7) ^ ((tid >> 3) & 7)) * 4;   // swizzled float offset inside the 32-float chunk row
-  const float* a_ptr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + a_r0 + 64 * i;
-    m = m < p.M ? m : p.M - 1;
-    const int wo = m % p.Wo;
-    const int t = m / p.Wo;
-    const int ho = t % p.Ho;
-    const int n = t / p.Ho;
-    const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
-    a_ptr[i] = p.x + pix * p.C;
-  }
-  for (int r = tid; r < BM; r += 512) {
-    const int m = m0 + r;
-    int off = -1;
-    if (m < p.M) {
-      const int wo = m % p.Wo;
-      const int t = m / p.Wo;
-      const int ho = t % p.Ho;
-      const int n = t / p.Ho;
-      off = (((n * p.Hop) + ho + p.out_border) * p.Wop + wo + p.out_border) * p.Cout;
-    }
-    row_off[r] = off;
-  }
-  const float* bp = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;  // rows tid>>3 (+64): +2048 floats
-  const int row_stride = p.Wp * p.C;
-  const int row_wrap = row_stride - p.run;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int aoff = a_col, ju = 0;
-  float* aw0 = As0 + wave * 8 * BK;
-  float* aw1 = As1 + wave * 8 * BK;
-  float* aw2 = As2 + wave * 8 * BK;
-  float* bw0 = Bs0 + wave * 8 * BK;
-  float* bw1 = Bs1 + wave * 8 * BK;
-  float* bw2 = Bs2 + wave * 8 * BK;
-#define MP_LDSD_ADVANCE()                           \
-  if (loaded + 1 < p.n_chunks) {                    \
-    ++loaded;                                       \
-    bp += BN * BK;                                  \
-    aoff += BK;                                     \
-    ju += BK;                                       \
-    if (ju == p.run) { ju = 0; aoff += row_wrap; }  \
-  }
-#define MP_LDSD_ISSUE(AW, BW)                                                                     \
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[0] + aoff), MP_LPTR(AW), 16, 0, 0);              \
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[1] + aoff), MP_LPTR(AW + 64 * BK), 16, 0, 0);    \
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[2] + aoff), MP_LPTR(AW + 128 * BK), 16, 0, 0);   \
-  __builtin_amdgcn_global_load_lds(MP_GPTR(a_ptr[3] + aoff), MP_LPTR(AW + 192 * BK), 16, 0, 0);   \
-  __builtin_amdgcn_global_load_lds(MP_GPTR(bp), MP_LPTR(BW), 16, 0, 0);                           \
-  __builtin_amdgcn_global_load_lds(MP_GPTR(bp + 2048), MP_LPTR(BW + 64 * BK), 16, 0, 0);
-  int loaded = 0;  // index of the chunk the (aoff, bp) cursor points at; past the end it harmlessly re-loads the last chunk
-  MP_LDSD_ISSUE(aw0, bw0)
-  MP_LDSD_ADVANCE()
-  MP_LDSD_ISSUE(aw1, bw1)
-  // (not __syncthreads(): its release fence would wait for ALL vector-memory operations, i.e. also for the chunk just issued)
-  MP_WAIT6_BARRIER();  // chunk 0 has landed everywhere; chunk 1 may still be in flight
-
-  const int frag_row = lane & 31;
-  const int swz = ((lane >> 5) ^ (frag_row & 7)) * 4;
-  const int a_idx = (wm * 64 + frag_row) * BK + swz, b_idx = (wn * 64 + frag_row) * BK + swz;
-#define MP_LDSD_STEP(ARD, BRD, AWR, BWR)                                                                                              \
-  MP_LDSD_ADVANCE()                                                                                                                   \
-  ldsd256_chunk<TM, TN>(ARD, BRD, AWR, BWR, a_ptr[0] + aoff, a_ptr[1] + aoff, a_ptr[2] + aoff, a_ptr[3] + aoff, bp, a_idx, b_idx, acc); \
-  MP_WAIT6_BARRIER(); /* next chunk landed in every wave; the newest may be in flight */     \
-
-  for (int chunk = 0; chunk < p.n_chunks; chunk += 3) {
-    MP_LDSD_STEP(As0, Bs0, aw2, bw2)   // consume stage 0 (chunk), prefetch chunk + 2 into stage 2
-    if (chunk + 1 >= p.n_chunks) break;
-    MP_LDSD_STEP(As1, Bs1, aw0, bw0)
-    if (chunk + 2 >= p.n_chunks) break;
-    MP_LDSD_STEP(As2, Bs2, aw1, bw1)
-  }
-#undef MP_LDSD_STEP
-#undef MP_LDSD_ISSUE
-#undef MP_LDSD_ADVANCE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  const int erow0 = wm * 64 + (lane >> 5) * 4, en0 = n0 + wn * 64 + (lane & 31);
-  const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
-  switch (emode) {
-    case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
-    case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
-    case 2: conv_epilogue<TM, TN, false, true, false>(p, acc, row_off, erow0, en0); break;
-    case 3: conv_epilogue<TM, TN, true, true, false>(p, acc, row_off, erow0, en0); break;
-    case 4: conv_epilogue<TM, TN, false, false, true>(p, acc, row_off, erow0, en0); break;
-    case 5: conv_epilogue<TM, TN, true, false, true>(p, acc, row_off, erow0, en0); break;
-    case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
-    default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
-  }
-}
-
-static int launch_ldsd256(const ConvParams& p, hipStream_t s, double alg_k) {
-  ConvParams q = p;
-  q.n_mblocks = ceil_div(p.M, 256);
-  q.n_nblocks = ceil_div(p.Cout, 128);
-  ProfScope prof("conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * (double)p.M * p.Cout * alg_k,
-                 4.0 * ((double)p.M * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + (double)p.M * p.Cout), s);
-  hipLaunchKernelGGL(conv_nhwc_f32_mfma_ldsd256, dim3(q.n_mblocks * q.n_nblocks), dim3(512), 0, s, q);
-  MP_CHECK_HIP(hipGetLastError());
-  return MP_OK;
-}
-#undef MP_GPTR
-#undef MP_LPTR
-
-template <int BN, int WM, int WN, bool RAGGED, int SPREAD = 0>
-static int launch_ldsd(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_main = 0) {
-  ConvParams q = p;
-  q.n_mblocks = ceil_div(p.M, 128);
-  q.n_nblocks = ceil_div(p.Cout, BN);
-  const int n_tiles = n_tiles_main > 0 ? n_tiles_main : q.n_mblocks * q.n_nblocks;
-  const double m_here = n_tiles_main > 0 ? (double)(n_tiles_main / q.n_nblocks) * 128 : (double)p.M;
-  ProfScope prof(BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>", 2.0 * m_here * p.Cout * alg_k,
-                 4.0 * (m_here * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + m_here * p.Cout), s);
-  hipLaunchKernelGGL((conv_nhwc_f32_mfma_ldsd<BN, WM, WN, RAGGED, SPREAD>), dim3(n_tiles), dim3(256), 0, s, q);
-  MP_CHECK_HIP(hipGetLastError());
-  return MP_OK;
 }
 
 // sum of the k_split partial tiles in ascending split order + the fused epilogue (bias, residual, ReLU, pre-activation output)
@@ -989,26 +606,12 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     p.m_part_begin = plan.m_begin;
     return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
   }
-  static const int ldsd = getenv("MP_CONV_LDSD") ? atoi(getenv("MP_CONV_LDSD")) : 0;  // bit 0: 128x128 layers, bit 1: 128x64, bit 2: stems
-  if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
-    if (ldsd & 4) return small ? launch_ldsd<64, 64, 32, true>(p, s, alg_k) : launch_ldsd<128, 64, 64, true>(p, s, alg_k);
+  if (p.run % BK != 0)  // ragged K (stems): per-lane K bookkeeping
     return small ? launch<128, 64, 64, 32, 257, true>(p, s, alg_k) : launch<128, 128, 64, 64, 257, true>(p, s, alg_k);
-  }
-  if ((ldsd & 16) && !small && p.run % BK == 0) return launch_ldsd256(p, s, alg_k);
-  if (small ? (ldsd & 2) : (ldsd & 1)) {
-    if (ldsd & 8) return small ? launch_ldsd<64, 64, 32, false, 1>(p, s, alg_k) : launch_ldsd<128, 64, 64, false, 1>(p, s, alg_k);
-    return small ? launch_ldsd<64, 64, 32, false>(p, s, alg_k) : launch_ldsd<128, 64, 64, false>(p, s, alg_k);
-  }
-  switch (variant) {
+  switch (variant) {  // every variant computes the same result; 257 is the measured best, the others are kept for A/B timing
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
-    case 17: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 17>(p, s, alg_k);
-    case 33: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 33>(p, s, alg_k);
-    case 2: return small ? launch<128, 64, 64, 32, 2>(p, s, alg_k) : launch<128, 128, 64, 64, 2>(p, s, alg_k);
-    case 3: return small ? launch<128, 64, 64, 32, 3>(p, s, alg_k) : launch<128, 128, 64, 64, 3>(p, s, alg_k);
-    case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
-    case 5: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
-    case 6: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
     case 1: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
+    case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
     default: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);
   }
 }

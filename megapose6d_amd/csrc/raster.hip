@@ -349,7 +349,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
   const int lane = threadIdx.x & 63;
   // The list is only drained when the next scan chunk could overflow it (or at the end), so that the drain runs with (nearly)
   // all 512 threads busy instead of once per scan chunk with a fifth of them.
-  const int n_faces_eff = (flags & (1u << 16)) ? 0 : m.n_faces;
+  const int n_faces_eff = m.n_faces;
   if (threadIdx.x == 0) list_n = 0;
   __syncthreads();
   // scan: one 16-byte load = the packed bounds of 4 consecutive triangles per thread and chunk (the bounds array is padded to a
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     __syncthreads();
   }
   // ---- pass 1b: larger triangles: waves pull them from the queue, 64 lanes share one bbox -----------------
-  const int nbig = (flags & (1u << 17)) ? 0 : min(big_count, BIG_QUEUE);
+  const int nbig = min(big_count, BIG_QUEUE);
   for (;;) {
     int q = 0;
     if (lane == 0) q = atomicAdd(&q_head, 1);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     const int i = base + threadIdx.x;
     const bool live = i < npix;
     const int py = y0 + (live ? i : 0) / w, px = (live ? i : 0) % w;
-    const unsigned long long key = (live && !(flags & (1u << 18))) ? zbuf[i] : ~0ull;
+    const unsigned long long key = live ? zbuf[i] : ~0ull;
     float r = 0.f, g = 0.f, b = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, depth = 0.f;
     if (key != ~0ull) {
       const int t = (int)(key & 0xFFFFFFFFu);
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(BAND_THREADS) void raster_bands(
     float* st = stage + threadIdx.x * STAGE_CH;
     st[0] = r; st[1] = g; st[2] = b; st[3] = nx; st[4] = ny; st[5] = nz; st[6] = depth;
     __syncthreads();
-    const int n_here = (flags & (1u << 19)) ? 0 : min(BAND_THREADS, npix - base);
+    const int n_here = min(BAND_THREADS, npix - base);
     // 8 lanes per pixel (channel slot k = lane & 7, active while k < n_ch), 64 pixels per pass: consecutive lanes write
     // consecutive floats of one pixel, no per-element integer division (the chunk's first (row, col) is wave-uniform).
     const int k = threadIdx.x & 7;

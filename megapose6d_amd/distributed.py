@@ -51,6 +51,30 @@ def shard_size(n: int, r: int, world: int) -> int:
     return len(range(r, n, world))
 
 
+# Per-process gather statistics (bench.py reports them): number of all-gathers, payload bytes and -- when `timing` is switched
+# on -- the device time of each RCCL all-gather measured with HIP events on the stream it is issued on.
+class GatherStats:
+    def __init__(self) -> None:
+        self.timing = False
+        self.reset()
+
+    def reset(self) -> None:
+        self.calls = 0
+        self.bytes = 0
+        self.backend = None
+        self._events = []
+
+    def ms(self) -> float:
+        """sum of the recorded all-gather intervals (synchronises)"""
+        if not self._events:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self._events))
+
+
+stats = GatherStats()
+
+
 def gather_rows(local: torch.Tensor, n: int, r: int, world: int, group=None) -> torch.Tensor:
     """Inverse of shard_indices: every rank passes its [shard_size, k] rows and receives the full [n, k] table in
     original row order.  One all_gather of equally sized (padded) blocks."""
@@ -60,8 +84,19 @@ def gather_rows(local: torch.Tensor, n: int, r: int, world: int, group=None) -> 
     block = torch.zeros(per, k, dtype=local.dtype, device=local.device)
     block[: local.shape[0]] = local
     out = torch.empty(world * per, k, dtype=local.dtype, device=local.device)
-    if dist.get_backend(group) == "nccl":  # RCCL over xGMI: one fused all-gather
+    backend = dist.get_backend(group)
+    stats.calls += 1
+    stats.bytes += out.numel() * out.element_size()
+    stats.backend = backend
+    if backend == "nccl":  # RCCL over xGMI: one fused all-gather
+        ev = None
+        if stats.timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_gather_into_tensor(out, block, group=group)
+        if ev is not None:
+            ev[1].record()
+            stats._events.append(ev)
     else:  # gloo (CPU tests, or several ranks sharing one GPU in tests): gather through host memory
         host = torch.empty(world * per, k, dtype=local.dtype)
         _all_gather_cpu(host, block.cpu(), world, group)

@@ -255,6 +255,22 @@ def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int
         check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
 
 
+def conv2d_plan(N: int, H: int, W: int, Cp: int, in_border: int, Cout: int, K: int, stride: int, pad: int, n_cu: int,
+                ws_floats: int = 0) -> Dict[str, int]:
+    """How mp_conv2d_nhwc would lay this launch out on `n_cu` CUs (host-only, no GPU work): mode 0 single pass, 1 every tile
+    split along K, 2 full rounds + split-K tail."""
+    d = ConvDesc()
+    dummy = 0x1000  # the planner only tests pointers for NULL
+    d.d_x, d.N, d.H, d.W, d.C, d.in_border = dummy, N, H, W, Cp, in_border
+    d.d_w, d.Cout, d.KH, d.KW, d.stride, d.pad = dummy, Cout, K, K, stride, pad
+    d.d_y, d.out_border = dummy, 1
+    if ws_floats:
+        d.d_splitk_ws, d.splitk_ws_floats = dummy, ws_floats
+    out = (C.c_int32 * 5)()
+    check(_lib.load().mp_conv2d_plan(C.byref(d), n_cu, out))
+    return dict(zip(("mode", "k_split", "chunks_per_split", "n_main", "m_begin"), out))
+
+
 def conv_pack_weights_split(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
     """bf16 (hi, mid, lo) pieces for the split-precision conv; returns a uint8 blob"""
     lib = _lib.load()
@@ -309,6 +325,8 @@ class Backbone:
         if ws is None or ws.numel() < need or ws.device != torch.device(device):
             self._ws.pop(slot, None)
             self._ws[slot] = ws = torch.empty(need, dtype=torch.uint8, device=device)
+            # a NEW allocation: its borders are not zero even if the executor has seen this address before
+            check(_lib.load().mp_backbone_workspace_reset(self.handle, ws.data_ptr()))
         return ws
 
     def flops(self, batch: int, h: int, w: int) -> float:

@@ -61,8 +61,58 @@ class Config(SimpleNamespace):
         return Config(**{k: getattr(cfg, k) for k in dir(cfg) if not k.startswith("_") and not callable(getattr(cfg, k))})
 
 
+class _CfgLoader(yaml.SafeLoader):
+    """SafeLoader + the python-tagged nodes the reference's run directories contain.  The reference reads config.yaml with
+    yaml.UnsafeLoader (inference/utils.py:71-75), which instantiates arbitrary classes; released / cosypose-era runs store the
+    config as `!!python/object:...TrainingConfig` or `!!python/object:argparse.Namespace` with `pathlib.PosixPath` fields.  Those
+    tags are mapped to plain data here (object -> mapping, PosixPath -> str, tuple -> tuple, python/name -> its dotted name):
+    no class is imported and no callable is invoked."""
+
+
+def _construct_py_object(loader, suffix, node):
+    if isinstance(node, yaml.MappingNode):
+        m = loader.construct_mapping(node, deep=True)
+        for key in ("__dict__", "dictitems", "state"):   # object/new + state layouts
+            if isinstance(m.get(key), dict) and len(m) <= 3:
+                return m[key]
+        return m
+    if isinstance(node, yaml.SequenceNode):
+        return loader.construct_sequence(node, deep=True)
+    return loader.construct_scalar(node)
+
+
+def _construct_py_apply(loader, suffix, node):
+    if isinstance(node, yaml.SequenceNode):
+        args = loader.construct_sequence(node, deep=True)
+    elif isinstance(node, yaml.MappingNode):
+        m = loader.construct_mapping(node, deep=True)
+        args = m.get("args", [])
+        if "Namespace" in suffix or "dict" in suffix:
+            return m.get("kwds", m.get("state", m))
+    else:
+        args = [loader.construct_scalar(node)]
+    if "Path" in suffix:
+        return str(Path(*[str(a) for a in args])) if args else ""
+    if len(args) == 1:
+        return args[0]
+    return list(args)
+
+
+_CfgLoader.add_multi_constructor("tag:yaml.org,2002:python/object:", _construct_py_object)
+_CfgLoader.add_multi_constructor("tag:yaml.org,2002:python/object/new:", _construct_py_object)
+_CfgLoader.add_multi_constructor("tag:yaml.org,2002:python/object/apply:", _construct_py_apply)
+_CfgLoader.add_multi_constructor("tag:yaml.org,2002:python/name:", lambda loader, suffix, node: suffix)
+_CfgLoader.add_constructor("tag:yaml.org,2002:python/tuple", lambda loader, node: tuple(loader.construct_sequence(node, deep=True)))
+
+
 def load_cfg(path) -> Config:
-    data = yaml.safe_load(Path(path).read_text())
+    """run_dir/config.yaml -> Config (reference inference/utils.py:71-75).  Plain (OmegaConf-style) YAML mappings and the
+    python-tagged object dumps of older runs both load; anything else raises a ValueError naming the file."""
+    try:
+        data = yaml.load(Path(path).read_text(), Loader=_CfgLoader)
+    except yaml.YAMLError as e:
+        raise ValueError(f"{path}: unsupported config.yaml layout ({e}); expected a YAML mapping or a python-tagged "
+                         "TrainingConfig / argparse.Namespace dump") from e
     if not isinstance(data, dict):
         raise ValueError(f"{path}: expected a YAML mapping")
     return Config(**data)

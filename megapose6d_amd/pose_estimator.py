@@ -167,12 +167,38 @@ class PoseEstimator(torch.nn.Module):
             return mpdist.gather_rows(local, n, mpdist.rank(), mpdist.world_size())
         return local
 
+    # -- timing ---------------------------------------------------------------------------------------------------
+    # Reference semantics (pose_estimator.py:274-275, 422-423; training/utils.py:224-264): `model_time` is a CUDA-event time that is
+    # only measured with cuda_timer=True (0.0 otherwise), `render_time` and `time` are host wall clocks around SYNCHRONOUS work.
+    # Here every launch is asynchronous, so: cuda_timer=True -> each stage synchronises at its start and end and reports DEVICE
+    # times (render_time / model_time = sums of per-chunk HIP-event intervals around the raster+crop launch and the backbone,
+    # time = wall clock of the fenced stage); cuda_timer=False -> nothing synchronises, model_time = 0.0 like the reference and
+    # render_time / time are HOST ENQUEUE times (they say how long the host was busy, not how long the GPU took).
+    @staticmethod
+    def _sum_events(event_sets) -> Tuple[float, float]:
+        from .pose_rigid import PosePredictor
+
+        r = m = 0.0
+        for ev in event_sets:
+            dr, dm = PosePredictor.step_times(ev)
+            r += dr
+            m += dm
+        return r, m
+
+    def _is_sharded(self) -> bool:
+        return self.distributed and mpdist.world_size() > 1
+
     # -- coarse ---------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_coarse_model(self, observation: ObservationTensor, detections: DetectionsType, cuda_timer: bool = False,
                              return_debug_data: bool = False) -> Tuple[PoseEstimatesType, dict]:
+        if cuda_timer:
+            torch.cuda.synchronize()
         start = time.time()
         assert_detections_valid(detections)
+        if return_debug_data and self._is_sharded():
+            raise NotImplementedError("return_debug_data with distributed=True: crops/renders are shard-local (rows rank::world); "
+                                      "run the debug call on one rank with distributed=False")
         coarse = self.coarse_model
         device = observation.images.device
         B, M = len(detections), self._SO3_grid.shape[0]
@@ -183,30 +209,32 @@ class PoseEstimator(torch.nn.Module):
         df_h["bbox_id"] = np.repeat(df.index.values, M)
         n = B * M
         labels_det = df["label"].tolist()
+        im_det = df["batch_im_id"].values.astype(np.int32)
+        rows_h = self._shard(n)                       # host copies of every index table: no D2H read-back inside the chunk loop
+        det_h = rows_h // M
         det_mesh = torch.tensor(self.mesh_db.ids(labels_det), dtype=torch.int32, device=device)
-        det_im = torch.as_tensor(df["batch_im_id"].values.astype(np.int32), device=device)
-        rows = torch.as_tensor(self._shard(n), device=device, dtype=torch.long)
-        det_of_row = torch.div(rows, M, rounding_mode="floor")
-        rot_of_row = (rows % M).to(torch.int32)
+        det_of_row = torch.as_tensor(det_h, device=device, dtype=torch.long)
+        rot_of_row = torch.as_tensor((rows_h % M).astype(np.int32), device=device)
+        im_of_row = torch.as_tensor(im_det[det_h], device=device)
         bboxes_all = detections.bboxes.to(device=device, dtype=torch.float32)
-        K_rows = observation.K[det_im[det_of_row].long()].float()
+        K_rows = observation.K[im_of_row.long()].float()
         TCO_local = eng.init_poses_from_boxes(bboxes_all[det_of_row], K_rows, det_mesh[det_of_row], rot_of_row, self._SO3_grid,
                                               self._grid_extents())
         logits_l, scores_l = [], []
-        crops, renders = [], []
+        crops, renders, event_sets = [], [], []
         render_time = model_time = 0.0
-        chunk, streams = self._plan(rows.numel(), self.bsz_images)
+        chunk, streams = self._plan(rows_h.size, self.bsz_images)   # after the inputs above are enqueued: side streams wait for them
         n_batches = 0
-        for ci, s in enumerate(range(0, rows.numel(), chunk)):
-            sl = slice(s, min(s + chunk, rows.numel()))
-            d = det_of_row[sl]
-            labels_ = [labels_det[i] for i in d.tolist()]
+        for ci, s in enumerate(range(0, rows_h.size, chunk)):
+            sl = slice(s, min(s + chunk, rows_h.size))
+            labels_ = [labels_det[i] for i in det_h[sl]]
             slot = ci % len(streams)
             with torch.cuda.stream(streams[slot]):
                 out_ = coarse.forward_coarse(images=observation.images, K=K_rows[sl], labels=labels_, TCO_input=TCO_local[sl],
-                                             cuda_timer=cuda_timer, return_debug_data=return_debug_data, im_ids=det_im[d], slot=slot)
+                                             cuda_timer=cuda_timer, return_debug_data=return_debug_data, im_ids=im_of_row[sl], slot=slot,
+                                             defer_timing=True)
             render_time += out_["render_time"]
-            model_time += out_["model_time"]
+            event_sets.append(out_["events"])
             logits_l.append(out_["logits"])
             scores_l.append(out_["scores"])
             if return_debug_data:
@@ -227,6 +255,9 @@ class PoseEstimator(torch.nn.Module):
         host = torch.stack([logits.flatten(), scores.flatten()]).cpu().numpy()  # the stage's single D2H sync
         df_h["coarse_logit"] = host[0]
         df_h["coarse_score"] = host[1]
+        if cuda_timer:
+            torch.cuda.synchronize()
+            render_time, model_time = self._sum_events(event_sets)
         elapsed = time.time() - start
         timing_str = f"time: {elapsed:.2f}, model_time: {model_time:.2f}, render_time: {render_time:.2f}"
         extra_data = {"render_time": render_time, "model_time": model_time, "time": elapsed, "logits": logits, "scores": scores,
@@ -237,37 +268,43 @@ class PoseEstimator(torch.nn.Module):
     @torch.no_grad()
     def forward_refiner(self, observation: ObservationTensor, data_TCO_input: PoseEstimatesType, n_iterations: int = 5,
                         keep_all_outputs: bool = False, cuda_timer: bool = False, **refiner_kwargs) -> Tuple[dict, dict]:
+        if cuda_timer:
+            torch.cuda.synchronize()
         start = time.time()
         assert self.refiner_model is not None
+        if keep_all_outputs and self._is_sharded():
+            raise NotImplementedError("keep_all_outputs with distributed=True: the per-batch outputs are shard-local")
         device = observation.images.device
         R = data_TCO_input.poses.shape[0]
-        chunk, streams = self._plan(len(self._shard(R)), self.bsz_objects)
+        rows_h = self._shard(R)
         df = data_TCO_input.infos.copy()  # the reference adds these two columns to its per-batch copies (:155-156)
-        df["refiner_batch_idx"] = np.arange(R) // chunk
-        df["refiner_instance_idx"] = np.arange(R) % chunk
         labels_all = df["label"].tolist()
-        im_all = torch.as_tensor(df["batch_im_id"].values.astype(np.int32), device=device)
-        rows = torch.as_tensor(self._shard(R), device=device, dtype=torch.long)
+        im_h = df["batch_im_id"].values.astype(np.int32)
+        im_all = torch.as_tensor(im_h, device=device)
+        rows = torch.as_tensor(rows_h, device=device, dtype=torch.long)
         poses_in = data_TCO_input.poses.to(device=device, dtype=torch.float32)
         K_all = observation.K[im_all.long()].float()
-        keys = ("poses", "poses_input", "K_crop", "boxes_rend", "boxes_crop")
+        K_rows, poses_rows, im_rows = K_all[rows], poses_in[rows], im_all[rows]
+        chunk, streams = self._plan(rows_h.size, self.bsz_objects)   # after the inputs above are enqueued (side streams wait for them)
+        df["refiner_batch_idx"] = np.arange(R) // chunk
+        df["refiner_instance_idx"] = np.arange(R) % chunk
+        keys = ("poses", "poses_input", "K_crop", "boxes_rend", "boxes_crop", "pose_out")
         acc: Dict[int, Dict[str, list]] = {n: {k: [] for k in keys} for n in range(1, n_iterations + 1)}
         all_outputs = []
-        model_time = 0.0
-        ev = None
-        if cuda_timer:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        event_sets = []
+        render_time = model_time = 0.0
         produced = []
-        for ci, s in enumerate(range(0, rows.numel(), chunk)):
-            r = rows[s : s + chunk]
-            labels_ = [labels_all[i] for i in r.tolist()]
+        for ci, s in enumerate(range(0, rows_h.size, chunk)):
+            sl = slice(s, min(s + chunk, rows_h.size))
+            labels_ = [labels_all[i] for i in rows_h[sl]]
             slot = ci % len(streams)
             with torch.cuda.stream(streams[slot]):
-                outputs_ = self.refiner_model(images=observation.images, K=K_all[r], TCO=poses_in[r], n_iterations=n_iterations,
-                                              labels=labels_, im_ids=im_all[r], materialize=keep_all_outputs, slot=slot, **refiner_kwargs)
+                outputs_ = self.refiner_model(images=observation.images, K=K_rows[sl], TCO=poses_rows[sl], n_iterations=n_iterations,
+                                              labels=labels_, im_ids=im_rows[sl], materialize=keep_all_outputs, slot=slot,
+                                              cuda_timer=cuda_timer, **refiner_kwargs)
             for o in outputs_.values():
                 produced += [o.TCO_output, o.TCO_input, o.KV_crop, o.boxes_rend, o.boxes_crop, o.renders, o.images_crop]
+                produced += list(o.network_outputs.values())
             if keep_all_outputs:
                 all_outputs.append(outputs_)
             for n in range(1, n_iterations + 1):
@@ -278,23 +315,32 @@ class PoseEstimator(torch.nn.Module):
                 a["K_crop"].append(o.K_crop)
                 a["boxes_rend"].append(o.boxes_rend)
                 a["boxes_crop"].append(o.boxes_crop)
+                a["pose_out"].append(o.network_outputs["pose"] if "pose" in o.network_outputs else
+                                     torch.zeros(o.TCO_output.shape[0], 9, device=device))
+                render_time += o.timing_dict["render"]
+                event_sets.append(o.timing_dict.get("events"))
         self._join(streams, produced)
-        if cuda_timer:
-            ev[1].record()
-            torch.cuda.synchronize()
-            model_time = ev[0].elapsed_time(ev[1]) / 1000.0
         preds = dict()
+        pose_outputs = dict()
         for n in range(1, n_iterations + 1):
             a = acc[n]
             packed = torch.cat([torch.cat(a["poses"]).flatten(1), torch.cat(a["poses_input"]).flatten(1), torch.cat(a["K_crop"]).flatten(1),
-                                torch.cat(a["boxes_rend"]), torch.cat(a["boxes_crop"])], dim=1) if rows.numel() else torch.zeros(0, 49, device=device)
+                                torch.cat(a["boxes_rend"]), torch.cat(a["boxes_crop"]), torch.cat(a["pose_out"])],
+                               dim=1) if rows_h.size else torch.zeros(0, 58, device=device)
             packed = self._gather(packed, R)
             preds[f"iteration={n}"] = PandasTensorCollection(
                 df, poses=packed[:, 0:16].reshape(R, 4, 4).contiguous(), poses_input=packed[:, 16:32].reshape(R, 4, 4).contiguous(),
                 K_crop=packed[:, 32:41].reshape(R, 3, 3).contiguous(), K=K_all, boxes_rend=packed[:, 41:45].contiguous(),
                 boxes_crop=packed[:, 45:49].contiguous())
+            pose_outputs[f"iteration={n}"] = packed[:, 49:58].contiguous()
+        if cuda_timer:
+            torch.cuda.synchronize()
+            render_time, model_time = self._sum_events(event_sets)
         elapsed = time.time() - start
-        extra_data = {"n_iterations": n_iterations, "outputs": all_outputs, "model_time": model_time, "time": elapsed}
+        # `pose_outputs` (engine extension): the refiner network's raw 9-vector per row and iteration, [R, 9] -- what the parity
+        # checks compare before the pose update damps it (PosePredictorOutput.network_outputs["pose"], pose_rigid.py:50-66)
+        extra_data = {"n_iterations": n_iterations, "outputs": all_outputs, "model_time": model_time, "render_time": render_time,
+                      "time": elapsed, "pose_outputs": pose_outputs}
         return preds, extra_data
 
     # -- scoring --------------------------------------------------------------------------------------------------
@@ -302,29 +348,36 @@ class PoseEstimator(torch.nn.Module):
     def forward_scoring_model(self, observation: ObservationTensor, data_TCO: PoseEstimatesType, cuda_timer: bool = False,
                               return_debug_data: bool = False) -> Tuple[PoseEstimatesType, dict]:
         """Adds 'pose_logit' / 'pose_score' to data_TCO.infos (modifies the collection in place, :217-322)."""
+        if cuda_timer:
+            torch.cuda.synchronize()
         start = time.time()
         assert self.coarse_model is not None
+        if return_debug_data and self._is_sharded():
+            raise NotImplementedError("return_debug_data with distributed=True: crops/renders are shard-local (rows rank::world)")
         device = observation.images.device
         df = data_TCO.infos
         R = len(df)
         labels_all = df["label"].tolist()
-        im_all = torch.as_tensor(df["batch_im_id"].values.astype(np.int32), device=device)
-        rows = torch.as_tensor(self._shard(R), device=device, dtype=torch.long)
+        im_h = df["batch_im_id"].values.astype(np.int32)
+        rows_h = self._shard(R)
+        im_all = torch.as_tensor(im_h, device=device)
+        rows = torch.as_tensor(rows_h, device=device, dtype=torch.long)
         poses = data_TCO.poses.to(device=device, dtype=torch.float32)
         K_all = observation.K[im_all.long()].float()
-        chunk, streams = self._plan(rows.numel(), self.bsz_images)
-        logits_l, scores_l, crops, renders = [], [], [], []
+        K_rows, poses_rows, im_rows = K_all[rows], poses[rows], im_all[rows]
+        chunk, streams = self._plan(rows_h.size, self.bsz_images)
+        logits_l, scores_l, crops, renders, event_sets = [], [], [], [], []
         render_time = model_time = 0.0
         n_batches = 0
-        for ci, s in enumerate(range(0, rows.numel(), chunk)):
-            r = rows[s : s + chunk]
+        for ci, s in enumerate(range(0, rows_h.size, chunk)):
+            sl = slice(s, min(s + chunk, rows_h.size))
             slot = ci % len(streams)
             with torch.cuda.stream(streams[slot]):
-                out_ = self.coarse_model.forward_coarse(images=observation.images, K=K_all[r], labels=[labels_all[i] for i in r.tolist()],
-                                                        TCO_input=poses[r], cuda_timer=cuda_timer, return_debug_data=return_debug_data,
-                                                        im_ids=im_all[r], slot=slot)
+                out_ = self.coarse_model.forward_coarse(images=observation.images, K=K_rows[sl], labels=[labels_all[i] for i in rows_h[sl]],
+                                                        TCO_input=poses_rows[sl], cuda_timer=cuda_timer, return_debug_data=return_debug_data,
+                                                        im_ids=im_rows[sl], slot=slot, defer_timing=True)
             render_time += out_["render_time"]
-            model_time += out_["model_time"]
+            event_sets.append(out_["events"])
             logits_l.append(out_["logits"])
             scores_l.append(out_["scores"])
             if return_debug_data:
@@ -332,7 +385,7 @@ class PoseEstimator(torch.nn.Module):
                 renders.append(out_["renders"])
             n_batches += 1
         self._join(streams, logits_l + scores_l + crops + renders)
-        packed = torch.cat([torch.cat(logits_l), torch.cat(scores_l)], dim=1) if rows.numel() else torch.zeros(0, 2, device=device)
+        packed = torch.cat([torch.cat(logits_l), torch.cat(scores_l)], dim=1) if rows_h.size else torch.zeros(0, 2, device=device)
         packed = self._gather(packed, R)
         logits, scores = packed[:, 0:1].contiguous(), packed[:, 1:2].contiguous()
         debug_data = dict()
@@ -341,6 +394,9 @@ class PoseEstimator(torch.nn.Module):
         host = packed.cpu().numpy()
         df["pose_logit"] = host[:, 0]
         df["pose_score"] = host[:, 1]
+        if cuda_timer:
+            torch.cuda.synchronize()
+            render_time, model_time = self._sum_events(event_sets)
         elapsed = time.time() - start
         timing_str = f"time: {elapsed:.2f}, model_time: {model_time:.2f}, render_time: {render_time:.2f}"
         extra_data = {"render_time": render_time, "model_time": model_time, "time": elapsed, "logits": logits, "scores": scores,

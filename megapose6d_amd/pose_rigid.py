@@ -221,9 +221,12 @@ class PosePredictor(nn.Module):
 
     # -- the fused step ------------------------------------------------------------------------------------------
     def _step(self, images: torch.Tensor, im_ids: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO_in: torch.Tensor,
-              want_sigmoid: bool, slot: int = 0):
+              want_sigmoid: bool, slot: int = 0, events: bool = False):
         """images [n_im,C,H,W] (C already trimmed to the model's input channels), im_ids [b] row -> image.
-        Returns dict of device tensors; the CNN input stays in self._x."""
+        Returns dict of device tensors; the CNN input stays in self._x.
+        `events=True` records three HIP events on the launch stream (before the render+crop launch, after it, after the
+        backbone) so that the caller can report DEVICE render / model times (`step_times`); without them `render_time`
+        is the host time spent enqueueing the render (the launch is asynchronous, unlike the reference's Panda3D call)."""
         device = TCO_in.device
         b = TCO_in.shape[0]
         V = self.n_rendered_views
@@ -238,12 +241,18 @@ class PosePredictor(nn.Module):
         # the observation crop (channels 0..nin-1) is written by the rasteriser launch below (one launch fills the whole CNN input)
         nin, nper = self._n_input_channels, self._n_single_render_channels
         t0 = time.time()
+        ev = None
+        if events:
+            ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+            ev[0].record()
         view_ids = ren_ids.repeat_interleave(V) if V > 1 else ren_ids
         self.renderer.render_into(view_ids, TCV_O.view(b * V, 4, 4), KV_crop.view(b * V, 3, 3), self._lights(), (h, w), x, s_row,
                                   s_y, s_x, nin, nin + 3 if self.render_normals else -1,
                                   nin + (6 if self.render_normals else 3) if self.render_depth else -1, off,
                                   views_per_item=V, stride_view=nper, slot=slot, crop=(self._packed(images), im_ids, boxes_crop, 0))
         render_time = time.time() - t0
+        if ev is not None:
+            ev[1].record()
         mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
         bb = self._backbone_engine()
         depth_ch = []
@@ -258,8 +267,17 @@ class PosePredictor(nn.Module):
         out = torch.empty(b, n_out, dtype=torch.float32, device=device)
         sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
         bb.forward(x, b, h, w, out, sig, slot=slot)
+        if ev is not None:
+            ev[2].record()
         return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,
-                    sigmoid=sig, render_time=render_time)
+                    sigmoid=sig, render_time=render_time, events=ev)
+
+    @staticmethod
+    def step_times(events) -> Tuple[float, float]:
+        """(render_s, model_s) of one step from the events `_step(events=True)` recorded; the caller must have synchronised."""
+        if events is None:
+            return 0.0, 0.0
+        return events[0].elapsed_time(events[1]) / 1000.0, events[1].elapsed_time(events[2]) / 1000.0
 
     def _prep_images(self, images: torch.Tensor) -> torch.Tensor:
         if not self.input_depth:
@@ -270,10 +288,11 @@ class PosePredictor(nn.Module):
     @torch.no_grad()
     def forward(self, images: torch.Tensor, K: torch.Tensor, labels: List[str], TCO: torch.Tensor, n_iterations: int = 1,
                 random_ambient_light: bool = False, im_ids: Optional[torch.Tensor] = None,
-                materialize: bool = True, slot: int = 0) -> Dict[str, PosePredictorOutput]:
+                materialize: bool = True, slot: int = 0, cuda_timer: bool = False) -> Dict[str, PosePredictorOutput]:
         """Same contract as the reference forward (pose_rigid.py:498-604).  Engine extensions: `im_ids` lets several rows
         share one observation frame (images is then [n_im,C,H,W] and K stays per-row); `materialize=False` skips the
-        clones of the crops/renders (they stay valid only until the next step)."""
+        clones of the crops/renders (they stay valid only until the next step); `cuda_timer=True` attaches the step's HIP
+        events to `timing_dict["events"]` (resolve with `PosePredictor.step_times` after a synchronise)."""
         if random_ambient_light:
             raise NotImplementedError("random_ambient_light is a training-time augmentation")
         images = self._prep_images(images)
@@ -287,7 +306,7 @@ class PosePredictor(nn.Module):
         TCO_input = TCO
         nin = self._n_input_channels
         for n in range(n_iterations):
-            st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=False, slot=slot)
+            st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=False, slot=slot, events=cuda_timer)
             K_crop = st["KV_crop"][:, 0]
             if self.predict_pose_update:
                 TCO_output = eng.pose_update(st["TCO_n"], st["KV_crop"], st["out"], st["tCR"], 9 * self.n_rendered_views)
@@ -305,14 +324,14 @@ class PosePredictor(nn.Module):
                 renders=renders, images_crop=images_crop, TCO_input=st["TCO_n"], TCO_output=TCO_output, TCV_O_input=st["TCV_O"],
                 tCR=st["tCR"], labels=labels, K=K, K_crop=K_crop, KV_crop=st["KV_crop"], network_outputs=network_outputs,
                 boxes_rend=st["boxes_rend"], boxes_crop=st["boxes_crop"], renderings_logits=renderings_logits,
-                timing_dict={"render": st["render_time"]})
+                timing_dict={"render": st["render_time"], "events": st["events"]})
             TCO_input = TCO_output
         return outputs
 
     @torch.no_grad()
     def forward_coarse(self, images: torch.Tensor, K: torch.Tensor, labels: List[str], TCO_input: torch.Tensor,
                        cuda_timer: bool = False, return_debug_data: bool = False,
-                       im_ids: Optional[torch.Tensor] = None, slot: int = 0) -> Dict[str, Any]:
+                       im_ids: Optional[torch.Tensor] = None, slot: int = 0, defer_timing: bool = False) -> Dict[str, Any]:
         """pose_rigid.py:634-708: logits/scores [b,1] of each hypothesis."""
         assert self.predict_rendered_views_logits, "Method only valid if coarse classification model"
         images = self._prep_images(images)
@@ -321,18 +340,18 @@ class PosePredictor(nn.Module):
         if im_ids is None:
             assert images.shape[0] == bsz
             im_ids = torch.arange(bsz, dtype=torch.int32, device=TCO_input.device)
-        ev0 = ev1 = None
-        if cuda_timer:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True, slot=slot)
-        elapsed = 0.0
-        if cuda_timer:
-            ev1.record()
+        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True, slot=slot, events=cuda_timer)
+        # cuda_timer=True: `events` lets the caller resolve DEVICE render / model times once per stage (PoseEstimator does, after
+        # its single synchronisation); a direct caller gets them here at the price of a synchronise, like the reference's
+        # CudaTimer.end() (training/utils.py:224-264).  cuda_timer=False: model_time = 0.0 as in the reference, render_time =
+        # host time to enqueue the (asynchronous) render launch.
+        out = {"logits": st["out"], "scores": st["sigmoid"], "time": 0.0, "render_time": st["render_time"], "model_time": 0.0,
+               "TCO_n": st["TCO_n"], "K_crop": st["KV_crop"][:, 0], "boxes_rend": st["boxes_rend"], "boxes_crop": st["boxes_crop"],
+               "events": st["events"]}
+        if cuda_timer and not defer_timing:
             torch.cuda.synchronize()
-            elapsed = ev0.elapsed_time(ev1) / 1000.0
-        out = {"logits": st["out"], "scores": st["sigmoid"], "time": elapsed, "render_time": st["render_time"], "model_time": elapsed,
-               "TCO_n": st["TCO_n"], "K_crop": st["KV_crop"][:, 0], "boxes_rend": st["boxes_rend"], "boxes_crop": st["boxes_crop"]}
+            out["render_time"], out["model_time"] = self.step_times(st["events"])
+            out["time"] = out["model_time"]
         if return_debug_data:
             nin = self._n_input_channels
             out["images_crop"] = self._nchw_view(bsz, 0, nin, slot).clone()

@@ -18,7 +18,7 @@ from .types import ObservationTensor, Panda3dLightData
 
 
 def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
-                    seeds=(11, 12), precision: int = 0, **est_kwargs) -> PoseEstimator:
+                    seeds=(11, 12), precision: int = 0, pose_head_scale: float = 0.001, **est_kwargs) -> PoseEstimator:
     """Seeded random-weight coarse + refiner models in the released recipes' structure, on the HIP engine."""
     renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
     mesh_db = MeshDataBase.from_object_ds(object_dataset).batched().cuda()
@@ -26,7 +26,7 @@ def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bo
     for role, seed in zip(("coarse", "refiner"), seeds):
         cfg = syn.make_cfg(role, backbone, rgbd=(rgbd and role == "refiner"))
         head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
-        sd = syn.make_state_dict(backbone, syn.n_inputs_for(cfg), head, n_out, seed=seed)
+        sd = syn.make_state_dict(backbone, syn.n_inputs_for(cfg), head, n_out, seed=seed, pose_head_scale=pose_head_scale)
         models[role] = build_pose_model(cfg, sd, renderer, mesh_db)
         models[role].conv_precision = precision
     return PoseEstimator(refiner_model=models["refiner"], coarse_model=models["coarse"], SO3_grid_size=SO3_grid_size, **est_kwargs)
@@ -78,3 +78,31 @@ def make_scene(n_objects: int = 1, seed: int = 0, backbone: str = "vanilla_resne
     obs = ObservationTensor(images, torch.from_numpy(K)[None].cuda())
     det = make_detections(labels, bboxes).cuda()
     return est, obs, det, poses
+
+
+def make_multi_frame_scene(n_frames: int = 8, n_per_frame: int = 8, n_meshes: int = 16, seed: int = 40, backbone: str = "vanilla_resnet34",
+                           rgbd: bool = False, SO3_grid_size: int = 576, tmp_dir: Optional[str] = None, **est_kwargs):
+    """BASELINE.json configs[3]/[4] shape: `n_frames` 640x480 frames with `n_per_frame` detections each over `n_meshes` distinct
+    meshes (every mesh appears n_frames * n_per_frame / n_meshes times).  -> (estimator, observation, detections, object dataset)"""
+    import pandas as pd
+
+    from .tcoll import PandasTensorCollection
+
+    tmp = Path(tmp_dir or tempfile.mkdtemp(prefix="mp_scene_mf_"))
+    ds = syn.make_object_dataset(tmp, n_objects=n_meshes, seed=seed, n_theta=48, n_z=50)
+    est = build_estimator(ds, backbone, rgbd, SO3_grid_size, **est_kwargs)
+    r = est.coarse_model.renderer
+    rng = np.random.RandomState(seed - 31)
+    K = syn.K_EXAMPLE.astype(np.float32)
+    labels_all = [o.label for o in ds.list_objects]
+    frames, rows, boxes = [], [], []
+    for f in range(n_frames):
+        labs = [labels_all[(2 * f + j) % n_meshes] for j in range(n_per_frame)]
+        poses = np.stack([syn.random_pose(rng, (0.5, 0.8), 0.3) for _ in labs])
+        im, bb = render_observation(r, labs, poses, K, seed=f, with_depth=rgbd)
+        frames.append(im)
+        rows += [dict(label=l, batch_im_id=f) for l in labs]
+        boxes.append(bb)
+    obs = ObservationTensor(torch.cat(frames), torch.from_numpy(np.repeat(K[None], n_frames, 0)).cuda())
+    det = PandasTensorCollection(pd.DataFrame(rows), bboxes=torch.from_numpy(np.concatenate(boxes)).cuda())
+    return est, obs, det, ds

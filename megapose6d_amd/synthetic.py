@@ -246,10 +246,13 @@ def _linear(sd, g, prefix, out_f, in_f, scale=1.0):
     sd[prefix + ".bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * bound * scale
 
 
-def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: int = 0,
+                    pose_head_scale: float = 0.001) -> Dict[str, torch.Tensor]:
     """state_dict of a PosePredictor (backbone.* + pose_fc.* | views_logits_head.*), seeded.
     BN running stats are non-trivial so folding is exercised; the pose head is initialised near the identity update
-    (bias = ortho6d identity, vx=vy=0, vz=1) so chained refiner iterations stay in the frustum."""
+    (bias = ortho6d identity, vx=vy=0, vz=1) so chained refiner iterations stay in the frustum (SURVEY.md 8c);
+    `pose_head_scale` is the damping of its weights (1e-3 by default; the teacher-forced parity tests use >= 0.02 so that a
+    conv error reaches the pose undamped)."""
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     B = "backbone."
@@ -289,7 +292,7 @@ def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: i
     else:
         raise ValueError(backbone_str)
     if head == "pose":
-        _linear(sd, g, "pose_fc", 9, 512, scale=0.001)
+        _linear(sd, g, "pose_fc", 9, 512, scale=pose_head_scale)
         sd["pose_fc.bias"] = sd["pose_fc.bias"] + torch.tensor([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0])
     else:
         _linear(sd, g, "views_logits_head", n_out, 512)

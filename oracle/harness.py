@@ -1,0 +1,113 @@
+"""Builds the CPU oracle estimator for a synthetic object dataset + the row-sampled comparisons the parity checks use.
+TEST INFRASTRUCTURE ONLY (imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline/parity leg)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import geometry as og
+from . import pipeline as op
+from . import raster as orr
+
+
+def make_oracle_models(ds, backbone: str = "vanilla_resnet34", rgbd: bool = False, seeds=(11, 12), pose_head_scale: float = 0.001,
+                       renderer_kwargs: Optional[dict] = None):
+    """-> (coarse OraclePosePredictor, refiner OraclePosePredictor, batched mesh db) with the SAME seeded weights that
+    megapose6d_amd.scene.build_estimator gives the HIP engine."""
+    from megapose6d_amd import mesh_io
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.mesh_db import MeshDataBase
+
+    meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}
+    db = MeshDataBase.from_object_ds(ds).batched()
+    rend = orr.OracleBatchRenderer(meshes, **(renderer_kwargs or {}))
+    preds = {}
+    for role, seed in zip(("coarse", "refiner"), seeds):
+        cfg = syn.make_cfg(role, backbone, rgbd=(rgbd and role == "refiner"))
+        head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
+        sd = syn.make_state_dict(backbone, syn.n_inputs_for(cfg), head, n_out, seed=seed, pose_head_scale=pose_head_scale)
+        preds[role] = op.OraclePosePredictor(cfg, sd, db.labels.tolist(), db.points, rend)
+    return preds["coarse"], preds["refiner"], db
+
+
+def make_oracle_estimator(ds, grid_size: int, backbone: str = "vanilla_resnet34", rgbd: bool = False, bsz: int = 24, **kw):
+    from megapose6d_amd.pose_estimator import load_SO3_grid
+
+    coarse, refiner, db = make_oracle_models(ds, backbone, rgbd, **kw)
+    return op.OraclePoseEstimator(coarse, refiner, load_SO3_grid(grid_size), bsz=bsz), db
+
+
+@torch.no_grad()
+def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor, K_im: torch.Tensor, bboxes: torch.Tensor,
+                        extra: dict, coarse_rows: Sequence[int], refine_rows: Sequence[int], n_iterations: int) -> Dict[str, object]:
+    """Compare a finished HIP pipeline call (`extra` = its extra_data, run at ANY size) with the oracle restricted to sampled rows.
+
+    coarse_rows: indices into the B*M coarse table (detection-major).  refine_rows: indices into the FILTERED table the HIP
+    call refined (`extra["coarse_filter"]["preds"]`); the oracle starts each chain from the oracle's own initial pose of that
+    (detection, hypothesis) and runs all iterations + the re-score on the CPU.
+    Returns max errors: coarse_TCO, coarse_logit (abs, and the logit scale), pose per iteration (abs on the 4x4),
+    pose_out per iteration (the network's raw 9-vector), score_logit."""
+    cpred, rpred = oest.coarse, oest.refiner
+    M = oest.grid.shape[0]
+    cd = extra["coarse"]
+    dfc = cd["preds"].infos.reset_index(drop=True)
+    res: Dict[str, object] = {"n_coarse_rows": len(coarse_rows), "n_refine_rows": len(refine_rows)}
+
+    def init_pose(det_ids, hyp_ids, labels, im):
+        obj = torch.tensor([cpred.label_to_id[l] for l in labels])
+        return og.TCO_init_from_boxes_autodepth_with_R(bboxes[det_ids].float(), cpred.points[obj], K_im[im], oest.grid[hyp_ids])
+
+    def batches(n, b):
+        return [slice(s, min(s + b, n)) for s in range(0, n, b)]
+
+    if len(coarse_rows):
+        rows = np.asarray(coarse_rows)
+        sub = dfc.iloc[rows]
+        labels = sub["label"].tolist()
+        im = torch.as_tensor(sub["batch_im_id"].values.astype(np.int64))
+        T0 = init_pose(rows // M, rows % M, labels, im)
+        gT = cd["preds"].poses[rows].cpu()
+        res["coarse_TCO_max_err"] = (gT - T0).abs().max().item()
+        lo = torch.cat([cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T0[s])["logits"] for s in batches(len(rows), oest.bsz)])
+        lg = cd["data"]["logits"].flatten()[rows].cpu()
+        res["logit_scale"] = max(1.0, lo.abs().max().item())
+        res["coarse_logit_max_err"] = (lg - lo.flatten()).abs().max().item()
+    if len(refine_rows):
+        rows = np.asarray(refine_rows)
+        dff = extra["coarse_filter"]["preds"].infos.reset_index(drop=True).iloc[rows]
+        labels = dff["label"].tolist()
+        im = torch.as_tensor(dff["batch_im_id"].values.astype(np.int64))
+        # detection index of a filtered row = position of its bbox_id in the detections table
+        det_index = {b: i for i, b in enumerate(dict.fromkeys(dfc["bbox_id"].tolist()))}
+        det_ids = np.asarray([det_index[b] for b in dff["bbox_id"].tolist()])
+        T0 = init_pose(det_ids, dff["hypothesis_id"].values, labels, im)
+        preds = extra["refiner_all_hypotheses"]["preds"]
+        pouts = extra["refiner_all_hypotheses"]["data"].get("pose_outputs", {})
+        outs = []
+        for s in batches(len(rows), oest.bsz_refiner):
+            outs.append(rpred.forward(images, im[s], K_im[im[s]], labels[s], T0[s], n_iterations))
+        pose_err, out_err = [], []
+        for n in range(n_iterations):
+            To = torch.cat([o[n]["TCO_output"] for o in outs])
+            po = torch.cat([o[n]["net"]["pose"] for o in outs])
+            pose_err.append((preds[f"iteration={n + 1}"].poses[rows].cpu() - To).abs().max().item())
+            if f"iteration={n + 1}" in pouts:
+                out_err.append((pouts[f"iteration={n + 1}"][rows].cpu() - po).abs().max().item())
+        res["pose_max_err_per_iter"], res["pose_out_max_err_per_iter"] = pose_err, out_err
+        T_ref = torch.cat([o[-1]["TCO_output"] for o in outs])
+        sl = torch.cat([cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T_ref[s])["logits"] for s in batches(len(rows), oest.bsz)])
+        sg = extra["scoring"]["data"]["logits"].flatten()[rows].cpu()
+        res["logit_scale"] = max(res.get("logit_scale", 1.0), sl.abs().max().item())
+        res["score_logit_max_err"] = (sg - sl.flatten()).abs().max().item()
+    return res
+
+
+def parity_ok(res: Dict[str, object], tol: float = 1e-4) -> bool:
+    """north_star tolerance: 1e-4 on the pose tensors; logits 1e-4 relative to the logit scale"""
+    scale = float(res.get("logit_scale", 1.0))
+    ok = res.get("coarse_TCO_max_err", 0.0) < tol
+    ok = ok and res.get("coarse_logit_max_err", 0.0) < tol * scale and res.get("score_logit_max_err", 0.0) < tol * scale
+    ok = ok and all(e < tol for e in res.get("pose_max_err_per_iter", []))
+    return bool(ok)

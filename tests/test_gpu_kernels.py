@@ -371,22 +371,26 @@ def test_backbone_bf16x9_matches_oracle(eng):
     assert (out.cpu() - ref["pose"]).abs().max().item() < 2e-4
 
 
-def test_conv_full_rounds_plus_splitk_tail(eng):
-    """a grid of 600 tiles on 512 resident workgroups: the first 512 tiles run single-pass, the 88 tail tiles split K three ways and
-    are reduced deterministically; the result must equal the plain single launch up to summation order"""
+@pytest.mark.parametrize("shape", [(64, 64, 60, 80), (128, 128, 30, 40), (256, 256, 15, 20), (128, 256, 15, 20)])
+def test_conv_full_rounds_plus_splitk_tail(eng, shape):
+    """a grid of ~600 tiles on 512 resident workgroups: the first 512 tiles run single-pass, the ~88 tail tiles split K and are
+    reduced deterministically ("mode 2" of plan_conv); checked against torch fp32 for the Cout = 64 tile AND the 128x128 tile
+    (Cout = 128 / 256: the launch mode the 576-row layer-2/3 convs of BASELINE config 2 take)"""
     n_cu = eng.device_info()[0]
     g = torch.Generator().manual_seed(5)
-    Cin = Cout = 64
-    H, W = 60, 80
-    N = -(-(2 * n_cu + 88) * 128 // (H * W))      # enough rows for 2*n_cu + ~88 tiles of 128 pixels
+    Cin, Cout, H, W = shape
+    n_nb = max(1, Cout // 128)
+    N = -(-((2 * n_cu + 88) // n_nb) * 128 // (H * W))      # enough rows for 2*n_cu + ~88 tiles of 128 pixels
     x = torch.randn(N, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
     res = torch.randn(N, Cout, H, W, generator=g)
     bias = torch.randn(Cout, generator=g) * 0.1
     xb = _to_padded(eng, x, Cin, 1)
     rb = _to_padded(eng, res, Cout, 1)
     wp = torch.from_numpy(eng.conv_pack_weights(w.numpy(), Cin, None)).cuda()
-    ws = torch.empty(12 << 20, device="cuda")
+    ws = torch.empty(24 << 20, device="cuda")
+    plan = eng.conv2d_plan(N, H, W, Cin, 1, Cout, 3, 1, 1, n_cu, ws.numel())
+    assert plan["mode"] == 2 and plan["k_split"] >= 2, plan
     outs = []
     for scratch in (None, ws, ws):
         yb = eng.padded_nhwc(N, H, W, Cout, 1, "cuda")

@@ -1,0 +1,118 @@
+"""-m gpu: the HIP path against the CPU ORACLE at BASELINE.json's full sizes (576-rotation grid, 576-row launches).
+
+The oracle cannot run 4 032 CNN rows in a test, so every case runs the HIP pipeline at FULL size and the oracle on SAMPLED rows of
+that very call (`oracle.harness.sampled_rows_parity`): because every (object, hypothesis) row is independent the
+sampled rows see exactly the launch modes of the full-size call (single-pass 5 400-tile conv grids, "full rounds + split-K tail",
+the 576-row raster/crop launch).  Tolerances = BASELINE.json north_star: 1e-4 on the pose tensors, logits 1e-4 x logit scale.
+Reference being matched: inference/pose_estimator.py:324-483 (coarse), :101-215 (refiner), :217-322 (scoring)."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _check(res):
+    scale = res["logit_scale"]
+    assert res.get("coarse_TCO_max_err", 0.0) < 1e-5, res
+    assert res.get("coarse_logit_max_err", 0.0) < TOL * scale, res
+    assert res.get("score_logit_max_err", 0.0) < TOL * scale, res
+    for n, e in enumerate(res.get("pose_max_err_per_iter", [])):
+        assert e < TOL, (n, res)
+    for n, e in enumerate(res.get("pose_out_max_err_per_iter", [])):
+        assert e < TOL, (n, res)
+
+
+def test_config2_rgb_1x576x5_sampled_rows_vs_oracle():
+    """BASELINE configs[1] exactly as bench.py runs it: vanilla ResNet-34, 1 object, all 576 hypotheses refined 5 iterations"""
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.scene import make_scene
+    from oracle import harness
+
+    tmp = tempfile.mkdtemp(prefix="mp_p2_")
+    est, obs, det, _ = make_scene(n_objects=1, seed=0, SO3_grid_size=576, tmp_dir=tmp)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=576)
+    ds = syn.make_object_dataset(tmp, n_objects=1, seed=0)
+    oest, db = harness.make_oracle_estimator(ds, 576, bsz=16)
+    res = harness.sampled_rows_parity(oest, db, obs.images.cpu(), obs.K.cpu(), det.bboxes.cpu(), extra,
+                                      coarse_rows=[0, 1, 97, 255, 256, 383, 511, 575], refine_rows=[0, 191, 320, 575], n_iterations=5)
+    _check(res)
+    assert len(res["pose_out_max_err_per_iter"]) == 5
+
+
+def test_config3_rgbd_wide_resnet_8x576_sampled_rows_vs_oracle():
+    """BASELINE configs[2]: RGB coarse + 32-channel RGBD refiner on WideResNet-34, 8 objects x 576 hypotheses, all refined"""
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.scene import make_scene
+    from oracle import harness
+
+    tmp = tempfile.mkdtemp(prefix="mp_p3_")
+    est, obs, det, _ = make_scene(n_objects=8, seed=7, backbone="resnet34", rgbd=True, SO3_grid_size=576, tmp_dir=tmp)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=576)
+    assert len(extra["refiner_all_hypotheses"]["preds"]["iteration=5"]) == 8 * 576
+    ds = syn.make_object_dataset(tmp, n_objects=8, seed=7)
+    oest, db = harness.make_oracle_estimator(ds, 576, backbone="resnet34", rgbd=True, bsz=16)
+    res = harness.sampled_rows_parity(oest, db, obs.images.cpu(), obs.K.cpu(), det.bboxes.cpu(), extra,
+                                      coarse_rows=[5, 576 + 200, 3 * 576 + 575, 7 * 576 + 1], refine_rows=[3, 2 * 576 + 17, 5 * 576 + 300, 8 * 576 - 1],
+                                      n_iterations=5)
+    _check(res)
+
+
+def test_config4_64_detections_two_detections_vs_oracle():
+    """BASELINE configs[3] (K = 5): 64 detections / 8 frames / 16 meshes; the oracle re-computes two detections completely from the
+    top-K on (sampled coarse rows, all 5 refiner chains x 5 iterations, re-score) and must pick the same final hypothesis"""
+    from megapose6d_amd.scene import make_multi_frame_scene
+    from oracle import harness
+
+    tmp = tempfile.mkdtemp(prefix="mp_p4_")
+    est, obs, det, ds = make_multi_frame_scene(8, 8, 16, SO3_grid_size=576, tmp_dir=tmp)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=5)
+    assert len(final) == 64
+    oest, db = harness.make_oracle_estimator(ds, 576, bsz=16)
+    dff = extra["coarse_filter"]["preds"].infos.reset_index(drop=True)
+    bbox_ids = list(dict.fromkeys(extra["coarse"]["preds"].infos["bbox_id"].tolist()))
+    for d in (3, 42):
+        rows = np.nonzero(dff["bbox_id"].values == bbox_ids[d])[0].tolist()
+        assert len(rows) == 5
+        hyp = dff["hypothesis_id"].values[rows]
+        res = harness.sampled_rows_parity(oest, db, obs.images.cpu(), obs.K.cpu(), det.bboxes.cpu(), extra,
+                                          coarse_rows=[d * 576 + int(h) for h in hyp[:3]] + [d * 576 + 11], refine_rows=rows, n_iterations=5)
+        _check(res)
+
+
+def test_teacher_forced_iterations_with_undamped_pose_head():
+    """The synthetic pose head is damped 1e-3 so chained parity mostly tests geometry.  Here the head is scaled 0.03
+    (30x; a conv error reaches the 9-vector and the pose almost undamped) and every iteration is TEACHER-FORCED: the HIP refiner gets
+    the oracle's input pose of iteration n inside a 576-row launch and its raw network output and updated pose are compared with the
+    oracle's iteration n.  Reference: models/pose_rigid.py:498-604 (forward), :305-312 (update_pose)."""
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.scene import make_scene
+    from oracle import harness
+
+    tmp = tempfile.mkdtemp(prefix="mp_tf_")
+    est, obs, det, gt = make_scene(n_objects=1, seed=0, SO3_grid_size=72, tmp_dir=tmp, pose_head_scale=0.03)
+    ds = syn.make_object_dataset(tmp, n_objects=1, seed=0)
+    _, rpred, db = harness.make_oracle_models(ds, pose_head_scale=0.03)
+    label = ds[0].label
+    rng = np.random.RandomState(3)
+    T0 = torch.from_numpy(np.stack([gt[0]] * 4)).clone()
+    T0[:, :3, 3] += torch.from_numpy(rng.uniform(-0.015, 0.015, size=(4, 3)).astype(np.float32))
+    K1 = obs.K.cpu()
+    n_it = 3
+    outs = rpred.forward(obs.images.cpu(), torch.zeros(4, dtype=torch.long), K1.repeat(4, 1, 1), [label] * 4, T0, n_it)
+    # an undamped head must actually move the pose (otherwise this test would be as blunt as the damped one)
+    assert (outs[0]["TCO_output"] - outs[0]["TCO_n"]).abs().max().item() > 2e-3
+    pos = [0, 191, 383, 575]
+    filler = torch.from_numpy(np.stack([syn.random_pose(rng, (0.45, 0.7), 0.1) for _ in range(576)]))
+    for n in range(n_it):
+        T_in = filler.clone()
+        T_in[pos] = T0 if n == 0 else outs[n - 1]["TCO_output"]
+        o = est.refiner_model(images=obs.images, K=obs.K.repeat(576, 1, 1), labels=[label] * 576, TCO=T_in.cuda(), n_iterations=1,
+                              im_ids=torch.zeros(576, dtype=torch.int32, device="cuda"), materialize=False)["iteration=1"]
+        e_out = (o.network_outputs["pose"][pos].cpu() - outs[n]["net"]["pose"]).abs().max().item()
+        e_pose = (o.TCO_output[pos].cpu() - outs[n]["TCO_output"]).abs().max().item()
+        assert e_out < TOL, (n, e_out)
+        assert e_pose < TOL, (n, e_pose)

@@ -193,16 +193,19 @@ def test_smoke_entry():
     ge.smoke()
 
 
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, backend="gloo"):
     import os
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    local = rank if backend == "nccl" else 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     from megapose6d_amd.scene import make_scene
 
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the single test GPU -> gloo, not RCCL
+    torch.cuda.set_device(local)
+    # gloo: both ranks share the single test GPU (RCCL needs one device per rank); nccl: one GPU per rank, RCCL all-gathers
+    dist.init_process_group(backend, rank=rank, world_size=world)
     est, obs, det, _ = make_scene(n_objects=2, seed=7, SO3_grid_size=72, distributed=True)
     final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=3)
     q.put((rank, final.poses.cpu().numpy(), extra["coarse"]["data"]["logits"].cpu().numpy(), final.infos["hypothesis_id"].tolist()))
@@ -210,9 +213,14 @@ def _dist_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_row_sharded_pipeline_two_ranks_matches_single_rank():
-    """the N>1 path (rows rank::world + one all-gather per stage) must reproduce the single-rank result exactly"""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_row_sharded_pipeline_two_ranks_matches_single_rank(backend):
+    """the N>1 path (rows rank::world + one all-gather per stage) must reproduce the single-rank result exactly;
+    `nccl` (= RCCL, all_gather_into_tensor on device buffers) needs two visible GPUs and is skipped on a 1-GPU box"""
     import os
+
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
 
     import torch.multiprocessing as mp
 
@@ -224,7 +232,7 @@ def test_row_sharded_pipeline_two_ranks_matches_single_rank():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + os.getpid() % 1000
-    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
@@ -257,3 +265,33 @@ def test_pipeline_split_precision_modes_match_reference_golden(precision):
         p = extra["refiner_all_hypotheses"]["preds"][f"iteration={n}"]
         assert np.abs(p.poses.cpu().numpy()[order] - g[f"refiner_poses_{n}"]).max() < 1e-4, n
     assert np.abs(final.poses.cpu().numpy() - g["final_TCO"]).max() < 1e-4
+
+
+def test_bench_self_launches_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` outside torchrun must spawn its own ranks (torch.distributed.run, backend nccl) and print ONE line
+    with n_gpus = 2 and the RCCL world size; skipped on a 1-GPU box"""
+    import json
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl"]["backend"] == "nccl" and j["rccl"]["world_size"] == 2 and j["rccl"]["all_gathers_per_step"] >= 3
+    assert j["config"]["objects"] == 2
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)

@@ -366,3 +366,31 @@ def test_conv_launch_plan_small_grids_and_half_empty_last_rounds():
     assert _plan(1, 30, 40, 64, 128, 1, 2)[0] == 0
     # scratch too small for two partial copies -> single pass
     assert _plan(1, 8, 10, 512, 512, 3, 1, ws_floats=80 * 512)[0] == 0
+
+
+def test_load_cfg_reads_python_tagged_legacy_configs_without_instantiating_them(tmp_path):
+    """reference inference/utils.py:71-75 reads config.yaml with yaml.UnsafeLoader; older runs are python-tagged object dumps"""
+    import argparse
+    import pathlib
+
+    import yaml
+
+    from megapose6d_amd.load_model import load_cfg
+
+    ns = argparse.Namespace(backbone_str="resnet34", n_rendered_views=4, save_dir=pathlib.PosixPath("/a/b"), hw=(240, 320), opt=dict(lr=0.1))
+    (tmp_path / "ns.yaml").write_text(yaml.dump(ns))
+    c = load_cfg(tmp_path / "ns.yaml")
+    assert (c.backbone_str, c.n_rendered_views, c.save_dir, c.hw, c.opt) == ("resnet34", 4, "/a/b", (240, 320), {"lr": 0.1})
+    (tmp_path / "plain.yaml").write_text("backbone_str: vanilla_resnet34\nn_rendered_views: 1\n")
+    assert load_cfg(tmp_path / "plain.yaml").backbone_str == "vanilla_resnet34"
+    # a tag that would execute code under UnsafeLoader is mapped to data, never called
+    (tmp_path / "evil.yaml").write_text("a: !!python/object/apply:os.system ['echo pwned > /tmp/mp_pwned']\n")
+    import os
+
+    if os.path.exists("/tmp/mp_pwned"):
+        os.remove("/tmp/mp_pwned")
+    c = load_cfg(tmp_path / "evil.yaml")
+    assert not os.path.exists("/tmp/mp_pwned") and c.a == "echo pwned > /tmp/mp_pwned"
+    (tmp_path / "bad.yaml").write_text("- 1\n- 2\n")
+    with pytest.raises(ValueError):
+        load_cfg(tmp_path / "bad.yaml")
