@@ -1,4 +1,5 @@
-"""Micro-benchmark of the rasteriser with phase-skip debug bits (profiling aid)."""
+"""Micro-benchmark of the rasteriser on crop-like (zoomed) views: ms per launch of 2304 views = 576 items x 4 views written
+into a 32-channel CNN input tensor, and the algorithmic-bytes bandwidth (output channels + mesh once per view)."""
 import sys
 from pathlib import Path
 
@@ -18,16 +19,16 @@ K = torch.tensor([[1500.0, 0, 160], [0, 1500.0, 120], [0, 0, 1]]).repeat(n, 1, 1
 ids = torch.zeros(n, dtype=torch.int32, device="cuda")
 out = torch.zeros(n // 4, 246, 326, 32, device="cuda")
 L = eng.make_lights()
-names = {0: "full", 1 << 16: "skip pass1", 1 << 17: "skip wave-queue", (1 << 16) | (1 << 17): "skip pass1+1b", 1 << 18: "skip shading",
-         1 << 19: "skip stores", (1 << 18) | (1 << 19): "skip shading+stores", (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19): "skip all"}
-for dbg, name in names.items():
-    for rep in range(2):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        eng.raster_render(db, ids, T, K, 240, 320, 1 | dbg, L, out, 246 * 326 * 32, 326 * 32, 32, 3, 6, -1, (3 * 326 + 3) * 32,
+flags_list = [int(a) for a in sys.argv[1:]] or [1]
+for flags in flags_list:
+    for rep in range(3):
+        eng.profile_begin()
+        eng.raster_render(db, ids, T, K, 240, 320, flags, L, out, 246 * 326 * 32, 326 * 32, 32, 3, 6, -1, (3 * 326 + 3) * 32,
                           views_per_item=4, stride_view=6)
-        e1.record()
-        torch.cuda.synchronize()
-    print(f"{name:22s} {e0.elapsed_time(e1):8.3f} ms for {n} views")
+        prof = eng.profile_end()
+    tot = sum(v["ms"] for v in prof.values())
+    by = sum(v["bytes"] for k, v in prof.items() if k.startswith("raster_bands") or k.startswith("raster_tiles"))
+    print(f"flags={flags}: {tot:8.3f} ms for {n} views  ({by / tot / 1e6:.0f} GB/s algorithmic)  " +
+          ", ".join(f"{k} {v['ms']:.3f}" for k, v in prof.items()))
 cov = (out[..., 3:6].sum(-1) > 0).float().mean().item()
 print("coverage of view 0 channel block:", cov)
