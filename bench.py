@@ -77,24 +77,24 @@ def cpu_baseline(ds, obs_images: torch.Tensor, K: torch.Tensor, bboxes: torch.Te
         def coarse(n, poses):
             t0 = time.perf_counter()
             o = cpred.forward_coarse(images, im[:n], Kc[:1].repeat(n, 1, 1), [label] * n, poses[:n])
-            return time.perf_counter() - t0, o["logits"].flatten()
+            return time.perf_counter() - t0, o["logits"].flatten(), o["net"]["features"].abs().max().item()
 
         coarse(2, T)  # warm-up
         t_row = coarse(4, T)[0] / 4  # probe
         n_coarse = int(max(4, min(n_max, 0.35 * budget_s / max(t_row, 1e-4))))
         n_refine = int(max(1, min(8, 0.65 * budget_s / max(t_row * 4.5 * (N_ITERS + 1), 1e-4))))
-        t_coarse, coarse_logits = coarse(n_coarse, T)
+        t_coarse, coarse_logits, fs1 = coarse(n_coarse, T)
         t0 = time.perf_counter()
         outs = rpred.forward(images, im[:n_refine], Kc[:1].repeat(n_refine, 1, 1), [label] * n_refine, T[:n_refine], N_ITERS)
         t_refine = time.perf_counter() - t0
-        t_score, score_logits = coarse(n_refine, outs[-1]["TCO_output"])
+        t_score, score_logits, fs2 = coarse(n_refine, outs[-1]["TCO_output"])
     t_full = t_coarse * (N_HYP / n_coarse) + (t_refine + t_score) * (N_HYP / n_refine)
     return {"value": N_HYP / t_full, "unit": "pose-hypotheses/s", "cores": threads, "kind": "port",
             "sample": f"{n_coarse} of 576 coarse rows + {n_refine} of 576 hypotheses x {N_ITERS} refine iters + {n_refine} score rows, "
                       f"{t_coarse + t_refine + t_score:.1f} s of CPU work on {threads} threads ({os.cpu_count()} host cores), extrapolated "
                       "linearly per stage; Panda3D replaced by the oracle's C rasteriser",
             "_values": {"coarse_TCO": T[:n_coarse], "coarse_logits": coarse_logits, "refine_poses": [o["TCO_output"] for o in outs],
-                        "refine_pose_out": [o["net"]["pose"] for o in outs], "score_logits": score_logits}}
+                        "refine_pose_out": [o["net"]["pose"] for o in outs], "score_logits": score_logits, "feature_scale": max(fs1, fs2)}}
 
 
 def parity_block(vals: dict, extra: dict) -> dict:
@@ -102,16 +102,17 @@ def parity_block(vals: dict, extra: dict) -> dict:
     cd = extra["coarse"]
     n_c = vals["coarse_logits"].numel()
     lo = vals["coarse_logits"]
-    scale = max(1.0, lo.abs().max().item())
+    # logits are linear read-outs of the 512-d features: their fp32 round-off scales with the feature magnitude
+    scale = max(1.0, lo.abs().max().item(), float(vals.get("feature_scale", 0.0)))
     out = {"rows": {"coarse": n_c, "refine_chains": len(vals["score_logits"]), "iterations": len(vals["refine_poses"])},
            "tolerance": PARITY_TOL, "logit_scale": scale}
     out["coarse_TCO_max_err"] = (cd["preds"].poses[:n_c].cpu() - vals["coarse_TCO"]).abs().max().item()
     out["coarse_logit_max_err"] = (cd["data"]["logits"].flatten()[:n_c].cpu() - lo).abs().max().item()
     # the GPU call refined the hypotheses in top-K order: find hypotheses 0..n-1 of detection 0 in its filtered table
     dff = extra["coarse_filter"]["preds"].infos.reset_index(drop=True)
-    first_det = dff["bbox_id"].iloc[0] if len(dff) else None
     n_r = len(vals["score_logits"])
-    pos = [int(np.nonzero((dff["hypothesis_id"].values == h) & (dff["bbox_id"].values == dff["bbox_id"].values.min()))[0][0]) for h in range(n_r)]
+    det0 = dff["bbox_id"].values == dff["bbox_id"].values.min()
+    pos = [int(np.nonzero((dff["hypothesis_id"].values == h) & det0)[0][0]) for h in range(n_r)]
     preds = extra["refiner_all_hypotheses"]["preds"]
     pouts = extra["refiner_all_hypotheses"]["data"]["pose_outputs"]
     out["pose_max_err_per_iter"] = [(preds[f"iteration={n + 1}"].poses[pos].cpu() - vals["refine_poses"][n]).abs().max().item()

@@ -1,0 +1,455 @@
+// raster_core.h -- the arithmetic of the rasteriser's pixel contract (v2), shared by the HIP kernels (raster.hip) and by a
+// host emulation of those kernels that the CPU tests run against the independent oracle (oracle/raster.c) without a GPU
+// (tests/raster_emul.cpp).  Everything here is plain scalar code: geometry set-up incl. near-plane clipping, exact edge
+// functions, the per-sample depth rule, per-(pixel, piece) shading and the multisample resolve.  The contract itself is stated
+// at the top of oracle/raster.c; reference lines: panda3d_renderer/panda3d_scene_renderer.py:71-74, 99-136, 210-216,
+// panda3d_batch_renderer.py:109-135, 261-274, types.py:63-64, utils.py:44-68.
+// Built with -ffp-contract=off on both sides: every fused operation is an explicit fmaf().
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define MP_HD __host__ __device__ __forceinline__
+#else
+#define MP_HD static inline
+#endif
+
+#ifndef MP_TEX_MAX_LEVELS
+#define MP_TEX_MAX_LEVELS 15
+#endif
+
+namespace mp {
+namespace rc {
+
+constexpr int SUBPIX = 256;
+constexpr float GUARD = 16384.f;  // |screen coord| limit (pixels) of the fixed-point path
+constexpr float Z_NEAR = 0.1f, Z_FAR = 10.0f;
+constexpr int TILE = 8;           // raster tile = 8 x 8 pixels = one wave
+
+// sample positions inside a pixel, 1/256 px: index 0 = single-sample pattern, 1..4 = the standard 4x pattern
+MP_HD int sample_off_x(int ns, int s) { return ns == 1 ? 128 : (s == 0 ? 96 : s == 1 ? 224 : s == 2 ? 32 : 160); }
+MP_HD int sample_off_y(int ns, int s) { return ns == 1 ? 128 : (s == 0 ? 32 : s == 1 ? 96 : s == 2 ? 160 : 224); }
+MP_HD int sample_off_min(int ns) { return ns == 1 ? 128 : 32; }
+MP_HD int sample_off_max(int ns) { return ns == 1 ? 128 : 224; }
+
+struct MeshRef {
+  const float* verts;
+  const float* normals;
+  const float* colors;
+  const int32_t* faces;
+  int n_verts, n_faces;
+  float radius;
+  const float* uvs;  // per-corner uv [n_faces][3][2] or NULL
+};
+
+struct TexRef {
+  const uint32_t* texels;
+  int tex_w, tex_h, tex_levels;
+  int tex_off[MP_TEX_MAX_LEVELS];
+};
+
+struct Lights {
+  float ambient[3];
+  int n_point;
+  float dir[8][3];
+  float color[8][3];
+  float offset[8][3];
+};
+
+// One piece of a triangle as seen by one view: snapped screen coordinates (positively oriented), 1/z per vertex and the
+// depth-tie id.  `bary[k][j]` = weight of the ORIGINAL corner j in piece vertex k (a permutation matrix when unclipped).
+struct Piece {
+  int X[3], Y[3];
+  float iz[3];
+  int id;   // < 0: no piece
+  int tri;
+  float bary[3][3];
+};
+
+MP_HD int imin(int a, int b) { return a < b ? a : b; }
+MP_HD int imax(int a, int b) { return a > b ? a : b; }
+
+MP_HD float dot3p(float a0, float a1, float a2, float x, float y, float z, float t) { return fmaf(a2, z, fmaf(a1, y, fmaf(a0, x, t))); }
+
+struct CVert {
+  float x, y, z;
+  float bary[3];
+};
+
+MP_HD CVert clip_edge(const CVert& in, const CVert& out, int i_in, int i_out) {
+  CVert r;
+  const float t = (Z_NEAR - in.z) / (out.z - in.z);
+  r.x = fmaf(t, out.x - in.x, in.x);
+  r.y = fmaf(t, out.y - in.y, in.y);
+  r.z = Z_NEAR;
+  r.bary[0] = r.bary[1] = r.bary[2] = 0.f;
+  r.bary[i_in] = 1.0f - t;
+  r.bary[i_out] = t;
+  return r;
+}
+
+// project + snap + orient; id < 0 on rejection
+template <bool WITH_BARY>
+MP_HD void finish_piece(const CVert& v0, const CVert& v1, const CVert& v2, const float* Kv, int tri, int id, Piece& p) {
+  p.id = -1;
+  p.tri = tri;
+  const CVert* v[3] = {&v0, &v1, &v2};
+  int X[3], Y[3];
+  float iz[3];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    iz[k] = 1.0f / v[k]->z;
+    const float sx = fmaf(Kv[0], v[k]->x * iz[k], Kv[2]);
+    const float sy = fmaf(Kv[4], v[k]->y * iz[k], Kv[5]);
+    ok = ok && (fabsf(sx) < GUARD) && (fabsf(sy) < GUARD);
+    X[k] = (int)rintf(sx * (float)SUBPIX);
+    Y[k] = (int)rintf(sy * (float)SUBPIX);
+  }
+  if (!ok) return;
+  const long long area = (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]) - (long long)(Y[1] - Y[0]) * (long long)(X[2] - X[0]);
+  if (area == 0) return;
+  const bool swap = area < 0;
+  const int o1 = swap ? 2 : 1, o2 = swap ? 1 : 2;
+  p.X[0] = X[0]; p.Y[0] = Y[0]; p.iz[0] = iz[0];
+  p.X[1] = X[o1]; p.Y[1] = Y[o1]; p.iz[1] = iz[o1];
+  p.X[2] = X[o2]; p.Y[2] = Y[o2]; p.iz[2] = iz[o2];
+  if (WITH_BARY) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      p.bary[0][j] = v[0]->bary[j];
+      p.bary[1][j] = v[o1]->bary[j];
+      p.bary[2][j] = v[o2]->bary[j];
+    }
+  }
+  p.id = id;
+}
+
+// Piece `which` (0 = first, 1 = second) of triangle `tri` under pose T / intrinsics Kv.  Stateless: the binning pass, the
+// coverage pass and the shading pass each recompute the piece they need from the mesh (which stays L2-resident) instead of
+// round-tripping per-view set-up records through HBM.
+template <bool WITH_BARY>
+MP_HD int make_piece(const MeshRef& m, const float* T, const float* Kv, int tri, int which, Piece& p) {
+  // returns how many pieces the triangle has at most under this view (0, 1 or 2; a piece can still be rejected: p.id < 0)
+  p.id = -1;
+  p.tri = tri;
+  CVert c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vi = m.faces[3 * tri + k];
+    const float px = m.verts[3 * vi], py = m.verts[3 * vi + 1], pz = m.verts[3 * vi + 2];
+    c[k].x = dot3p(T[0], T[1], T[2], px, py, pz, T[3]);
+    c[k].y = dot3p(T[4], T[5], T[6], px, py, pz, T[7]);
+    c[k].z = dot3p(T[8], T[9], T[10], px, py, pz, T[11]);
+    c[k].bary[0] = c[k].bary[1] = c[k].bary[2] = 0.f;
+    c[k].bary[k] = 1.0f;
+  }
+  const bool in0 = c[0].z >= Z_NEAR, in1 = c[1].z >= Z_NEAR, in2 = c[2].z >= Z_NEAR;
+  const int n_in = (int)in0 + (int)in1 + (int)in2;
+  if (n_in == 3) {
+    if (which == 0) finish_piece<WITH_BARY>(c[0], c[1], c[2], Kv, tri, tri, p);
+    return 1;
+  }
+  if (n_in == 0) return 0;
+  if (n_in == 1) {
+    if (which != 0) return 1;
+    const int a = in0 ? 0 : (in1 ? 1 : 2), b = (a + 1) % 3, d = (a + 2) % 3;  // cyclic order a, b, d; a inside
+    const CVert P = clip_edge(c[a], c[b], a, b), Q = clip_edge(c[a], c[d], a, d);
+    finish_piece<WITH_BARY>(c[a], P, Q, Kv, tri, tri, p);
+    return 1;
+  }
+  const int o = !in0 ? 0 : (!in1 ? 1 : 2), a = (o + 1) % 3, b = (o + 2) % 3;  // cyclic order a, b, o; o outside
+  const CVert P = clip_edge(c[b], c[o], b, o);
+  if (which == 0) {
+    finish_piece<WITH_BARY>(c[a], c[b], P, Kv, tri, tri, p);
+  } else {
+    const CVert Q = clip_edge(c[a], c[o], a, o);
+    finish_piece<WITH_BARY>(c[a], P, Q, Kv, tri, m.n_faces + tri, p);
+  }
+  return 2;
+}
+
+// piece index space of a view: [0, F) first pieces, [F, 2F) second pieces
+template <bool WITH_BARY>
+MP_HD void piece_from_index(const MeshRef& m, const float* T, const float* Kv, int idx, Piece& p) {
+  const int tri = idx < m.n_faces ? idx : idx - m.n_faces;
+  (void)make_piece<WITH_BARY>(m, T, Kv, tri, idx < m.n_faces ? 0 : 1, p);
+}
+
+// pixel bbox (inclusive) of the pixels that own a sample inside the piece's snapped bbox
+MP_HD void piece_pixel_bbox(const Piece& p, int ns, int w, int h, int& x0, int& y0, int& x1, int& y1) {
+  const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
+  const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
+  const int omin = sample_off_min(ns), omax = sample_off_max(ns);
+  x0 = imax(0, (Xmin - omax + 255) >> 8);   // arithmetic shift = floor division (coordinates may be negative)
+  x1 = imin(w - 1, (Xmax - omin) >> 8);
+  y0 = imax(0, (Ymin - omax + 255) >> 8);
+  y1 = imin(h - 1, (Ymax - omin) >> 8);
+}
+
+// Edge a->b: E(p) = (bx-ax)*(py-ay) - (by-ay)*(px-ax) = A*px + B*py + C.  With y pointing down and a positively oriented piece
+// the interior is E >= 0; an edge is "left" if it goes up (dy < 0) and "top" if dy == 0 && dx > 0.  Top-left edges own their
+// boundary samples (threshold 0); the others exclude E == 0 (threshold 1).
+struct Edges {
+  long long A[3], B[3], C[3];
+  int thr[3];
+  float inv_area;
+};
+
+MP_HD void edge_setup(int ax, int ay, int bx, int by, long long& A, long long& B, long long& C, int& thr) {
+  const long long dx = (long long)bx - ax, dy = (long long)by - ay;
+  A = -dy;
+  B = dx;
+  C = dy * ax - dx * ay;
+  thr = ((dy < 0) || (dy == 0 && dx > 0)) ? 0 : 1;
+}
+
+MP_HD void piece_edges(const Piece& p, Edges& e) {
+  edge_setup(p.X[1], p.Y[1], p.X[2], p.Y[2], e.A[0], e.B[0], e.C[0], e.thr[0]);  // edge opposite vertex 0
+  edge_setup(p.X[2], p.Y[2], p.X[0], p.Y[0], e.A[1], e.B[1], e.C[1], e.thr[1]);
+  edge_setup(p.X[0], p.Y[0], p.X[1], p.Y[1], e.A[2], e.B[2], e.C[2], e.thr[2]);
+  const long long area = (long long)(p.X[1] - p.X[0]) * (long long)(p.Y[2] - p.Y[0]) - (long long)(p.Y[1] - p.Y[0]) * (long long)(p.X[2] - p.X[0]);
+  e.inv_area = 1.0f / (float)area;
+}
+
+// barycentrics and wsum at fixed-point position (sx, sy); returns coverage
+MP_HD bool eval_at(const Piece& p, const Edges& e, long long sx, long long sy, float b[3], float& wsum) {
+  bool inside = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const long long v = e.A[i] * sx + e.B[i] * sy + e.C[i];
+    inside = inside && (v >= e.thr[i]);
+    b[i] = (float)v * e.inv_area;
+  }
+  wsum = fmaf(b[2], p.iz[2], fmaf(b[1], p.iz[1], b[0] * p.iz[0]));
+  return inside;
+}
+
+// ---- 32-bit fast path of the edge functions (the GPU's inner loop) -----------------------------------------------------------
+// For a piece whose extent D = max(Xmax - Xmin, Ymax - Ymin) and whose distance R to the farthest sample of the 8x8 tile are both
+// <= 23170 sub-pixel units (90 px), every |E| = |dx * ry - dy * rx| <= 2 * 23170^2 < 2^31 and every factor fits 24 bits, so the
+// edge functions can be evaluated in int32 relative to the edge's first vertex -- the same integers as the 64-bit form.
+struct Edges32 {
+  int dx[3], dy[3];   // edge vector b - a
+  int ax[3], ay[3];   // edge origin
+  int thr[3];
+  float inv_area;
+};
+
+MP_HD bool piece_is_small(const Piece& p, int tile_x0, int tile_y0) {
+  const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
+  const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
+  const int sx0 = tile_x0 * SUBPIX, sx1 = sx0 + TILE * SUBPIX, sy0 = tile_y0 * SUBPIX, sy1 = sy0 + TILE * SUBPIX;
+  const long long D = imax(Xmax - Xmin, Ymax - Ymin);
+  const long long R = (long long)imax(imax(sx1 - Xmin, Xmax - sx0), imax(sy1 - Ymin, Ymax - sy0));
+  // (differences of ints below 2^23 in magnitude: no overflow)
+  return D <= 23170 && R <= 23170 && sx1 - Xmin >= -23170 && Xmax - sx0 >= -23170 && sy1 - Ymin >= -23170 && Ymax - sy0 >= -23170;
+}
+
+MP_HD void piece_edges32(const Piece& p, Edges32& e) {
+  const int a[3] = {1, 2, 0}, b[3] = {2, 0, 1};  // edge i runs a[i] -> b[i] (edge opposite vertex i)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    e.dx[i] = p.X[b[i]] - p.X[a[i]];
+    e.dy[i] = p.Y[b[i]] - p.Y[a[i]];
+    e.ax[i] = p.X[a[i]];
+    e.ay[i] = p.Y[a[i]];
+    e.thr[i] = ((e.dy[i] < 0) || (e.dy[i] == 0 && e.dx[i] > 0)) ? 0 : 1;
+  }
+  const long long area = (long long)(p.X[1] - p.X[0]) * (long long)(p.Y[2] - p.Y[0]) - (long long)(p.Y[1] - p.Y[0]) * (long long)(p.X[2] - p.X[0]);
+  e.inv_area = 1.0f / (float)area;
+}
+
+// E_i at sample (sx, sy), int32 (valid under piece_is_small)
+MP_HD int edge32(const Edges32& e, int i, int sx, int sy) { return e.dx[i] * (sy - e.ay[i]) - e.dy[i] * (sx - e.ax[i]); }
+
+struct Sample {
+  float wsum;
+  int id;  // < 0: empty
+};
+
+MP_HD bool depth_in_range(float wsum) { return wsum >= 1.0f / Z_FAR && wsum <= 1.0f / Z_NEAR; }
+
+MP_HD void sample_update(Sample& s, float wsum, int id) {
+  if (s.id < 0 || wsum > s.wsum || (wsum == s.wsum && id < s.id)) {
+    s.wsum = wsum;
+    s.id = id;
+  }
+}
+
+// piece index (in the [0, 2F) space) from a depth-tie id: they coincide (first piece: tri, second: F + tri)
+MP_HD int index_of_id(int id) { return id; }
+
+MP_HD float lut_val(int i) { return (float)((i * 255) >> 5); }  // floor(i*255/32), utils.py:65
+
+// Eye-normal LUT lookup: 32-texel separable ramp, GL_LINEAR filter, repeat wrap; value on the 0..255 scale
+MP_HD float normal_lut(float n) {
+  const float u = n - floorf(n);
+  const float t = fmaf(u, 32.0f, -0.5f);
+  const float fl = floorf(t);
+  const float f = t - fl;
+  const int i0 = ((int)fl + 32) & 31;
+  const int i1 = (i0 + 1) & 31;
+  const float a = lut_val(i0), b = lut_val(i1);
+  return fmaf(b - a, f, a);
+}
+
+// clamp to [0, 255] and round half up (the 8-bit colour buffer); NaN -> 0
+MP_HD float q255(float v255) { return floorf(fminf(fmaxf(v255, 0.f), 255.f) + 0.5f); }
+
+MP_HD void tex_sample(const TexRef& m, int level, float u, float v, float out[3]) {
+  const int tw = imax(1, m.tex_w >> level), th = imax(1, m.tex_h >> level);
+  const uint32_t* tx = m.texels + m.tex_off[level];
+  const float fu = fmaf(u - floorf(u), (float)tw, -0.5f), fv = fmaf(v - floorf(v), (float)th, -0.5f);
+  const float flu = floorf(fu), flv = floorf(fv);
+  const float au = fu - flu, av = fv - flv;
+  int x0 = (int)flu, y0 = (int)flv;
+  if (x0 < 0) x0 = tw - 1;
+  if (y0 < 0) y0 = th - 1;
+  if (x0 >= tw) x0 = tw - 1;  // u - floor(u) can round to 1.0f for tiny negative u
+  if (y0 >= th) y0 = th - 1;
+  const int x1 = (x0 + 1 == tw) ? 0 : x0 + 1, y1 = (y0 + 1 == th) ? 0 : y0 + 1;
+  const uint32_t t00 = tx[y0 * tw + x0], t01 = tx[y0 * tw + x1], t10 = tx[y1 * tw + x0], t11 = tx[y1 * tw + x1];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a00 = (float)((t00 >> (8 * c)) & 255u), a01 = (float)((t01 >> (8 * c)) & 255u);
+    const float a10 = (float)((t10 >> (8 * c)) & 255u), a11 = (float)((t11 >> (8 * c)) & 255u);
+    const float top = fmaf(a01 - a00, au, a00), bot = fmaf(a11 - a10, au, a10);
+    out[c] = fmaf(bot - top, av, top);
+  }
+}
+
+// level of detail from rho^2 (squared texel footprint): lambda = log2(rho) ~ 0.5 * (exponent + mantissa fraction) of rho^2
+MP_HD void tex_lod(int levels, float rho2, int& level, float& frac) {
+  level = 0;
+  frac = 0.f;
+  if (!(rho2 > 1.0f)) return;
+  if (!(rho2 < 1e30f)) { level = levels - 1; return; }
+  uint32_t bits;
+  memcpy(&bits, &rho2, 4);
+  const int e = (int)(bits >> 23) - 127;
+  const float m = (float)(bits & 0x7FFFFFu) * (1.0f / 8388608.0f);
+  const float lambda = 0.5f * ((float)e + m);
+  const float fl = floorf(lambda);
+  int l0 = (int)fl;
+  float f = lambda - fl;
+  if (l0 >= levels - 1) { l0 = levels - 1; f = 0.f; }
+  level = l0;
+  frac = f;
+}
+
+// attribute `comp` (stride 3) of piece vertex k = bary-weighted combination of the original corners' attributes
+MP_HD float pv_attr(const Piece& p, int k, const float* attr, int i0, int i1, int i2, int comp) {
+  return fmaf(p.bary[k][2], attr[3 * i2 + comp], fmaf(p.bary[k][1], attr[3 * i1 + comp], p.bary[k][0] * attr[3 * i0 + comp]));
+}
+
+// Shade piece p at the centre of pixel (px, py): col255 = RGB on the 0..255 scale before clamping/rounding, nrm255 = eye-normal
+// LUT values on the 0..255 scale.  (Barycentrics are extrapolated when the centre lies outside the piece.)
+MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const float* T, bool gl_eye, bool want_normals, const Piece& p,
+                 int px, int py, float col255[3], float nrm255[3]) {
+  Edges e;
+  piece_edges(p, e);
+  float b[3], wsum;
+  (void)eval_at(p, e, (long long)px * SUBPIX + 128, (long long)py * SUBPIX + 128, b, wsum);
+  const float w0 = b[0] * p.iz[0], w1 = b[1] * p.iz[1], w2 = b[2] * p.iz[2];
+  const float z = 1.0f / wsum;
+  const int i0 = m.faces[3 * p.tri], i1 = m.faces[3 * p.tri + 1], i2 = m.faces[3 * p.tri + 2];
+  float col[3], on[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    col[k] = fmaf(w2, pv_attr(p, 2, m.colors, i0, i1, i2, k), fmaf(w1, pv_attr(p, 1, m.colors, i0, i1, i2, k), w0 * pv_attr(p, 0, m.colors, i0, i1, i2, k))) * z;
+    on[k] = fmaf(w2, pv_attr(p, 2, m.normals, i0, i1, i2, k), fmaf(w1, pv_attr(p, 1, m.normals, i0, i1, i2, k), w0 * pv_attr(p, 0, m.normals, i0, i1, i2, k))) * z;
+  }
+  if (m.uvs && tex && tex->texels) {
+    const float* uv = m.uvs + 6 * (size_t)p.tri;
+    float pu[3], pv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pu[k] = fmaf(p.bary[k][2], uv[4], fmaf(p.bary[k][1], uv[2], p.bary[k][0] * uv[0]));
+      pv[k] = fmaf(p.bary[k][2], uv[5], fmaf(p.bary[k][1], uv[3], p.bary[k][0] * uv[1]));
+    }
+    const float u = fmaf(w2, pu[2], fmaf(w1, pu[1], w0 * pu[0])) * z;
+    const float v = fmaf(w2, pv[2], fmaf(w1, pv[1], w0 * pv[0])) * z;
+    float dbx[3], dby[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dbx[i] = (float)(e.A[i] * 256) * e.inv_area * p.iz[i];
+      dby[i] = (float)(e.B[i] * 256) * e.inv_area * p.iz[i];
+    }
+    const float dDx = dbx[2] + (dbx[1] + dbx[0]), dDy = dby[2] + (dby[1] + dby[0]);
+    const float dNux = fmaf(dbx[2], pu[2], fmaf(dbx[1], pu[1], dbx[0] * pu[0])), dNuy = fmaf(dby[2], pu[2], fmaf(dby[1], pu[1], dby[0] * pu[0]));
+    const float dNvx = fmaf(dbx[2], pv[2], fmaf(dbx[1], pv[1], dbx[0] * pv[0])), dNvy = fmaf(dby[2], pv[2], fmaf(dby[1], pv[1], dby[0] * pv[0]));
+    const float tw = (float)tex->tex_w, th = (float)tex->tex_h;
+    const float dudx = fmaf(-u, dDx, dNux) * z * tw, dvdx = fmaf(-v, dDx, dNvx) * z * th;
+    const float dudy = fmaf(-u, dDy, dNuy) * z * tw, dvdy = fmaf(-v, dDy, dNvy) * z * th;
+    const float rx2 = fmaf(dvdx, dvdx, dudx * dudx), ry2 = fmaf(dvdy, dvdy, dudy * dudy);
+    int level;
+    float frac;
+    tex_lod(tex->tex_levels, fmaxf(rx2, ry2), level, frac);
+    float tc[3];
+    tex_sample(*tex, level, u, v, tc);
+    if (frac > 0.f) {
+      float tc1[3];
+      tex_sample(*tex, level + 1, u, v, tc1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tc[k] = fmaf(tc1[k] - tc[k], frac, tc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) col[k] *= tc[k] / 255.0f;
+  }
+  float lr = L.ambient[0], lg = L.ambient[1], lb = L.ambient[2];
+  if (L.n_point > 0) {
+    float op[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      op[k] = fmaf(w2, pv_attr(p, 2, m.verts, i0, i1, i2, k), fmaf(w1, pv_attr(p, 1, m.verts, i0, i1, i2, k), w0 * pv_attr(p, 0, m.verts, i0, i1, i2, k))) * z;
+    const float nn = sqrtf(fmaf(on[2], on[2], fmaf(on[1], on[1], on[0] * on[0])));
+    const float inn = nn > 0.f ? 1.0f / nn : 0.f;
+    const float R10 = 10.0f * m.radius;
+    for (int l = 0; l < L.n_point; ++l) {
+      const float lx = fmaf(L.dir[l][0], R10, L.offset[l][0]) - op[0];
+      const float ly = fmaf(L.dir[l][1], R10, L.offset[l][1]) - op[1];
+      const float lz = fmaf(L.dir[l][2], R10, L.offset[l][2]) - op[2];
+      const float ln = sqrtf(fmaf(lz, lz, fmaf(ly, ly, lx * lx)));
+      const float d = fmaf(lz, on[2], fmaf(ly, on[1], lx * on[0])) * inn / ln;
+      const float dd = fmaxf(d, 0.f);
+      lr = fmaf(L.color[l][0], dd, lr);
+      lg = fmaf(L.color[l][1], dd, lg);
+      lb = fmaf(L.color[l][2], dd, lb);
+    }
+  }
+  col255[0] = col[0] * lr * 255.0f;
+  col255[1] = col[1] * lg * 255.0f;
+  col255[2] = col[2] * lb * 255.0f;
+  nrm255[0] = nrm255[1] = nrm255[2] = 0.f;
+  if (want_normals) {
+    // eye-space normal: camera (OpenCV) frame first, then the eye-axis convention
+    const float cx = fmaf(T[2], on[2], fmaf(T[1], on[1], T[0] * on[0]));
+    const float cy = fmaf(T[6], on[2], fmaf(T[5], on[1], T[4] * on[0]));
+    const float cz = fmaf(T[10], on[2], fmaf(T[9], on[1], T[8] * on[0]));
+    float ex, ey, ez;
+    if (gl_eye) { ex = cx; ey = -cy; ez = -cz; }   // GL eye: x right, y up, z back
+    else { ex = cx; ey = cz; ez = -cy; }           // Panda view: x right, y forward, z up (TCCGL, types.py:40)
+    nrm255[0] = normal_lut(ex);
+    nrm255[1] = normal_lut(ey);
+    nrm255[2] = normal_lut(ez);
+  }
+}
+
+// final value of a channel from the per-sample sum (already q255'ed unless no_quant)
+MP_HD float resolve_channel(float acc, int ns, bool no_quant) {
+  const float inv_ns = 1.0f / (float)ns;  // 1 or 0.25: exact
+  return no_quant ? (acc * inv_ns) / 255.0f : floorf(fmaf(acc, inv_ns, 0.5f)) / 255.0f;
+}
+
+MP_HD bool view_finite(const float* T, const float* K) {
+  bool ok = true;
+  for (int i = 0; i < 16; ++i) ok = ok && isfinite(T[i]);
+  for (int i = 0; i < 9; ++i) ok = ok && isfinite(K[i]);
+  return ok;
+}
+
+}  // namespace rc
+}  // namespace mp

@@ -47,8 +47,10 @@ def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor
     coarse_rows: indices into the B*M coarse table (detection-major).  refine_rows: indices into the FILTERED table the HIP
     call refined (`extra["coarse_filter"]["preds"]`); the oracle starts each chain from the oracle's own initial pose of that
     (detection, hypothesis) and runs all iterations + the re-score on the CPU.
-    Returns max errors: coarse_TCO, coarse_logit (abs, and the logit scale), pose per iteration (abs on the 4x4),
-    pose_out per iteration (the network's raw 9-vector), score_logit."""
+    Returns max errors: coarse_TCO, coarse_logit (abs), pose per iteration (abs on the 4x4), pose_out per iteration (the
+    network's raw 9-vector), score_logit, and `logit_scale` = max(1, |logits|, |512-d features|) of the sampled rows: a logit is a
+    linear read-out of the features, so fp32 round-off in the conv stack reaches it in proportion to the FEATURE magnitude even when
+    the logit itself is small (WideResNet coarse nets) -- the feature tests use the same 1e-4-relative-to-features bound."""
     cpred, rpred = oest.coarse, oest.refiner
     M = oest.grid.shape[0]
     cd = extra["coarse"]
@@ -70,9 +72,10 @@ def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor
         T0 = init_pose(rows // M, rows % M, labels, im)
         gT = cd["preds"].poses[rows].cpu()
         res["coarse_TCO_max_err"] = (gT - T0).abs().max().item()
-        lo = torch.cat([cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T0[s])["logits"] for s in batches(len(rows), oest.bsz)])
+        outs_c = [cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T0[s]) for s in batches(len(rows), oest.bsz)]
+        lo = torch.cat([o["logits"] for o in outs_c])
         lg = cd["data"]["logits"].flatten()[rows].cpu()
-        res["logit_scale"] = max(1.0, lo.abs().max().item())
+        res["logit_scale"] = max(1.0, lo.abs().max().item(), max(o["net"]["features"].abs().max().item() for o in outs_c))
         res["coarse_logit_max_err"] = (lg - lo.flatten()).abs().max().item()
     if len(refine_rows):
         rows = np.asarray(refine_rows)
@@ -97,9 +100,10 @@ def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor
                 out_err.append((pouts[f"iteration={n + 1}"][rows].cpu() - po).abs().max().item())
         res["pose_max_err_per_iter"], res["pose_out_max_err_per_iter"] = pose_err, out_err
         T_ref = torch.cat([o[-1]["TCO_output"] for o in outs])
-        sl = torch.cat([cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T_ref[s])["logits"] for s in batches(len(rows), oest.bsz)])
+        outs_s = [cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T_ref[s]) for s in batches(len(rows), oest.bsz)]
+        sl = torch.cat([o["logits"] for o in outs_s])
         sg = extra["scoring"]["data"]["logits"].flatten()[rows].cpu()
-        res["logit_scale"] = max(res.get("logit_scale", 1.0), sl.abs().max().item())
+        res["logit_scale"] = max(res.get("logit_scale", 1.0), sl.abs().max().item(), max(o["net"]["features"].abs().max().item() for o in outs_s))
         res["score_logit_max_err"] = (sg - sl.flatten()).abs().max().item()
     return res
 
