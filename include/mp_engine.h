@@ -67,7 +67,9 @@ int mp_mesh_db_create(const mp_mesh_desc* h_meshes, int n_meshes, mp_mesh_db** o
  * textured RigidObject): h_uvs = per-corner (u,v) [n_faces][3][2] float32 in the corner order of h_faces (v = 0 at the FIRST
  * texel row passed here, i.e. the host flips image rows so that v grows with the row index); h_texels = RGBA8 mip chain, level l
  * of size max(1,w>>l) x max(1,h>>l), levels concatenated (built on the host: megapose6d_amd.mesh_io.build_mip_chain).
- * Sampling: repeat wrap, bilinear, per-triangle level selection; albedo = vertex colour x texel / 255. */
+ * Sampling: repeat wrap, trilinear (bilinear taps in the two mip levels around a per-pixel level of detail derived from the
+ * analytic screen-space uv derivatives; texture-minfilter mipmap, panda3d_scene_renderer.py:71); albedo = vertex colour x
+ * texel / 255.  16x anisotropic filtering (:72) is not reproduced. */
 #define MP_TEX_MAX_LEVELS 15
 int mp_mesh_db_set_texture(mp_mesh_db* db, int mesh_id, const float* h_uvs, const uint32_t* h_texels, int tex_w, int tex_h,
                            int n_levels);
@@ -86,16 +88,21 @@ float mp_mesh_db_radius(const mp_mesh_db* db, int mesh_id);
 #define MP_RASTER_NORMALS 1u      /* render_normals=True: eye-normal LUT pass               */
 #define MP_RASTER_DEPTH 2u        /* render_depth=True: metric z, 0 = background            */
 #define MP_RASTER_NORMALS_GL 4u   /* eye space = GL (x right,y up,z back) instead of Panda  */
-#define MP_RASTER_NO_QUANT 8u     /* skip the uint8 round trip (not reference behaviour)    */
+#define MP_RASTER_MSAA4 16u        /* 4x multisampling (the reference's configuration: framebuffer-multisample 1,
+                                     multisamples 4, panda3d_scene_renderer.py:73-74): coverage and depth per sample of the
+                                     standard 4-sample pattern, shading once per (pixel, piece) at the pixel centre, 8-bit
+                                     per-sample colours averaged; without the flag: one sample at the pixel centre          */
 
 typedef struct {
   float ambient[3];        /* sum of ambient light colours                                  */
   int32_t n_point;         /* number of point lights (<= 8)                                 */
-  float point_dir[8][3];   /* unit direction; position = dir * 10 * mesh radius             */
-  float point_color[8][3]; /* (panda3d_scene_renderer.py:104-136 make_scene_lights)         */
+  float point_dir[8][3];   /* light position (object frame) = dir * 10 * mesh radius + offset: the affine-in-the-radius  */
+  float point_color[8][3]; /* form of Panda3dLightData.positioning_function (panda3d_scene_renderer.py:104-136,         */
+  float point_offset[8][3];/* types.py:104-114); make_scene_lights: dir = +-axes, offset = 0                            */
 } mp_lights;
 
-size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views);
+/* scratch for the per-view tile lists of a launch of n_views views at h x w (<= 1024 x 1024) */
+size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views, int h, int w);
 
 /* d_out addressing: element (view v, y, x, channel c) at
  *   d_out[(v / views_per_item)*stride_v + (v % views_per_item)*stride_view + y*stride_y + x*stride_x + c]
@@ -103,7 +110,9 @@ size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views);
  * one hypothesis are folded into the channels of one CNN input row, models/pose_rigid.py:405-408).
  * c_rgb / c_normals / c_depth are the first channel of each group (negative = not written).
  * Values are uint8-quantised then /255 exactly as panda3d_batch_renderer.py:261-274
- * (depth is not quantised).  Non-finite TCO/K rows produce zeros (:109-135).              */
+ * (depth is not quantised).  Non-finite TCO/K rows produce zeros (:109-135).  Triangles crossing the near plane are
+ * clipped.  One launch writes at most 32 consecutive channels per pixel (c_lo .. c_hi over all groups / views / the crop),
+ * and stride_x must be >= that run.                                                        */
 int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO /*[n,4,4]*/,
                      const float* d_K /*[n,3,3]*/, int n_views, int h, int w, uint32_t flags,
                      const mp_lights* h_lights, float* d_out, int64_t stride_v, int views_per_item,
@@ -112,9 +121,9 @@ int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const floa
 
 /* mp_raster_render + the observation crop of every item (mp_crop_roi_align semantics, boxes / im_ids per ITEM = n_views /
  * views_per_item) written by the same launch into channels c0_crop.. of the item's pixels: what PosePredictor.forward does per
- * iteration with crop_inputs (models/pose_rigid.py:180-247) + render_images_multiview (:336-408) + torch.cat (:567).  One extra
- * workgroup per (item, band) does the roi_align, co-located on the XCD of the views' workgroups so that the L2 merges the channel
- * slices of a pixel line. */
+ * iteration with crop_inputs (models/pose_rigid.py:180-247) + render_images_multiview (:336-408) + torch.cat (:567).  The wave
+ * that rasterises an 8x8-pixel tile of the item's views also computes the roi_align of those pixels, so every pixel of the CNN
+ * input leaves the chip once, as one contiguous record of all its channels. */
 int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K, int n_views,
                           int h, int w, uint32_t flags, const mp_lights* lights, float* d_out, int64_t stride_v,
                           int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb,

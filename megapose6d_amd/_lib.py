@@ -34,6 +34,7 @@ class Lights(C.Structure):
         ("n_point", C.c_int32),
         ("point_dir", (C.c_float * 3) * 8),
         ("point_color", (C.c_float * 3) * 8),
+        ("point_offset", (C.c_float * 3) * 8),
     ]
 
 
@@ -77,7 +78,7 @@ SIGNATURES = {
     "mp_mesh_db_destroy": (_i, [_vp]),
     "mp_mesh_db_max_vertices": (_i, [_vp]),
     "mp_mesh_db_radius": (_f, [_vp, _i]),
-    "mp_raster_workspace_bytes": (_sz, [_vp, _i]),
+    "mp_raster_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "mp_raster_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
                               _vp, _sz, _vp]),
     "mp_raster_render_crop": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,

@@ -2,78 +2,51 @@
 //
 // Reference contract: Panda3dBatchRenderer.render
 //   (/root/reference/src/megapose/panda3d_renderer/panda3d_batch_renderer.py:217-282, worker_loop :89-150,
-//    Panda3dSceneRenderer.render_scene panda3d_scene_renderer.py:298-358, camera model types.py:75-101,
-//    eye-normal LUT utils.py:58-68 + panda3d_scene_renderer.py:210-216, depth utils.py:44-55,
-//    lights panda3d_scene_renderer.py:104-136).
+//    Panda3dSceneRenderer.render_scene panda3d_scene_renderer.py:298-358, renderer configuration :71-74 (4x multisampling,
+//    mip-mapped textures), camera model types.py:75-101, eye-normal LUT utils.py:58-68 + panda3d_scene_renderer.py:210-216,
+//    depth utils.py:44-55, lights panda3d_scene_renderer.py:104-136).
 //
-// Pixel contract (identical, operation for operation, to oracle/raster.c -- see DESIGN.md "Rasteriser"):
-//   * camera-space vertex  Pc = R p + t  as an fmaf chain; screen  sx = fmaf(fx, x/z.., cx)
-//   * screen coords snapped to 1/256 px fixed point; coverage by exact integer edge functions (evaluated in fp64) sampled at
-//     pixel centres (x+.5, y+.5) with the top-left fill rule; two-sided (no back-face culling)
-//   * depth test on wsum = sum b_i/z_i (perspective-correct 1/z), nearest wins, ties -> lowest triangle id;
-//     fragments outside [near, far] = [0.1, 10] m are discarded
-//   * attributes interpolated perspective-correctly; RGB = albedo * light; normals through the 32^3 LUT
-//     (separable, linear filter, repeat wrap); uint8 quantisation then /255.
-//   * albedo = vertex colour, modulated for UV-textured meshes by a bilinear, repeat-wrapped sample of a host-built
-//     RGBA8 mip chain; the mip level is chosen per triangle from its texel-area / pixel-area ratio (thresholds 2, 8, 32, ...).
+// Pixel contract v2: stated at the top of oracle/raster.c (the independent CPU restatement this file must match bit for bit);
+// its arithmetic lives in raster_core.h, which tests/raster_emul.cpp also compiles for the host so that the contract is checked
+// against the oracle without a GPU.
 //
-// Structure: (1) raster_transform: one thread per (view, vertex) -> {X, Y (fixed point), 1/z, valid}
-//            (2) raster_bands: one workgroup per (view, band of BAND_H rows): 64-bit {depth,tri} z-buffer in
-//                LDS, row-bounds prefilter + LDS compaction, thread-per-triangle LDS atomicMin for tiny triangles and a
-//                wave-per-triangle queue for the rest,
-//                then a pixel-parallel resolve/shade that writes straight into the CNN input tensor slice.
-// Roofline: HBM-bound on the output writes ((3+3[+1])*4*h*w bytes per view).
+// Structure (v4, stateless -- nothing but small index lists goes through HBM between the two kernels):
+//   (1) raster_bin    one workgroup per view: every triangle is transformed, clipped against the near plane, projected and its
+//                     pieces are binned by their pixel bbox into 8x8-pixel tiles (LDS counters -> prefix scan -> fill).  Pieces
+//                     touching more than LARGE_TILES tiles go to a per-view "large" list that every tile walks.
+//   (2) raster_tiles  one wave per (item, tile), four tiles per workgroup: for each of the item's views the wave sets up 64 listed
+//                     pieces at a time lane-parallel (recomputed from the L2-resident mesh), broadcasts them with v_readlane and
+//                     tests the tile's 64 pixels x 1|4 samples against each (exact integer edge functions, 32-bit when the piece
+//                     is small); depth state lives in registers -- no LDS z-buffer, no atomics.  Shading runs once per (pixel,
+//                     distinct winning piece) from a dense per-wave task list; the observation crop (roi_align) of the item is
+//                     another role of the same wave.  All channels of the tile's pixels are staged in LDS and leave as whole,
+//                     contiguous pixel records (one launch fills the CNN input with full-line writes).
+// Roofline: HBM-bound on the output writes ((3+3[+1])*4*h*w bytes per view + the mesh once per view).
 #include <cmath>
 #include <vector>
 
 #include "common.h"
 #include "crop_device.h"
+#include "raster_core.h"
 
 namespace mp {
 
-constexpr int SUBPIX = 256;
-constexpr float GUARD = 16384.f;  // |screen coord| limit (pixels) for the fixed-point path
-constexpr float Z_EPS = 1e-6f;
-constexpr float Z_NEAR = 0.1f, Z_FAR = 10.0f;
-#ifndef MP_BAND_H
-#define MP_BAND_H 16
-#endif
-constexpr int BAND_H = MP_BAND_H;
-constexpr int BAND_THREADS = 512;
-constexpr int BIG_TRI_AREA = 128;   // clipped-bbox pixels above which a triangle is rasterised by a whole wave (a lane that
-                                    // walks a several-hundred-pixel bbox alone stalls its wave and the block's barrier)
-constexpr int BIG_QUEUE = 1024;
-constexpr int SCAN_CHUNK = 2048;  // triangles scanned between two looks at the list fill level
-constexpr int LIST_CAP = 4096;    // compacted triangle list (drained when another scan chunk might not fit)
-constexpr int STAGE_CH = 7;  // rgb(3) + normals(3) + depth(1) staged per pixel for coalesced stores
+using rc::Piece;
+using rc::Sample;
+using rc::SUBPIX;
+using rc::TILE;
 
-struct MeshDev {
-  const float* verts;
-  const float* normals;
-  const float* colors;
-  const int32_t* faces;
-  int n_verts, n_faces;
-  float radius;
-  float center[3];
-  const float* uvs;  // UV texture (optional): per-corner uv [n_faces][3][2], NULL = vertex colours only
-};
+typedef rc::MeshRef MeshDev;
+typedef rc::TexRef TexDev;
+typedef rc::Lights LightsDev;
 
-// texture of mesh i (kept out of MeshDev so that the untextured path does not carry it in registers):
-// RGBA8 mip chain, level l at texels + tex_off[l], size max(1, w>>l) x max(1, h>>l)
-struct TexDev {
-  const uint32_t* texels;
-  int tex_w, tex_h, tex_levels;
-  int tex_off[MP_TEX_MAX_LEVELS];
-};
+constexpr int BIN_THREADS = 512;
+constexpr int LARGE_TILES = 16;    // a piece whose bbox touches more tiles is not replicated into tile lists
+constexpr int TILE_WAVES = 4;      // tiles (waves) per workgroup of raster_tiles: a 32 x 8 pixel strip
+constexpr int MAX_RUN = 32;        // channels per pixel one launch may stage
+constexpr int HDR_INTS = 4;        // per-view header: n_large, n_entries, overflow, unused
 
-struct VtxRec {
-  int X, Y;     // fixed-point screen coordinates (1/256 px)
-  float invz;   // 1 / camera z
-  int valid;
-};
-
-// optional fused crop role (one extra workgroup per (item, band)): roi_align of the observation into channels c0.. of the same
-// pixel lines the views write, so that the XCD's L2 merges all slices of a line (see the work-to-workgroup map in raster_bands)
+// optional fused crop role: roi_align of the observation into channels c0.. of the same pixels
 struct CropArgs {
   const float* images;     // [n_im][C][H][W], or [n_im][H][W][4] when nhwc4; NULL = no crop role
   const int32_t* im_ids;   // [n_items]
@@ -81,447 +54,281 @@ struct CropArgs {
   int C, H, W, c0, nhwc4;
 };
 
-struct LightsDev {
-  float ambient[3];
-  int n_point;
-  float dir[8][3];
-  float color[8][3];
+struct BinLayout {   // per-view workspace (ints): [hdr HDR_INTS][tile_off n_tiles + 1][list cap_list][large 2 * max_faces]
+  long long view_ints;
+  int n_tiles, tiles_x, tiles_y, cap_list, max_faces;
 };
 
-__device__ __forceinline__ float dot3p(float a0, float a1, float a2, float x, float y, float z, float t) {
-  return fmaf(a2, z, fmaf(a1, y, fmaf(a0, x, t)));
+__device__ __forceinline__ void tile_range(const Piece& p, int ns, int w, int h, int& tx0, int& ty0, int& tx1, int& ty1) {
+  int x0, y0, x1, y1;
+  rc::piece_pixel_bbox(p, ns, w, h, x0, y0, x1, y1);
+  tx0 = x0 >> 3; ty0 = y0 >> 3; tx1 = x1 >> 3; ty1 = y1 >> 3;
+  if (x0 > x1 || y0 > y1) { tx1 = tx0 - 1; ty1 = ty0 - 1; }  // empty
 }
 
-__device__ __forceinline__ bool view_finite(const float* T, const float* K) {
-  bool ok = true;
-  for (int i = 0; i < 16; ++i) ok = ok && isfinite(T[i]);
-  for (int i = 0; i < 9; ++i) ok = ok && isfinite(K[i]);
-  return ok;
-}
-
-__global__ void raster_transform(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
-                                 const float* __restrict__ TCO, const float* __restrict__ K, int max_verts,
-                                 VtxRec* __restrict__ out) {
-  const int view = blockIdx.y;
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
+                                                          const float* __restrict__ TCO, const float* __restrict__ K, int h, int w, int ns,
+                                                          int* __restrict__ ws, BinLayout lay) {
+  extern __shared__ int counts[];  // [n_tiles]: counters, then (in place) exclusive offsets = fill cursors
+  __shared__ int partial[BIN_THREADS];
+  __shared__ int s_nlarge;
+  const int view = blockIdx.x;
+  const int tid = threadIdx.x;
+  int* hdr = ws + (size_t)view * lay.view_ints;
+  int* tile_off = hdr + HDR_INTS;
+  int* list = tile_off + lay.n_tiles + 1;
+  int* large = list + lay.cap_list;
   const MeshDev m = meshes[mesh_ids[view]];
-  if (v >= m.n_verts) return;
   const float* T = TCO + (size_t)view * 16;
   const float* Kv = K + (size_t)view * 9;
-  VtxRec rec;
-  rec.X = 0; rec.Y = 0; rec.invz = 0.f; rec.valid = 0;
-  if (view_finite(T, Kv)) {
-    const float px = m.verts[3 * v + 0], py = m.verts[3 * v + 1], pz = m.verts[3 * v + 2];
-    const float x = dot3p(T[0], T[1], T[2], px, py, pz, T[3]);
-    const float y = dot3p(T[4], T[5], T[6], px, py, pz, T[7]);
-    const float z = dot3p(T[8], T[9], T[10], px, py, pz, T[11]);
-    if (z > Z_EPS) {
-      const float iz = 1.0f / z;
-      const float sx = fmaf(Kv[0], x * iz, Kv[2]);
-      const float sy = fmaf(Kv[4], y * iz, Kv[5]);
-      if (fabsf(sx) < GUARD && fabsf(sy) < GUARD) {
-        rec.X = (int)rintf(sx * (float)SUBPIX);
-        rec.Y = (int)rintf(sy * (float)SUBPIX);
-        rec.invz = iz;
-        rec.valid = 1;
-      }
-    }
-  }
-  out[(size_t)view * max_verts + v] = rec;
-}
-
-// Per (view, triangle): pixel-row range [ymin, ymax] the triangle can touch, packed ymin | ymax << 16 (0xFFFF = culled).
-// Lets every band skip non-overlapping triangles with one coalesced 4-byte read instead of 3 index + 3 vertex gathers.
-__global__ void raster_tri_bounds(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
-                                  const VtxRec* __restrict__ vtx, int max_verts, int max_faces, int h,
-                                  unsigned* __restrict__ bounds) {
-  const int view = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const MeshDev m = meshes[mesh_ids[view]];
-  if (t >= m.n_faces) return;
-  const VtxRec* vv = vtx + (size_t)view * max_verts;
-  const VtxRec v0 = vv[m.faces[3 * t]], v1 = vv[m.faces[3 * t + 1]], v2 = vv[m.faces[3 * t + 2]];
-  unsigned packed = 0xFFFFu;
-  if (v0.valid && v1.valid && v2.valid) {
-    const int Ymin = min(v0.Y, min(v1.Y, v2.Y)), Ymax = max(v0.Y, max(v1.Y, v2.Y));
-    const int ymin = max(0, (Ymin - 128 + 255) >> 8), ymax = min(h - 1, (Ymax - 128) >> 8);
-    if (ymin <= ymax) packed = (unsigned)ymin | ((unsigned)ymax << 16);
-  }
-  bounds[(size_t)view * max_faces + t] = packed;
-}
-
-struct TriSetup {
-  // E_i(sx,sy) = A_i*sx + B_i*sy + C_i over fixed-point sample coordinates.  All quantities are integers below 2^47, held
-  // in fp64 where they (and every partial sum of the two-FMA evaluation) are exact; fp64 FMA runs at half the fp32 rate on
-  // gfx950, whereas 64-bit integer multiplies decompose into quarter-rate 32-bit multiplies.
-  double A0, B0, C0, A1, B1, C1, A2, B2, C2;
-  double t0, t1, t2;  // fill-rule thresholds: sample is inside iff E_i >= t_i (0 or 1)
-  float inv_area;     // 1 / (float)(2 * signed area) -- barycentric b_i = (float)E_i * inv_area
-  float iz0, iz1, iz2;
-  int xmin, xmax, ymin, ymax;  // pixel bbox (inclusive), clipped to the band
-  bool ok;
-};
-
-// Edge a->b: E(p) = (bx-ax)*(py-ay) - (by-ay)*(px-ax).  With y pointing down and a positively oriented
-// triangle the interior is E >= 0; an edge is "left" if it goes up (dy < 0) and "top" if dy == 0 && dx > 0.
-// Top-left edges own their boundary samples (threshold 0); the others exclude E == 0 (threshold 1).
-__device__ __forceinline__ void edge_setup(int ax, int ay, int bx, int by, double& A, double& B, double& C, double& thr) {
-  const int dx = bx - ax, dy = by - ay;  // |.| < 2^24
-  A = -(double)dy;
-  B = (double)dx;
-  C = (double)dy * (double)ax - (double)dx * (double)ay;  // exact: products < 2^47
-  thr = ((dy < 0) || (dy == 0 && dx > 0)) ? 0.0 : 1.0;
-}
-
-// v1/v2 (and i1/i2) are swapped in place when the screen-space orientation is negative (two-sided rendering).
-__device__ __forceinline__ TriSetup tri_setup(const VtxRec& v0, VtxRec& v1, VtxRec& v2, int& i1, int& i2, int w, int y_lo,
-                                              int y_hi) {
-  TriSetup s;
-  s.ok = false;
-  if (!(v0.valid && v1.valid && v2.valid)) return s;
-  double area = (double)(v1.X - v0.X) * (double)(v2.Y - v0.Y) - (double)(v1.Y - v0.Y) * (double)(v2.X - v0.X);  // exact
-  if (area == 0.0) return s;
-  if (area < 0.0) {
-    const VtxRec t = v1; v1 = v2; v2 = t;
-    const int ti = i1; i1 = i2; i2 = ti;
-    area = -area;
-  }
-  const int Xmin = min(v0.X, min(v1.X, v2.X)), Xmax = max(v0.X, max(v1.X, v2.X));
-  const int Ymin = min(v0.Y, min(v1.Y, v2.Y)), Ymax = max(v0.Y, max(v1.Y, v2.Y));
-  // samples sit at x*256+128: ceil((Xmin-128)/256) .. floor((Xmax-128)/256)
-  s.xmin = max(0, (Xmin - 128 + 255) >> 8);
-  s.xmax = min(w - 1, (Xmax - 128) >> 8);
-  s.ymin = max(y_lo, (Ymin - 128 + 255) >> 8);
-  s.ymax = min(y_hi, (Ymax - 128) >> 8);
-  if (s.xmin > s.xmax || s.ymin > s.ymax) return s;
-  edge_setup(v1.X, v1.Y, v2.X, v2.Y, s.A0, s.B0, s.C0, s.t0);  // edge opposite vertex 0
-  edge_setup(v2.X, v2.Y, v0.X, v0.Y, s.A1, s.B1, s.C1, s.t1);
-  edge_setup(v0.X, v0.Y, v1.X, v1.Y, s.A2, s.B2, s.C2, s.t2);
-  s.inv_area = 1.0f / (float)area;
-  s.iz0 = v0.invz;
-  s.iz1 = v1.invz;
-  s.iz2 = v2.invz;
-  s.ok = true;
-  return s;
-}
-
-__device__ __forceinline__ bool sample_tri(const TriSetup& s, int px, int py, float& b0, float& b1, float& b2, float& wsum) {
-  const double sx = (double)(px * SUBPIX + 128), sy = (double)(py * SUBPIX + 128);
-  const double e0 = fma(s.A0, sx, fma(s.B0, sy, s.C0));  // exact integer arithmetic in fp64
-  const double e1 = fma(s.A1, sx, fma(s.B1, sy, s.C1));
-  const double e2 = fma(s.A2, sx, fma(s.B2, sy, s.C2));
-  if (e0 < s.t0 || e1 < s.t1 || e2 < s.t2) return false;
-  b0 = (float)e0 * s.inv_area;
-  b1 = (float)e1 * s.inv_area;
-  b2 = (float)e2 * s.inv_area;
-  wsum = fmaf(b2, s.iz2, fmaf(b1, s.iz1, b0 * s.iz0));
-  return true;
-}
-
-__device__ __forceinline__ void raster_pixel(const TriSetup& s, int px, int py, int tri, int band_y0, int w,
-                                             unsigned long long* zbuf) {
-  float b0, b1, b2, wsum;
-  if (!sample_tri(s, px, py, b0, b1, b2, wsum)) return;
-  if (!(wsum >= 1.0f / Z_FAR && wsum <= 1.0f / Z_NEAR)) return;
-  const unsigned long long key = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(wsum)) << 32) | (unsigned)tri;
-  atomicMin(&zbuf[(py - band_y0) * w + px], key);
-}
-
-__device__ __forceinline__ float lut_val(int i) { return (float)((i * 255) >> 5); }  // floor(i*255/32), utils.py:65
-
-// Eye-normal LUT lookup: 32-texel separable ramp, GL_LINEAR filter, repeat wrap; returns the value on the 0..255 scale
-__device__ __forceinline__ float normal_lut(float n) {
-  const float u = n - floorf(n);
-  const float t = fmaf(u, 32.0f, -0.5f);
-  const float fl = floorf(t);
-  const float f = t - fl;
-  const int i0 = ((int)fl + 32) & 31;
-  const int i1 = (i0 + 1) & 31;
-  const float a = lut_val(i0), b = lut_val(i1);
-  return fmaf(b - a, f, a);
-}
-
-// Texture sample (contract shared with oracle/raster.c): repeat wrap, texel centres at (i + .5) / size, bilinear, result on the
-// 0..255 scale per channel.
-__device__ __forceinline__ void tex_sample(const TexDev& m, int level, float u, float v, float& r, float& g, float& b) {
-  const int tw = max(1, m.tex_w >> level), th = max(1, m.tex_h >> level);
-  const uint32_t* tx = m.texels + m.tex_off[level];
-  const float fu = fmaf(u - floorf(u), (float)tw, -0.5f), fv = fmaf(v - floorf(v), (float)th, -0.5f);
-  const float flu = floorf(fu), flv = floorf(fv);
-  const float au = fu - flu, av = fv - flv;
-  int x0 = (int)flu, y0 = (int)flv;
-  if (x0 < 0) x0 = tw - 1;
-  if (y0 < 0) y0 = th - 1;
-  if (x0 >= tw) x0 = tw - 1;   // u - floor(u) can round to 1.0f for tiny negative u
-  if (y0 >= th) y0 = th - 1;
-  const int x1 = (x0 + 1 == tw) ? 0 : x0 + 1, y1 = (y0 + 1 == th) ? 0 : y0 + 1;
-  const uint32_t t00 = tx[y0 * tw + x0], t01 = tx[y0 * tw + x1], t10 = tx[y1 * tw + x0], t11 = tx[y1 * tw + x1];
-  float out[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float a00 = (float)((t00 >> (8 * c)) & 255u), a01 = (float)((t01 >> (8 * c)) & 255u);
-    const float a10 = (float)((t10 >> (8 * c)) & 255u), a11 = (float)((t11 >> (8 * c)) & 255u);
-    const float top = fmaf(a01 - a00, au, a00), bot = fmaf(a11 - a10, au, a10);
-    out[c] = fmaf(bot - top, av, top);
-  }
-  r = out[0]; g = out[1]; b = out[2];
-}
-
-// mip level of a triangle: texels per pixel r = |uv area| * w * h / (screen area); level = #thresholds {2, 8, 32, ...} below r
-__device__ __forceinline__ int tex_level(const TexDev& m, const float* uv, float inv_area2) {
-  const float du1 = uv[2] - uv[0], dv1 = uv[3] - uv[1], du2 = uv[4] - uv[0], dv2 = uv[5] - uv[1];
-  const float at = fabsf(du1 * dv2 - du2 * dv1) * ((float)m.tex_w * (float)m.tex_h);
-  const float r = at * (inv_area2 * 65536.0f);   // inv_area2 = 1 / (2 * area in 1/256-px units)
-  int level = 0;
-  float thr = 2.0f;
-  while (level + 1 < m.tex_levels && r > thr) { ++level; thr *= 4.0f; }
-  return level;
-}
-
-__device__ __forceinline__ float quant8(float v255) {
-  const float q = floorf(fminf(fmaxf(v255, 0.f), 255.f) + 0.5f);
-  return q / 255.0f;
-}
-
-template <bool kUnused = false>
-__global__ __launch_bounds__(BAND_THREADS) void raster_bands(
-    const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
-    const VtxRec* __restrict__ vtx, const unsigned* __restrict__ bounds, int max_verts, int max_faces, int h, int w, uint32_t flags,
-    LightsDev lights, float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
-    long long stride_x, int c_rgb, int c_normals, int c_depth, CropArgs crop) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];  // [BAND_H*w] + big-triangle queue
-  int* big_queue = (int*)(zbuf + (size_t)BAND_H * w);
-  int* list = big_queue + BIG_QUEUE;  // [LIST_CAP]
-  float* stage = (float*)big_queue;   // [BAND_THREADS][STAGE_CH]: resolve-phase staging, aliases the (then dead) queue + list
-  static_assert((BIG_QUEUE + LIST_CAP) * sizeof(int) >= BAND_THREADS * STAGE_CH * sizeof(float), "stage must fit in queue + list");
-  __shared__ int list_n;
-  __shared__ int q_head;
-  __shared__ int big_count;
-
-  // Work-to-workgroup map: consecutive workgroup ids go round-robin to the 8 XCDs, and the `views_per_item` views of one
-  // (item, band) write interleaved channel slices of the SAME pixel lines of the CNN input.  Placing them in consecutive slots
-  // of one XCD lets its L2 merge the 24-byte slices into whole lines before they are written back (otherwise every slice is a
-  // partial-line write from a different L2).
-  const int n_bands = (h + BAND_H - 1) / BAND_H;
-  const int roles = views_per_item + (crop.images ? 1 : 0);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int q = (slot / roles) * 8 + xcd;   // (item, band) index
-  if (q >= n_items * n_bands) return;
-  const int band = q % n_bands;
-  const int y0 = band * BAND_H;
-  if (slot % roles == views_per_item) {  // crop role (whole workgroup): the band's rows of the observation crop
-    const int item = q / n_bands;
-    const int yl = min(h, y0 + BAND_H) - 1;
-    const float* bx = crop.boxes + (size_t)item * 4;
-    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
-    const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
-    const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
-    const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
-    float* o_item = out + (size_t)item * stride_v + crop.c0;
-    for (int i = threadIdx.x; i < (yl - y0 + 1) * w; i += BAND_THREADS) {
-      const int py = y0 + i / w, px = i % w;
-      float* o = o_item + (size_t)py * stride_y + (size_t)px * stride_x;
-      if (crop.nhwc4) {
-        if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
-        else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+  for (int i = tid; i < lay.n_tiles; i += BIN_THREADS) counts[i] = 0;
+  if (tid == 0) s_nlarge = 0;
+  __syncthreads();
+  const bool finite = rc::view_finite(T, Kv);  // non-finite pose / intrinsics: empty lists -> zero image (panda3d_batch_renderer.py:109-135)
+  const int F = finite ? m.n_faces : 0;
+  // ---- phase 1: count ------------------------------------------------------------------------------------------------------
+  for (int t = tid; t < F; t += BIN_THREADS) {
+    int n_pieces = 1;
+    for (int which = 0; which < n_pieces; ++which) {
+      Piece p;
+      n_pieces = rc::make_piece<false>(m, T, Kv, t, which, p);
+      if (p.id < 0) continue;
+      int tx0, ty0, tx1, ty1;
+      tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
+      if (tx0 > tx1 || ty0 > ty1) continue;
+      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) {
+        large[atomicAdd(&s_nlarge, 1)] = p.id;   // piece index == depth-tie id
       } else {
-        if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
-        else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, o);
+        for (int ty = ty0; ty <= ty1; ++ty)
+          for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&counts[ty * lay.tiles_x + tx], 1);
       }
     }
-    return;
   }
-  const int view = (q / n_bands) * views_per_item + slot % roles;
-  const int y1 = min(h, y0 + BAND_H) - 1;
-  const int npix = (y1 - y0 + 1) * w;
-  const MeshDev m = meshes[mesh_ids[view]];
-  const VtxRec* vv = vtx + (size_t)view * max_verts;
-  const unsigned* tb = bounds + (size_t)view * max_faces;
-
-  for (int i = threadIdx.x; i < npix; i += BAND_THREADS) zbuf[i] = ~0ull;
-  if (threadIdx.x == 0) { big_count = 0; q_head = 0; }
   __syncthreads();
-
-  // ---- pass 1: triangle-parallel coverage + depth ------------------------------------------------
-  // Two steps so that the expensive part runs on dense lanes: (a) scan the packed row
-  // bounds and compact the triangles overlapping this band into an LDS list (wave ballot + one LDS atomic per wave),
-  // (b) every thread takes list entries.  (A plain "if (!overlap) continue" loop leaves ~1 lane in 9 active.)
-  const int lane = threadIdx.x & 63;
-  // The list is only drained when the next scan chunk could overflow it (or at the end), so that the drain runs with (nearly)
-  // all 512 threads busy instead of once per scan chunk with a fifth of them.
-  const int n_faces_eff = m.n_faces;
-  if (threadIdx.x == 0) list_n = 0;
+  // ---- phase 2: exclusive scan of the tile counters (in place) ---------------------------------------------------------------
+  const int per = (lay.n_tiles + BIN_THREADS - 1) / BIN_THREADS;
+  const int i0 = min(tid * per, lay.n_tiles), i1 = min(i0 + per, lay.n_tiles);
+  int sum = 0;
+  for (int i = i0; i < i1; ++i) sum += counts[i];
+  partial[tid] = sum;
   __syncthreads();
-  // scan: one 16-byte load = the packed bounds of 4 consecutive triangles per thread and chunk (the bounds array is padded to a
-  // multiple of 4 entries per view with "culled"), the next chunk's load is issued before the current one is compacted
-  const uint4* tb4 = reinterpret_cast<const uint4*>(tb);
-  const uint4 culled4 = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
-  uint4 nxt = (4 * (int)threadIdx.x < n_faces_eff) ? tb4[threadIdx.x] : culled4;
-  for (int c0 = 0; c0 < n_faces_eff; c0 += SCAN_CHUNK) {
-    const int c1 = min(n_faces_eff, c0 + SCAN_CHUNK);
-    const uint4 cur = nxt;
-    const int tn = c0 + SCAN_CHUNK + 4 * (int)threadIdx.x;
-    nxt = (tn < n_faces_eff) ? tb4[tn >> 2] : culled4;
-    const int t0 = c0 + 4 * (int)threadIdx.x;
-    const unsigned pbs[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned pb = pbs[k];
-      const bool hit = (t0 + k < c1) && (int)(pb & 0xFFFFu) <= y1 && (int)(pb >> 16) >= y0;  // culled triangles carry ymin = 0xFFFF
-      const unsigned long long mask = __ballot(hit);
-      if (mask) {
-        int wbase = 0;
-        if (lane == 0) wbase = atomicAdd(&list_n, __popcll(mask));
-        wbase = __shfl(wbase, 0);
-        if (hit) list[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = t0 + k;
-      }
+  for (int d = 1; d < BIN_THREADS; d <<= 1) {  // Hillis-Steele inclusive scan over the 512 partial sums
+    const int v = tid >= d ? partial[tid - d] : 0;
+    __syncthreads();
+    partial[tid] += v;
+    __syncthreads();
+  }
+  const int total = partial[BIN_THREADS - 1];
+  const bool overflow = total > lay.cap_list;
+  int run = partial[tid] - sum;
+  for (int i = i0; i < i1; ++i) {
+    const int c = counts[i];
+    counts[i] = run;
+    tile_off[i] = run;
+    run += c;
+  }
+  if (tid == 0) {
+    tile_off[lay.n_tiles] = total;
+    hdr[0] = s_nlarge;
+    hdr[1] = total;
+    hdr[2] = overflow ? 1 : 0;  // the lists do not fit: raster_tiles walks ALL piece indices of this view instead (slow, correct)
+    hdr[3] = 0;
+  }
+  __syncthreads();
+  if (overflow) return;
+  // ---- phase 3: fill (pieces recomputed: cheaper than keeping 2F bboxes) -------------------------------------------------------
+  for (int t = tid; t < F; t += BIN_THREADS) {
+    int n_pieces = 1;
+    for (int which = 0; which < n_pieces; ++which) {
+      Piece p;
+      n_pieces = rc::make_piece<false>(m, T, Kv, t, which, p);
+      if (p.id < 0) continue;
+      int tx0, ty0, tx1, ty1;
+      tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
+      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) continue;
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = p.id;
     }
-    __syncthreads();
-    const int n_list = list_n;
-    if (n_list + SCAN_CHUNK <= LIST_CAP && c1 < n_faces_eff) continue;   // room for another scan chunk: keep collecting
-    for (int e = threadIdx.x; e < n_list; e += BAND_THREADS) {
-      const int t = list[e];
-      int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
-      const VtxRec v0 = vv[i0];
-      VtxRec v1 = vv[i1], v2 = vv[i2];
-      const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
-      if (!s.ok) continue;
-      const int area = (s.xmax - s.xmin + 1) * (s.ymax - s.ymin + 1);
-      if (area > BIG_TRI_AREA) {
-        const int slot = atomicAdd(&big_count, 1);
-        if (slot < BIG_QUEUE) {
-          big_queue[slot] = t;
-          continue;
-        }
-      }
-      for (int py = s.ymin; py <= s.ymax; ++py)
-        for (int px = s.xmin; px <= s.xmax; ++px) raster_pixel(s, px, py, t, y0, w, zbuf);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) list_n = 0;
-    __syncthreads();
   }
-  // ---- pass 1b: larger triangles: waves pull them from the queue, 64 lanes share one bbox -----------------
-  const int nbig = min(big_count, BIG_QUEUE);
-  for (;;) {
-    int q = 0;
-    if (lane == 0) q = atomicAdd(&q_head, 1);
-    q = __shfl(q, 0);
-    if (q >= nbig) break;
-    const int t = big_queue[q];
-    int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
-    const VtxRec v0 = vv[i0];
-    VtxRec v1 = vv[i1], v2 = vv[i2];
-    const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, y0, y1);
-    const int bw = s.xmax - s.xmin + 1, bh = s.ymax - s.ymin + 1;
-    for (int i = lane; i < bw * bh; i += 64) raster_pixel(s, s.xmin + i % bw, s.ymin + i / bw, t, y0, w, zbuf);
-  }
-  __syncthreads();
+}
 
-  // ---- pass 2: resolve + shade, pixel-parallel ----------------------------------------------------
-  const float* T = TCO + (size_t)view * 16;
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // s_waitcnt lgkmcnt(0): this wave's LDS writes are visible to its own lanes
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One wave-uniform piece against the 64 pixels (x NS samples) of a tile.  (px, py) = this lane's pixel.
+template <int NS>
+__device__ __forceinline__ void cover_piece(const Piece& p, int tile_x0, int tile_y0, int px, int py, Sample (&st)[NS]) {
+  // uniform reject: the piece's bbox against the tile's sample area
+  const int Xmin = min(p.X[0], min(p.X[1], p.X[2])), Xmax = max(p.X[0], max(p.X[1], p.X[2]));
+  const int Ymin = min(p.Y[0], min(p.Y[1], p.Y[2])), Ymax = max(p.Y[0], max(p.Y[1], p.Y[2]));
+  const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
+  if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) return;
+  if (NS > 1 && rc::piece_is_small(p, tile_x0, tile_y0)) {  // wave-level early out: no lane can own a covered sample
+    rc::Edges32 e;
+    rc::piece_edges32(p, e);
+    if (__ballot(rc::maybe_covered32(e, px, py)) == 0ull) return;
+  }
+  rc::cover_lane<NS>(p, tile_x0, tile_y0, px, py, st);
+}
+
+template <int NS>
+__global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
+    const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
+    const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
+    float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
+    long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];  // [TILE_WAVES * 64][run] then the per-wave task / result arrays
+  unsigned* tasks_all = (unsigned*)(stage + (size_t)TILE_WAVES * 64 * run);   // [TILE_WAVES][64 * NS]
+  uint2* res_all = (uint2*)(tasks_all + TILE_WAVES * 64 * NS);                // [TILE_WAVES][64][NS]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groups_x = (lay.tiles_x + TILE_WAVES - 1) / TILE_WAVES;
+  int b = blockIdx.x;
+  const int gx = b % groups_x; b /= groups_x;
+  const int ty = b % lay.tiles_y;
+  const int item = b / lay.tiles_y;
+  const int tx = gx * TILE_WAVES + wave;
+  const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
+  const int px = tile_x0 + (lane & 7), py = tile_y0 + (lane >> 3);
+  const bool wave_active = tx < lay.tiles_x;
+  float* my_stage = stage + (size_t)(wave * 64 + lane) * run;
+  unsigned* tasks = tasks_all + wave * 64 * NS;
+  uint2* res = res_all + (size_t)wave * 64 * NS;
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0;
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
-  const bool no_quant = flags & MP_RASTER_NO_QUANT;
-  float* out_v = out + (size_t)(view / views_per_item) * stride_v + (size_t)(view % views_per_item) * stride_view;
-  // channel map of the staged values -> output channel (only the enabled groups), so the store loop below can walk
-  // (pixel, channel) pairs with consecutive lanes on consecutive addresses (24/28-byte pieces instead of 4-byte scatters)
-  int n_ch = 0;
-  int ch_src[STAGE_CH], ch_dst[STAGE_CH];
-  if (c_rgb >= 0) { for (int k = 0; k < 3; ++k) { ch_src[n_ch] = k; ch_dst[n_ch++] = c_rgb + k; } }
-  if (do_norm) { for (int k = 0; k < 3; ++k) { ch_src[n_ch] = 3 + k; ch_dst[n_ch++] = c_normals + k; } }
-  if (do_depth) { ch_src[n_ch] = 6; ch_dst[n_ch++] = c_depth; }
-  for (int base = 0; base < npix; base += BAND_THREADS) {
-    const int i = base + threadIdx.x;
-    const bool live = i < npix;
-    const int py = y0 + (live ? i : 0) / w, px = (live ? i : 0) % w;
-    const unsigned long long key = live ? zbuf[i] : ~0ull;
-    float r = 0.f, g = 0.f, b = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, depth = 0.f;
-    if (key != ~0ull) {
-      const int t = (int)(key & 0xFFFFFFFFu);
-      int i0 = m.faces[3 * t], i1 = m.faces[3 * t + 1], i2 = m.faces[3 * t + 2];
-      const VtxRec v0 = vv[i0];
-      VtxRec v1 = vv[i1], v2 = vv[i2];
-      const int i1_in = i1;
-      const TriSetup s = tri_setup(v0, v1, v2, i1, i2, w, py, py);
-      float b0, b1, b2, wsum;
-      (void)sample_tri(s, px, py, b0, b1, b2, wsum);
-      const float w0 = b0 * s.iz0, w1 = b1 * s.iz1, w2 = b2 * s.iz2;
-      const float z = 1.0f / wsum;
-      depth = z;
-      const float* c0 = m.colors + 3 * i0; const float* c1 = m.colors + 3 * i1; const float* c2 = m.colors + 3 * i2;
-      float ar = fmaf(w2, c2[0], fmaf(w1, c1[0], w0 * c0[0])) * z;
-      float ag = fmaf(w2, c2[1], fmaf(w1, c1[1], w0 * c0[1])) * z;
-      float ab = fmaf(w2, c2[2], fmaf(w1, c1[2], w0 * c0[2])) * z;
-      if (m.uvs) {
-        const float* uv = m.uvs + 6 * (size_t)t;
-        const int k1 = (i1 == i1_in) ? 1 : 2, k2 = 3 - k1;   // corner slots follow the orientation swap
-        const float u = fmaf(w2, uv[2 * k2], fmaf(w1, uv[2 * k1], w0 * uv[0])) * z;
-        const float v = fmaf(w2, uv[2 * k2 + 1], fmaf(w1, uv[2 * k1 + 1], w0 * uv[1])) * z;
-        float tr, tg, tb2;
-        const TexDev& tx = texs[mesh_ids[view]];
-        tex_sample(tx, tex_level(tx, uv, s.inv_area), u, v, tr, tg, tb2);
-        ar *= tr / 255.0f; ag *= tg / 255.0f; ab *= tb2 / 255.0f;
-      }
-      const float* n0 = m.normals + 3 * i0; const float* n1 = m.normals + 3 * i1; const float* n2 = m.normals + 3 * i2;
-      // interpolated object-frame normal (perspective-correct, NOT renormalised: texcoord semantics)
-      const float onx = fmaf(w2, n2[0], fmaf(w1, n1[0], w0 * n0[0])) * z;
-      const float ony = fmaf(w2, n2[1], fmaf(w1, n1[1], w0 * n0[1])) * z;
-      const float onz = fmaf(w2, n2[2], fmaf(w1, n1[2], w0 * n0[2])) * z;
-      float lr = lights.ambient[0], lg = lights.ambient[1], lb = lights.ambient[2];
-      if (lights.n_point > 0) {
-        const float* p0 = m.verts + 3 * i0; const float* p1 = m.verts + 3 * i1; const float* p2 = m.verts + 3 * i2;
-        const float ox = fmaf(w2, p2[0], fmaf(w1, p1[0], w0 * p0[0])) * z;
-        const float oy = fmaf(w2, p2[1], fmaf(w1, p1[1], w0 * p0[1])) * z;
-        const float oz = fmaf(w2, p2[2], fmaf(w1, p1[2], w0 * p0[2])) * z;
-        const float nn = sqrtf(fmaf(onz, onz, fmaf(ony, ony, onx * onx)));
-        const float inn = nn > 0.f ? 1.0f / nn : 0.f;
-        const float R10 = 10.0f * m.radius;
-        for (int l = 0; l < lights.n_point; ++l) {
-          const float lx = fmaf(lights.dir[l][0], R10, -ox);
-          const float ly = fmaf(lights.dir[l][1], R10, -oy);
-          const float lz = fmaf(lights.dir[l][2], R10, -oz);
-          const float ln = sqrtf(fmaf(lz, lz, fmaf(ly, ly, lx * lx)));
-          const float d = fmaf(lz, onz, fmaf(ly, ony, lx * onx)) * inn / ln;
-          const float dd = fmaxf(d, 0.f);
-          lr = fmaf(lights.color[l][0], dd, lr);
-          lg = fmaf(lights.color[l][1], dd, lg);
-          lb = fmaf(lights.color[l][2], dd, lb);
+
+  if (wave_active) {
+    for (int r = 0; r < views_per_item; ++r) {
+      const int view = item * views_per_item + r;
+      const int mesh_id = mesh_ids[view];
+      const MeshDev m = meshes[mesh_id];
+      const float* T = TCO + (size_t)view * 16;
+      const float* Kv = K + (size_t)view * 9;
+      const int* hdr = ws + (size_t)view * lay.view_ints;
+      const int* tile_off = hdr + HDR_INTS;
+      const int* list = tile_off + lay.n_tiles + 1;
+      const int* large = list + lay.cap_list;
+      const int tile = ty * lay.tiles_x + tx;
+      const bool overflow = hdr[2] != 0;
+      const int begin = overflow ? 0 : tile_off[tile];
+      const int n_list = overflow ? 2 * m.n_faces : tile_off[tile + 1] - begin;
+      const int n_large = overflow ? 0 : hdr[0];
+      const int n_total = n_list + n_large;
+      Sample st[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { st[s].wsum = 0.f; st[s].id = -1; }
+      // ---- coverage + depth: 64 listed pieces are set up lane-parallel, then broadcast one at a time ---------------------------
+      for (int base = 0; base < n_total; base += 64) {
+        const int e = base + lane;
+        int idx = -1;
+        if (e < n_list) idx = overflow ? e : list[begin + e];
+        else if (e < n_total) idx = large[e - n_list];
+        Piece mine;
+        mine.id = -1;
+        if (idx >= 0) rc::piece_from_index<false>(m, T, Kv, idx, mine);
+        const int n_here = min(64, n_total - base);
+        for (int j = 0; j < n_here; ++j) {
+          Piece p;
+          p.id = rl(mine.id, j);
+          if (p.id < 0) continue;
+          p.X[0] = rl(mine.X[0], j); p.Y[0] = rl(mine.Y[0], j);
+          p.X[1] = rl(mine.X[1], j); p.Y[1] = rl(mine.Y[1], j);
+          p.X[2] = rl(mine.X[2], j); p.Y[2] = rl(mine.Y[2], j);
+          p.iz[0] = rlf(mine.iz[0], j); p.iz[1] = rlf(mine.iz[1], j); p.iz[2] = rlf(mine.iz[2], j);
+          cover_piece<NS>(p, tile_x0, tile_y0, px, py, st);
         }
       }
-      ar *= lr; ag *= lg; ab *= lb;
-      if (no_quant) { r = ar; g = ag; b = ab; }
-      else { r = quant8(ar * 255.0f); g = quant8(ag * 255.0f); b = quant8(ab * 255.0f); }
-      if (do_norm) {
-        // eye-space normal: camera (OpenCV) frame first, then the eye-axis convention
-        const float cx = fmaf(T[2], onz, fmaf(T[1], ony, T[0] * onx));
-        const float cy = fmaf(T[6], onz, fmaf(T[5], ony, T[4] * onx));
-        const float cz = fmaf(T[10], onz, fmaf(T[9], ony, T[8] * onx));
-        float ex, ey, ez;
-        if (gl_eye) { ex = cx; ey = -cy; ez = -cz; }   // GL eye: x right, y up, z back
-        else { ex = cx; ey = cz; ez = -cy; }           // Panda view: x right, y forward, z up (TCCGL, types.py:40)
-        if (no_quant) { nx = normal_lut(ex) / 255.0f; ny = normal_lut(ey) / 255.0f; nz = normal_lut(ez) / 255.0f; }
-        else { nx = quant8(normal_lut(ex)); ny = quant8(normal_lut(ey)); nz = quant8(normal_lut(ez)); }
-      }
-    }
-    float* st = stage + threadIdx.x * STAGE_CH;
-    st[0] = r; st[1] = g; st[2] = b; st[3] = nx; st[4] = ny; st[5] = nz; st[6] = depth;
-    __syncthreads();
-    const int n_here = min(BAND_THREADS, npix - base);
-    // 8 lanes per pixel (channel slot k = lane & 7, active while k < n_ch), 64 pixels per pass: consecutive lanes write
-    // consecutive floats of one pixel, no per-element integer division (the chunk's first (row, col) is wave-uniform).
-    const int k = threadIdx.x & 7;
-    int src = ch_src[0], dst = ch_dst[0];
+      // ---- shading tasks: one per (pixel, distinct winning piece), ordered by (sample, lane) -----------------------------------
+      int n_tasks = 0;
+      bool is_new[NS];
 #pragma unroll
-    for (int q = 1; q < STAGE_CH; ++q) if (k == q) { src = ch_src[q]; dst = ch_dst[q]; }
-    const int row0 = base / w, col0 = base - row0 * w;
-    for (int pl = threadIdx.x >> 3; pl < n_here; pl += BAND_THREADS / 8) {
-      int col = col0 + pl, rowp = row0;
-      while (col >= w) { col -= w; ++rowp; }
-      if (k < n_ch) out_v[(size_t)(y0 + rowp) * stride_y + (size_t)col * stride_x + dst] = stage[pl * STAGE_CH + src];
+      for (int s = 0; s < NS; ++s) {
+        bool nw = st[s].id >= 0;
+#pragma unroll
+        for (int k = 0; k < s; ++k) nw = nw && !(st[k].id == st[s].id);
+        is_new[s] = nw;
+        const unsigned long long mask = __ballot(nw);
+        if (nw) tasks[n_tasks + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned)st[s].id << 8) | ((unsigned)s << 6) | (unsigned)lane;
+        n_tasks += __popcll(mask);
+      }
+      wave_lds_fence();
+      const TexDev* tex = m.uvs ? &texs[mesh_id] : nullptr;
+      for (int k0 = 0; k0 < n_tasks; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < n_tasks) {
+          const unsigned tk = tasks[k];
+          const int tl = tk & 63, ts = (tk >> 6) & 3, id = (int)(tk >> 8);
+          Piece pf;
+          rc::piece_from_index<true>(m, T, Kv, id, pf);
+          float c255[3], n255[3];
+          rc::shade(m, tex, lights, T, gl_eye, do_norm, pf, tile_x0 + (tl & 7), tile_y0 + (tl >> 3), c255, n255);
+          uint2 q;
+          q.x = (unsigned)rc::q255(c255[0]) | ((unsigned)rc::q255(c255[1]) << 8) | ((unsigned)rc::q255(c255[2]) << 16);
+          q.y = (unsigned)rc::q255(n255[0]) | ((unsigned)rc::q255(n255[1]) << 8) | ((unsigned)rc::q255(n255[2]) << 16);
+          res[tl * NS + ts] = q;
+        }
+      }
+      wave_lds_fence();
+      // ---- resolve: mean of the samples' 8-bit values, background samples = 0 --------------------------------------------------
+      float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (st[s].id < 0) continue;
+        int src = s;
+#pragma unroll
+        for (int k = s - 1; k >= 0; --k)
+          if (st[k].id == st[s].id) src = k;   // ends at the first sample holding this piece (the one that was shaded)
+        const uint2 q = res[lane * NS + src];
+        acc[0] += (float)(q.x & 255u); acc[1] += (float)((q.x >> 8) & 255u); acc[2] += (float)((q.x >> 16) & 255u);
+        acc[3] += (float)(q.y & 255u); acc[4] += (float)((q.y >> 8) & 255u); acc[5] += (float)((q.y >> 16) & 255u);
+      }
+      (void)is_new;
+      const long long cv = (long long)r * stride_view;
+      if (c_rgb >= 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) my_stage[c_rgb + cv + c - c_lo] = rc::resolve_channel(acc[c], NS, false);
+      }
+      if (do_norm) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) my_stage[c_normals + cv + c - c_lo] = rc::resolve_channel(acc[3 + c], NS, false);
+      }
+      if (do_depth) my_stage[c_depth + cv - c_lo] = st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f;
+      wave_lds_fence();  // the task / result arrays are reused by the next view
     }
-    __syncthreads();
+    if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
+      const float* bx = crop.boxes + (size_t)item * 4;
+      const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+      const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
+      const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
+      const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
+      float cvals[4];
+      if (crop.nhwc4) {
+        if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+        else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+      } else {
+        if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+        else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+      }
+      my_stage[crop.c0 - c_lo] = cvals[0]; my_stage[crop.c0 + 1 - c_lo] = cvals[1]; my_stage[crop.c0 + 2 - c_lo] = cvals[2];
+      if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cvals[3];
+    }
+  }
+  __syncthreads();
+  // ---- store: the strip's pixels leave as contiguous channel runs (row-major over the 8 rows x 32 pixels x run floats) ----------
+  float* out_item = out + (size_t)item * stride_v + c_lo;
+  const int strip_w = min(TILE_WAVES * TILE, w - gx * TILE_WAVES * TILE);   // pixels of this strip inside the image
+  const int rows = min(TILE, h - tile_y0);
+  const int per_row = strip_w * run;
+  for (int i = threadIdx.x; i < rows * per_row; i += 64 * TILE_WAVES) {
+    const int row = i / per_row, rem = i - row * per_row;
+    const int x = rem / run, c = rem - x * run;
+    if (!((run_mask >> c) & 1u)) continue;
+    const int wv = x >> 3, ln = (row << 3) | (x & 7);
+    out_item[(size_t)(tile_y0 + row) * stride_y + (size_t)(gx * TILE_WAVES * TILE + x) * stride_x + c] = stage[(size_t)(wv * 64 + ln) * run + c];
   }
 }
 
@@ -550,6 +357,7 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
     const mp_mesh_desc& d = hm[i];
     MP_REQUIRE(d.h_vertices && d.h_normals && d.h_colors && d.h_faces && d.n_vertices > 0 && d.n_faces > 0,
                "mp_mesh_db_create: mesh %d incomplete", i);
+    MP_REQUIRE(d.n_faces < (1 << 22), "mp_mesh_db_create: mesh %d has %d faces (limit 4 194 303: piece ids are packed in 24 bits)", i, d.n_faces);
     for (int f = 0; f < 3 * d.n_faces; ++f)
       MP_REQUIRE(d.h_faces[f] >= 0 && d.h_faces[f] < d.n_vertices, "mp_mesh_db_create: mesh %d face index out of range", i);
     MeshDev m;
@@ -574,12 +382,13 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
         lo[k] = fminf(lo[k], d.h_vertices[3 * v + k]);
         hi[k] = fmaxf(hi[k], d.h_vertices[3 * v + k]);
       }
-    for (int k = 0; k < 3; ++k) m.center[k] = 0.5f * (lo[k] + hi[k]);
+    float center[3];
+    for (int k = 0; k < 3; ++k) center[k] = 0.5f * (lo[k] + hi[k]);
     float r2 = 0.f;
     for (int v = 0; v < d.n_vertices; ++v) {
       float s = 0.f;
       for (int k = 0; k < 3; ++k) {
-        const float dd = d.h_vertices[3 * v + k] - m.center[k];
+        const float dd = d.h_vertices[3 * v + k] - center[k];
         s += dd * dd;
       }
       r2 = fmaxf(r2, s);
@@ -638,10 +447,20 @@ extern "C" float mp_mesh_db_radius(const mp_mesh_db* db, int i) {
   return (db && i >= 0 && i < db->n) ? db->h_meshes[i].radius : 0.f;
 }
 
-static inline int faces_stride(const mp_mesh_db* db) { return (db->max_faces + 3) & ~3; }  // 16-byte aligned bounds rows
+static BinLayout bin_layout(const mp_mesh_db* db, int h, int w) {
+  BinLayout lay;
+  lay.tiles_x = ceil_div(w, TILE);
+  lay.tiles_y = ceil_div(h, TILE);
+  lay.n_tiles = lay.tiles_x * lay.tiles_y;
+  lay.max_faces = db->max_faces;
+  lay.cap_list = 4 * db->max_faces + 2048;
+  lay.view_ints = ((long long)HDR_INTS + lay.n_tiles + 1 + lay.cap_list + 2LL * db->max_faces + 3) & ~3LL;
+  return lay;
+}
 
-extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views) {
-  return db ? (size_t)n_views * ((size_t)db->max_verts * sizeof(VtxRec) + (size_t)faces_stride(db) * sizeof(unsigned)) : 0;
+extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views, int h, int w) {
+  if (!db || n_views <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)n_views * (size_t)bin_layout(db, h, w).view_ints * sizeof(int);
 }
 
 static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
@@ -649,49 +468,72 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
                               int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
                               int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream, const CropArgs& crop) {
   MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
-  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && views_per_item >= 1, "mp_raster_render: bad size");
+  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && h <= 1024 && views_per_item >= 1, "mp_raster_render: bad size");
   MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
+  MP_REQUIRE((flags & ~(MP_RASTER_NORMALS | MP_RASTER_DEPTH | MP_RASTER_NORMALS_GL | MP_RASTER_MSAA4)) == 0, "mp_raster_render: unknown flag bits 0x%x", flags);
   if (n_views == 0) return MP_OK;
-  MP_REQUIRE(ws_bytes >= mp_raster_workspace_bytes(db, n_views), "mp_raster_render: workspace too small");
-  MP_REQUIRE(n_views <= 65535, "mp_raster_render: at most 65535 views per call");
+  MP_REQUIRE(ws_bytes >= mp_raster_workspace_bytes(db, n_views, h, w), "mp_raster_render: workspace too small");
+  MP_REQUIRE(n_views % views_per_item == 0, "mp_raster_render: n_views (%d) must be a multiple of views_per_item (%d)", n_views, views_per_item);
   hipStream_t s = (hipStream_t)stream;
   LightsDev L;
   memcpy(L.ambient, lights->ambient, sizeof(L.ambient));
   L.n_point = lights->n_point;
   memcpy(L.dir, lights->point_dir, sizeof(L.dir));
   memcpy(L.color, lights->point_color, sizeof(L.color));
-  VtxRec* vtx = (VtxRec*)d_ws;
-  dim3 g1(ceil_div(db->max_verts, 256), n_views);
+  memcpy(L.offset, lights->point_offset, sizeof(L.offset));
+  const BinLayout lay = bin_layout(db, h, w);
+  const int ns = (flags & MP_RASTER_MSAA4) ? 4 : 1;
+  const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0, do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
+  // channel run [c_lo, c_hi) one pixel record of this launch spans, and which of its channels are written
+  int c_lo = 1 << 30, c_hi = -1;
+  auto span = [&](int c0, int n) { c_lo = std::min(c_lo, c0); c_hi = std::max(c_hi, c0 + n); };
+  for (int r = 0; r < views_per_item; ++r) {
+    if (c_rgb >= 0) span(c_rgb + r * (int)stride_view, 3);
+    if (do_norm) span(c_normals + r * (int)stride_view, 3);
+    if (do_depth) span(c_depth + r * (int)stride_view, 1);
+  }
+  if (crop.images) span(crop.c0, crop.C);
+  MP_REQUIRE(c_hi > c_lo, "mp_raster_render: nothing to write");
+  const int run = c_hi - c_lo;
+  MP_REQUIRE(run <= MAX_RUN, "mp_raster_render: one launch writes at most %d channels per pixel (asked for %d)", MAX_RUN, run);
+  MP_REQUIRE(stride_x >= run, "mp_raster_render: stride_x (%lld) smaller than the channel run (%d)", (long long)stride_x, run);
+  uint32_t mask = 0;
+  auto mark = [&](int c0, int n) { for (int c = c0; c < c0 + n; ++c) mask |= 1u << (c - c_lo); };
+  for (int r = 0; r < views_per_item; ++r) {
+    if (c_rgb >= 0) mark(c_rgb + r * (int)stride_view, 3);
+    if (do_norm) mark(c_normals + r * (int)stride_view, 3);
+    if (do_depth) mark(c_depth + r * (int)stride_view, 1);
+  }
+  if (crop.images) mark(crop.c0, crop.C);
   {
-  ProfScope prof("raster_transform", 0.0, (double)n_views * db->max_verts * (12.0 + sizeof(VtxRec)), s);
-  hipLaunchKernelGGL(raster_transform, g1, dim3(256), 0, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, db->max_verts, vtx);
+    const size_t lds = (size_t)lay.n_tiles * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bin, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      attr_set = true;
+    }
+    ProfScope prof("raster_bin", 0.0, (double)n_views * (12.0 * db->max_faces + 12.0 * db->max_verts + 4.0 * lay.n_tiles), s);
+    hipLaunchKernelGGL(raster_bin, dim3(n_views), dim3(BIN_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, h, w, ns, (int*)d_ws, lay);
   }
-  unsigned* tri_bounds = (unsigned*)(vtx + (size_t)n_views * db->max_verts);
-  {
-    ProfScope prof("raster_tri_bounds", 0.0, (double)n_views * db->max_faces * (12.0 + 4.0), s);
-    hipLaunchKernelGGL(raster_tri_bounds, dim3(ceil_div(db->max_faces, 256), n_views), dim3(256), 0, s, db->d_meshes, d_mesh_ids, vtx,
-                       db->max_verts, faces_stride(db), h, tri_bounds);
-  }
-  const size_t lds = (size_t)BAND_H * w * sizeof(unsigned long long) + (BIG_QUEUE + LIST_CAP) * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bands<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
-  }
-  MP_REQUIRE(lds <= 160 * 1024 - 64, "mp_raster_render: image too wide for the LDS z-buffer");
-  MP_REQUIRE(n_views % views_per_item == 0, "mp_raster_render: n_views (%d) must be a multiple of views_per_item (%d)", n_views, views_per_item);
   const int n_items = n_views / views_per_item;
-  const int roles = views_per_item + (crop.images ? 1 : 0);
-  dim3 g2(ceil_div(n_items * ceil_div(h, BAND_H), 8) * 8 * roles);
-  const int n_ch = (c_rgb >= 0 ? 3 : 0) + (((flags & MP_RASTER_NORMALS) && c_normals >= 0) ? 3 : 0) + (((flags & MP_RASTER_DEPTH) && c_depth >= 0) ? 1 : 0);
+  const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
+  const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
+  MP_REQUIRE(n_wg < (1LL << 31), "mp_raster_render: grid too large");
+  const size_t lds = (size_t)TILE_WAVES * 64 * run * sizeof(float) + (size_t)TILE_WAVES * 64 * ns * (sizeof(unsigned) + sizeof(uint2));
+  const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
   const double crop_bytes = crop.images ? (double)n_items * 2.0 * crop.C * 4.0 * h * w : 0.0;
-  ProfScope prof("raster_bands", 0.0,
+  ProfScope prof("raster_tiles", 0.0,
                  (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) + crop_bytes, s);
-  hipLaunchKernelGGL(raster_bands<false>, g2, dim3(BAND_THREADS), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, vtx, tri_bounds,
-                     db->max_verts, faces_stride(db), h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view, (long long)stride_y,
-                     (long long)stride_x, c_rgb, c_normals, c_depth, crop);
+  if (ns == 4)
+    hipLaunchKernelGGL(raster_tiles<4>, dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, d_K,
+                       (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
+                       (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
+  else
+    hipLaunchKernelGGL(raster_tiles<1>, dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, d_K,
+                       (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
+                       (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

@@ -78,15 +78,24 @@ struct CVert {
   float bary[3];
 };
 
-MP_HD CVert clip_edge(const CVert& in, const CVert& out, int i_in, int i_out) {
+// intersection of the edge in -> out with the near plane; in.bary / out.bary are the rows of the original corners (unit
+// vectors), so fmaf(t, out.bary, (1 - t) * in.bary) is exactly {1 - t at in's corner, t at out's corner, 0 elsewhere}
+MP_HD CVert clip_edge(const CVert& in, const CVert& out) {
   CVert r;
   const float t = (Z_NEAR - in.z) / (out.z - in.z);
   r.x = fmaf(t, out.x - in.x, in.x);
   r.y = fmaf(t, out.y - in.y, in.y);
   r.z = Z_NEAR;
-  r.bary[0] = r.bary[1] = r.bary[2] = 0.f;
-  r.bary[i_in] = 1.0f - t;
-  r.bary[i_out] = t;
+  const float s = 1.0f - t;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) r.bary[j] = fmaf(t, out.bary[j], s * in.bary[j]);
+  return r;
+}
+
+MP_HD CVert sel(bool c, const CVert& a, const CVert& b) {  // c ? a : b, field by field (no dynamically indexed arrays: they
+  CVert r;                                                  // would live in scratch memory on the GPU)
+  r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z;
+  r.bary[0] = c ? a.bary[0] : b.bary[0]; r.bary[1] = c ? a.bary[1] : b.bary[1]; r.bary[2] = c ? a.bary[2] : b.bary[2];
   return r;
 }
 
@@ -95,33 +104,28 @@ template <bool WITH_BARY>
 MP_HD void finish_piece(const CVert& v0, const CVert& v1, const CVert& v2, const float* Kv, int tri, int id, Piece& p) {
   p.id = -1;
   p.tri = tri;
-  const CVert* v[3] = {&v0, &v1, &v2};
-  int X[3], Y[3];
-  float iz[3];
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    iz[k] = 1.0f / v[k]->z;
-    const float sx = fmaf(Kv[0], v[k]->x * iz[k], Kv[2]);
-    const float sy = fmaf(Kv[4], v[k]->y * iz[k], Kv[5]);
-    ok = ok && (fabsf(sx) < GUARD) && (fabsf(sy) < GUARD);
-    X[k] = (int)rintf(sx * (float)SUBPIX);
-    Y[k] = (int)rintf(sy * (float)SUBPIX);
-  }
+  const float iz0 = 1.0f / v0.z, iz1 = 1.0f / v1.z, iz2 = 1.0f / v2.z;
+  const float sx0 = fmaf(Kv[0], v0.x * iz0, Kv[2]), sy0 = fmaf(Kv[4], v0.y * iz0, Kv[5]);
+  const float sx1 = fmaf(Kv[0], v1.x * iz1, Kv[2]), sy1 = fmaf(Kv[4], v1.y * iz1, Kv[5]);
+  const float sx2 = fmaf(Kv[0], v2.x * iz2, Kv[2]), sy2 = fmaf(Kv[4], v2.y * iz2, Kv[5]);
+  const bool ok = (fabsf(sx0) < GUARD) && (fabsf(sy0) < GUARD) && (fabsf(sx1) < GUARD) && (fabsf(sy1) < GUARD) && (fabsf(sx2) < GUARD) &&
+                  (fabsf(sy2) < GUARD);
   if (!ok) return;
-  const long long area = (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]) - (long long)(Y[1] - Y[0]) * (long long)(X[2] - X[0]);
+  const int X0 = (int)rintf(sx0 * (float)SUBPIX), Y0 = (int)rintf(sy0 * (float)SUBPIX);
+  const int X1 = (int)rintf(sx1 * (float)SUBPIX), Y1 = (int)rintf(sy1 * (float)SUBPIX);
+  const int X2 = (int)rintf(sx2 * (float)SUBPIX), Y2 = (int)rintf(sy2 * (float)SUBPIX);
+  const long long area = (long long)(X1 - X0) * (long long)(Y2 - Y0) - (long long)(Y1 - Y0) * (long long)(X2 - X0);
   if (area == 0) return;
-  const bool swap = area < 0;
-  const int o1 = swap ? 2 : 1, o2 = swap ? 1 : 2;
-  p.X[0] = X[0]; p.Y[0] = Y[0]; p.iz[0] = iz[0];
-  p.X[1] = X[o1]; p.Y[1] = Y[o1]; p.iz[1] = iz[o1];
-  p.X[2] = X[o2]; p.Y[2] = Y[o2]; p.iz[2] = iz[o2];
+  const bool swap = area < 0;  // two-sided: a negatively oriented piece is drawn with its vertices 1 and 2 exchanged
+  p.X[0] = X0; p.Y[0] = Y0; p.iz[0] = iz0;
+  p.X[1] = swap ? X2 : X1; p.Y[1] = swap ? Y2 : Y1; p.iz[1] = swap ? iz2 : iz1;
+  p.X[2] = swap ? X1 : X2; p.Y[2] = swap ? Y1 : Y2; p.iz[2] = swap ? iz1 : iz2;
   if (WITH_BARY) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      p.bary[0][j] = v[0]->bary[j];
-      p.bary[1][j] = v[o1]->bary[j];
-      p.bary[2][j] = v[o2]->bary[j];
+      p.bary[0][j] = v0.bary[j];
+      p.bary[1][j] = swap ? v2.bary[j] : v1.bary[j];
+      p.bary[2][j] = swap ? v1.bary[j] : v2.bary[j];
     }
   }
   p.id = id;
@@ -130,43 +134,51 @@ MP_HD void finish_piece(const CVert& v0, const CVert& v1, const CVert& v2, const
 // Piece `which` (0 = first, 1 = second) of triangle `tri` under pose T / intrinsics Kv.  Stateless: the binning pass, the
 // coverage pass and the shading pass each recompute the piece they need from the mesh (which stays L2-resident) instead of
 // round-tripping per-view set-up records through HBM.
+// Returns how many pieces the triangle has at most under this view (0, 1 or 2; a piece can still be rejected: p.id < 0).
 template <bool WITH_BARY>
 MP_HD int make_piece(const MeshRef& m, const float* T, const float* Kv, int tri, int which, Piece& p) {
-  // returns how many pieces the triangle has at most under this view (0, 1 or 2; a piece can still be rejected: p.id < 0)
   p.id = -1;
   p.tri = tri;
-  CVert c[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int vi = m.faces[3 * tri + k];
-    const float px = m.verts[3 * vi], py = m.verts[3 * vi + 1], pz = m.verts[3 * vi + 2];
-    c[k].x = dot3p(T[0], T[1], T[2], px, py, pz, T[3]);
-    c[k].y = dot3p(T[4], T[5], T[6], px, py, pz, T[7]);
-    c[k].z = dot3p(T[8], T[9], T[10], px, py, pz, T[11]);
-    c[k].bary[0] = c[k].bary[1] = c[k].bary[2] = 0.f;
-    c[k].bary[k] = 1.0f;
+  CVert c0, c1, c2;
+  {
+    const int v0 = m.faces[3 * tri], v1 = m.faces[3 * tri + 1], v2 = m.faces[3 * tri + 2];
+    const float* q0 = m.verts + 3 * (size_t)v0;
+    const float* q1 = m.verts + 3 * (size_t)v1;
+    const float* q2 = m.verts + 3 * (size_t)v2;
+    c0.x = dot3p(T[0], T[1], T[2], q0[0], q0[1], q0[2], T[3]); c0.y = dot3p(T[4], T[5], T[6], q0[0], q0[1], q0[2], T[7]);
+    c0.z = dot3p(T[8], T[9], T[10], q0[0], q0[1], q0[2], T[11]);
+    c1.x = dot3p(T[0], T[1], T[2], q1[0], q1[1], q1[2], T[3]); c1.y = dot3p(T[4], T[5], T[6], q1[0], q1[1], q1[2], T[7]);
+    c1.z = dot3p(T[8], T[9], T[10], q1[0], q1[1], q1[2], T[11]);
+    c2.x = dot3p(T[0], T[1], T[2], q2[0], q2[1], q2[2], T[3]); c2.y = dot3p(T[4], T[5], T[6], q2[0], q2[1], q2[2], T[7]);
+    c2.z = dot3p(T[8], T[9], T[10], q2[0], q2[1], q2[2], T[11]);
+    c0.bary[0] = 1.f; c0.bary[1] = 0.f; c0.bary[2] = 0.f;
+    c1.bary[0] = 0.f; c1.bary[1] = 1.f; c1.bary[2] = 0.f;
+    c2.bary[0] = 0.f; c2.bary[1] = 0.f; c2.bary[2] = 1.f;
   }
-  const bool in0 = c[0].z >= Z_NEAR, in1 = c[1].z >= Z_NEAR, in2 = c[2].z >= Z_NEAR;
+  const bool in0 = c0.z >= Z_NEAR, in1 = c1.z >= Z_NEAR, in2 = c2.z >= Z_NEAR;
   const int n_in = (int)in0 + (int)in1 + (int)in2;
   if (n_in == 3) {
-    if (which == 0) finish_piece<WITH_BARY>(c[0], c[1], c[2], Kv, tri, tri, p);
+    if (which == 0) finish_piece<WITH_BARY>(c0, c1, c2, Kv, tri, tri, p);
     return 1;
   }
   if (n_in == 0) return 0;
+  // rotate the corners (cyclic order kept) so that r0 is the single inside vertex (n_in == 1) or r2 the single outside one
+  const int k = n_in == 1 ? (in0 ? 0 : (in1 ? 1 : 2)) : (!in0 ? 1 : (!in1 ? 2 : 0));
+  const CVert r0 = sel(k == 0, c0, sel(k == 1, c1, c2));
+  const CVert r1 = sel(k == 0, c1, sel(k == 1, c2, c0));
+  const CVert r2 = sel(k == 0, c2, sel(k == 1, c0, c1));
   if (n_in == 1) {
     if (which != 0) return 1;
-    const int a = in0 ? 0 : (in1 ? 1 : 2), b = (a + 1) % 3, d = (a + 2) % 3;  // cyclic order a, b, d; a inside
-    const CVert P = clip_edge(c[a], c[b], a, b), Q = clip_edge(c[a], c[d], a, d);
-    finish_piece<WITH_BARY>(c[a], P, Q, Kv, tri, tri, p);
+    const CVert P = clip_edge(r0, r1), Q = clip_edge(r0, r2);
+    finish_piece<WITH_BARY>(r0, P, Q, Kv, tri, tri, p);
     return 1;
   }
-  const int o = !in0 ? 0 : (!in1 ? 1 : 2), a = (o + 1) % 3, b = (o + 2) % 3;  // cyclic order a, b, o; o outside
-  const CVert P = clip_edge(c[b], c[o], b, o);
+  const CVert P = clip_edge(r1, r2);
   if (which == 0) {
-    finish_piece<WITH_BARY>(c[a], c[b], P, Kv, tri, tri, p);
+    finish_piece<WITH_BARY>(r0, r1, P, Kv, tri, tri, p);
   } else {
-    const CVert Q = clip_edge(c[a], c[o], a, o);
-    finish_piece<WITH_BARY>(c[a], P, Q, Kv, tri, m.n_faces + tri, p);
+    const CVert Q = clip_edge(r0, r2);
+    finish_piece<WITH_BARY>(r0, P, Q, Kv, tri, m.n_faces + tri, p);
   }
   return 2;
 }
@@ -227,6 +239,20 @@ MP_HD bool eval_at(const Piece& p, const Edges& e, long long sx, long long sy, f
   return inside;
 }
 
+struct Sample {
+  float wsum;
+  int id;  // < 0: empty
+};
+
+MP_HD bool depth_in_range(float wsum) { return wsum >= 1.0f / Z_FAR && wsum <= 1.0f / Z_NEAR; }
+
+MP_HD void sample_update(Sample& s, float wsum, int id) {
+  if (s.id < 0 || wsum > s.wsum || (wsum == s.wsum && id < s.id)) {
+    s.wsum = wsum;
+    s.id = id;
+  }
+}
+
 // ---- 32-bit fast path of the edge functions (the GPU's inner loop) -----------------------------------------------------------
 // For a piece whose extent D = max(Xmax - Xmin, Ymax - Ymin) and whose distance R to the farthest sample of the 8x8 tile are both
 // <= 23170 sub-pixel units (90 px), every |E| = |dx * ry - dy * rx| <= 2 * 23170^2 < 2^31 and every factor fits 24 bits, so the
@@ -265,19 +291,54 @@ MP_HD void piece_edges32(const Piece& p, Edges32& e) {
 // E_i at sample (sx, sy), int32 (valid under piece_is_small)
 MP_HD int edge32(const Edges32& e, int i, int sx, int sy) { return e.dx[i] * (sy - e.ay[i]) - e.dy[i] * (sx - e.ax[i]); }
 
-struct Sample {
-  float wsum;
-  int id;  // < 0: empty
-};
+// conservative per-lane test of the 32-bit path: can ANY sample of pixel (px, py) be inside the (small) piece?
+// (no sample is farther than 96/256 px from the pixel centre in x or y)
+MP_HD bool maybe_covered32(const Edges32& e, int px, int py) {
+  const int cx = px * SUBPIX + 128, cy = py * SUBPIX + 128;
+  bool maybe = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) maybe = maybe && (edge32(e, i, cx, cy) + (abs(e.dx[i]) + abs(e.dy[i])) * 96 >= e.thr[i]);
+  return maybe;
+}
 
-MP_HD bool depth_in_range(float wsum) { return wsum >= 1.0f / Z_FAR && wsum <= 1.0f / Z_NEAR; }
-
-MP_HD void sample_update(Sample& s, float wsum, int id) {
-  if (s.id < 0 || wsum > s.wsum || (wsum == s.wsum && id < s.id)) {
-    s.wsum = wsum;
-    s.id = id;
+// One piece against the NS samples of pixel (px, py) of the tile at (tile_x0, tile_y0): coverage, depth range, depth test.
+template <int NS>
+MP_HD void cover_lane(const Piece& p, int tile_x0, int tile_y0, int px, int py, Sample (&st)[NS]) {
+  if (piece_is_small(p, tile_x0, tile_y0)) {
+    Edges32 e;
+    piece_edges32(p, e);
+    const int cx = px * SUBPIX + 128, cy = py * SUBPIX + 128;
+    int ec[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ec[i] = edge32(e, i, cx, cy);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int ox = sample_off_x(NS, s) - 128, oy = sample_off_y(NS, s) - 128;
+      int es[3];
+      bool inside = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        es[i] = ec[i] + (e.dx[i] * oy - e.dy[i] * ox);
+        inside = inside && (es[i] >= e.thr[i]);
+      }
+      if (inside) {
+        const float b0 = (float)es[0] * e.inv_area, b1 = (float)es[1] * e.inv_area, b2 = (float)es[2] * e.inv_area;
+        const float wsum = fmaf(b2, p.iz[2], fmaf(b1, p.iz[1], b0 * p.iz[0]));
+        if (depth_in_range(wsum)) sample_update(st[s], wsum, p.id);
+      }
+    }
+  } else {
+    Edges e;
+    piece_edges(p, e);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float b[3], wsum;
+      const bool inside = eval_at(p, e, (long long)(px * SUBPIX + sample_off_x(NS, s)), (long long)(py * SUBPIX + sample_off_y(NS, s)), b, wsum);
+      if (inside && depth_in_range(wsum)) sample_update(st[s], wsum, p.id);
+    }
   }
 }
+
 
 // piece index (in the [0, 2F) space) from a depth-tie id: they coincide (first piece: tri, second: F + tri)
 MP_HD int index_of_id(int id) { return id; }

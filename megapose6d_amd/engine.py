@@ -18,7 +18,7 @@ from ._lib import ConvDesc, EngineError, Lights, MeshDesc, NamedTensor, check
 RASTER_NORMALS = 1
 RASTER_DEPTH = 2
 RASTER_NORMALS_GL = 4
-RASTER_NO_QUANT = 8
+RASTER_MSAA4 = 16   # 4x multisampling = the reference renderer's configuration (panda3d_scene_renderer.py:73-74)
 
 BACKBONE_KINDS = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2}
 
@@ -114,9 +114,9 @@ class MeshDB:
     def radius(self, i: int) -> float:
         return _lib.load().mp_mesh_db_radius(self.handle, i)
 
-    def workspace(self, n_views: int, device, slot: int = 0) -> torch.Tensor:
-        """scratch for the transformed vertices / triangle bounds; one per `slot` (= concurrent HIP stream)"""
-        need = _lib.load().mp_raster_workspace_bytes(self.handle, n_views)
+    def workspace(self, n_views: int, h: int, w: int, device, slot: int = 0) -> torch.Tensor:
+        """scratch for the per-view tile lists of a launch; one per `slot` (= concurrent HIP stream)"""
+        need = _lib.load().mp_raster_workspace_bytes(self.handle, n_views, h, w)
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < need or ws.device != torch.device(device):
             self._ws[slot] = ws = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
@@ -134,13 +134,15 @@ class MeshDB:
             pass
 
 
-def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()) -> Lights:
+def make_lights(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=(), point_offsets=None) -> Lights:
+    """point light i sits at dir_i * 10 * (bounding radius of the mesh) + offset_i in the object frame"""
     L = Lights()
     L.ambient[:] = ambient
     L.n_point = len(point_dirs)
     for i, (d, c) in enumerate(zip(point_dirs, point_colors)):
         L.point_dir[i][:] = d
         L.point_color[i][:] = c
+        L.point_offset[i][:] = point_offsets[i] if point_offsets is not None else (0.0, 0.0, 0.0)
     return L
 
 
@@ -167,7 +169,7 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     TCO = _dev_f32(TCO)
     K = _dev_f32(K)
     assert out.dtype == torch.float32 and out.is_cuda
-    ws = db.workspace(n, out.device, slot)
+    ws = db.workspace(n, h, w, out.device, slot)
     if crop is not None:
         images, im_ids, boxes, c0 = crop
         if isinstance(images, PackedObservation):

@@ -15,33 +15,65 @@ import torch
 
 from . import engine as eng
 from . import mesh_io
-from .types import BatchRenderOutput, Panda3dLightData, Resolution
+from .types import BatchRenderOutput, Panda3dLightData, Resolution, resolve_light_position
+
+
+def _point_light(l: Panda3dLightData, k: int):
+    """-> (dir, offset): position = dir * 10 * radius + offset (engine form of the reference's positioning_function)"""
+    if l.positioning_function is not None:
+        hit = getattr(l, "_mp_resolved", None)  # memo on the light object: render() is called with one light list per view
+        if hit is None or hit[0] is not l.positioning_function:
+            a, b = resolve_light_position(l.positioning_function)
+            hit = (l.positioning_function, (tuple(v / 10.0 for v in a), b))
+            try:
+                l._mp_resolved = hit
+            except Exception:  # frozen / slotted light classes of a caller: just recompute next time
+                pass
+        return hit[1]
+    if l.direction is not None:
+        return tuple(float(x) for x in l.direction), (0.0, 0.0, 0.0)
+    raise NotImplementedError("point light without positioning_function (reference types.py:104-114) or direction")
 
 
 def _lights_key(lights: Sequence[Panda3dLightData]):
-    return tuple((l.light_type, tuple(float(c) for c in l.color[:3]), tuple(l.direction) if l.direction else None) for l in lights)
+    key = []
+    k = 0
+    for l in lights:
+        pos = None
+        if l.light_type == "point":
+            pos = _point_light(l, k)
+            k += 1
+        key.append((l.light_type, tuple(float(c) for c in l.color[:3]), pos))
+    return tuple(key)
 
 
 def _to_engine_lights(lights: Sequence[Panda3dLightData]):
     amb = np.zeros(3, np.float64)
-    dirs, cols = [], []
-    axis = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    dirs, cols, offs = [], [], []
     for l in lights:
         if l.light_type == "ambient":
             amb += np.asarray(l.color[:3], np.float64)
         elif l.light_type == "point":
-            d = l.direction if l.direction is not None else axis[len(dirs) % 6]  # make_scene_lights order
-            dirs.append(tuple(float(x) for x in d))
+            d, o = _point_light(l, len(dirs))
+            dirs.append(d)
+            offs.append(o)
             cols.append(tuple(float(c) for c in l.color[:3]))
         else:
             raise NotImplementedError(l.light_type)
-    return eng.make_lights(tuple(float(a) for a in amb), dirs, cols)
+    if len(dirs) > 8:
+        raise NotImplementedError("at most 8 point lights per view")
+    return eng.make_lights(tuple(float(a) for a in amb), dirs, cols, offs)
 
 
 class Panda3dBatchRenderer:
     def __init__(self, object_dataset, n_workers: int = 8, preload_cache: bool = True, split_objects: bool = False,
-                 normals_eye_convention: str = "panda"):
+                 normals_eye_convention: str = "panda", msaa: int = 4):
+        """`msaa` = samples per pixel: 4 (default) is what the reference configures for Panda3D (framebuffer-multisample 1,
+        multisamples 4, panda3d_scene_renderer.py:73-74); 1 = a single sample at the pixel centre (faster, jagged silhouettes)."""
         assert n_workers >= 1
+        if msaa not in (1, 4):
+            raise ValueError("msaa must be 1 or 4")
+        self.msaa = msaa
         self._object_dataset = object_dataset
         self._n_workers = n_workers          # accepted for API compatibility; there are no workers
         self._split_objects = split_objects
@@ -73,6 +105,8 @@ class Panda3dBatchRenderer:
         flags = (eng.RASTER_NORMALS if c_normals >= 0 else 0) | (eng.RASTER_DEPTH if c_depth >= 0 else 0)
         if self._gl_eye:
             flags |= eng.RASTER_NORMALS_GL
+        if self.msaa == 4:
+            flags |= eng.RASTER_MSAA4
         h, w = resolution
         eng.raster_render(db, mesh_ids, TCO, K, h, w, flags, _to_engine_lights(lights), out, stride_v, stride_y, stride_x, c_rgb,
                           c_normals, c_depth, out_offset_floats, views_per_item, stride_view, slot, crop)

@@ -115,22 +115,87 @@ class BatchRenderOutput:
 
 @dataclass
 class Panda3dLightData:
+    """reference panda3d_renderer/types.py:104-114.  `positioning_function(root_node, light_node)` places a point light exactly as
+    in the reference (it reads `root_node.getBounds().radius` and calls `light_node.setPos(...)`); the engine evaluates it with
+    recording stand-ins (`resolve_light_position`).  `direction` is an engine shortcut: position = direction * 10 * radius."""
     light_type: str
     color: RgbaColor = (1.0, 1.0, 1.0, 1.0)
     positioning_function: Optional[Callable] = None
-    direction: Optional[Tuple[float, float, float]] = None  # engine extension: unit direction of a point light (pos = dir*10*radius)
+    direction: Optional[Tuple[float, float, float]] = None
 
 
 _POINT_DIRS = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
 
 
+def _scene_light_pos_fn(root_node, light_node, pos) -> None:
+    """panda3d_scene_renderer.py:121-126: the light sits at pos * 10 * (bounding radius of the scene root)"""
+    radius = root_node.getBounds().radius
+    light_node.setPos(tuple(float(p) * radius * 10 for p in pos))
+
+
 def make_scene_lights(ambient_light_color: RgbaColor = (0.1, 0.1, 0.1, 1.0),
                       point_lights_color: RgbaColor = (0.4, 0.4, 0.4, 1.0)) -> List[Panda3dLightData]:
     """1 ambient + 6 point lights on the +-axes at 10 x the bounding radius (panda3d_scene_renderer.py:104-136)."""
+    from functools import partial
+
     lights = [Panda3dLightData(light_type="ambient", color=ambient_light_color)]
     for d in _POINT_DIRS:
-        lights.append(Panda3dLightData(light_type="point", color=point_lights_color, direction=d))
+        lights.append(Panda3dLightData(light_type="point", color=point_lights_color, positioning_function=partial(_scene_light_pos_fn, pos=d)))
     return lights
+
+
+class _ProbeBounds:
+    def __init__(self, radius: float):
+        self.radius = radius
+
+    def getRadius(self) -> float:
+        return self.radius
+
+    get_radius = getRadius
+
+
+class _ProbeRoot:
+    """what a positioning_function may ask the scene root: getBounds().radius"""
+
+    def __init__(self, radius: float):
+        self._bounds = _ProbeBounds(radius)
+
+    def getBounds(self) -> _ProbeBounds:
+        return self._bounds
+
+    get_bounds = getBounds
+
+
+class _ProbeLight:
+    def __init__(self) -> None:
+        self.pos = None
+
+    def setPos(self, *a) -> None:
+        self.pos = tuple(float(v) for v in (a[0] if len(a) == 1 else a))
+
+    set_pos = setPos
+
+
+def resolve_light_position(positioning_function: Callable) -> Tuple[Tuple[float, float, float], Tuple[float, float, float]]:
+    """-> (a, b): the light's object-frame position is a * bounding_radius + b.  The function is called with stand-ins for the
+    panda3d nodes at radius 1, 2 and 4; anything that is not affine in the radius (or touches other NodePath API) raises
+    NotImplementedError instead of rendering a silently wrong light rig."""
+    pts = []
+    for r in (1.0, 2.0, 4.0):
+        light = _ProbeLight()
+        try:
+            positioning_function(_ProbeRoot(r), light)
+        except AttributeError as e:
+            raise NotImplementedError(f"positioning_function uses panda3d API the engine does not emulate: {e}") from e
+        if light.pos is None or len(light.pos) != 3:
+            raise NotImplementedError("positioning_function did not call setPos(x, y, z) on the light node")
+        pts.append(light.pos)
+    a = tuple(p2 - p1 for p1, p2 in zip(pts[0], pts[1]))
+    b = tuple(p1 - ai for p1, ai in zip(pts[0], a))
+    for k in range(3):
+        if abs(a[k] * 4.0 + b[k] - pts[2][k]) > 1e-9 * (1.0 + abs(pts[2][k])):
+            raise NotImplementedError("positioning_function is not affine in the bounding radius")
+    return a, b
 
 
 @dataclass

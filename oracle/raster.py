@@ -15,7 +15,8 @@ _LIB = _HERE / "_build" / "liboracle.so"
 
 
 class _Lights(C.Structure):
-    _fields_ = [("ambient", C.c_float * 3), ("n_point", C.c_int32), ("dir", (C.c_float * 3) * 8), ("color", (C.c_float * 3) * 8)]
+    _fields_ = [("ambient", C.c_float * 3), ("n_point", C.c_int32), ("dir", (C.c_float * 3) * 8), ("color", (C.c_float * 3) * 8),
+                ("offset", (C.c_float * 3) * 8)]
 
 
 _lib = None
@@ -38,14 +39,19 @@ def lib():
 POINT_DIRS = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]  # panda3d_scene_renderer.py:109-118
 
 
-def lights_struct(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=()):
+def lights_struct(ambient=(1.0, 1.0, 1.0), point_dirs=(), point_colors=(), point_offsets=None):
+    """point light i sits at dir_i * 10 * bounding radius + offset_i (object frame)"""
     L = _Lights()
     L.ambient[:] = ambient
     L.n_point = len(point_dirs)
     for i, (d, c) in enumerate(zip(point_dirs, point_colors)):
         L.dir[i][:] = d
         L.color[i][:] = c
+        L.offset[i][:] = point_offsets[i] if point_offsets is not None else (0.0, 0.0, 0.0)
     return L
+
+
+FLAG_NORMALS, FLAG_DEPTH, FLAG_GL_EYE, FLAG_MSAA4 = 1, 2, 4, 16
 
 
 def mesh_radius(vertices: np.ndarray) -> float:
@@ -90,9 +96,11 @@ class OracleBatchRenderer:
     """CPU object with the Panda3dBatchRenderer.render signature
     (/root/reference/src/megapose/panda3d_renderer/panda3d_batch_renderer.py:217-282)."""
 
-    def __init__(self, meshes_by_label: Dict[str, Dict[str, np.ndarray]], gl_eye: bool = False):
+    def __init__(self, meshes_by_label: Dict[str, Dict[str, np.ndarray]], gl_eye: bool = False, msaa: int = 4):
+        assert msaa in (1, 4)
         self.meshes = meshes_by_label
         self.gl_eye = gl_eye
+        self.msaa = msaa  # 4 = the reference's configuration (panda3d_scene_renderer.py:73-74)
         self.n_calls = 0
         self.n_views = 0
 
@@ -110,7 +118,7 @@ class OracleBatchRenderer:
         rgbs = np.zeros((bsz, h, w, 3), np.float32)
         nrms = np.zeros((bsz, h, w, 3), np.float32)
         deps = np.zeros((bsz, h, w), np.float32)
-        flags = (1 if render_normals else 0) | (2 if render_depth else 0) | (4 if self.gl_eye else 0)
+        flags = (1 if render_normals else 0) | (2 if render_depth else 0) | (4 if self.gl_eye else 0) | (16 if self.msaa == 4 else 0)
         for i, lab in enumerate(labels):
             L = lights_from_datas(light_datas[i]) if light_datas is not None else lights_struct()
             r, n, d = render(self.meshes[lab], T[i : i + 1], Kn[i : i + 1], h, w, flags, L)
@@ -127,19 +135,76 @@ class OracleBatchRenderer:
         pass
 
 
+class _ProbeBounds:
+    def __init__(self, radius):
+        self.radius = radius
+
+    def getRadius(self):
+        return self.radius
+
+    get_radius = getRadius
+
+
+class _ProbeRoot:
+    """stands in for the panda3d root NodePath a positioning_function receives: only getBounds().radius is answered"""
+
+    def __init__(self, radius):
+        self._b = _ProbeBounds(radius)
+
+    def getBounds(self):
+        return self._b
+
+    get_bounds = getBounds
+
+
+class _ProbeLight:
+    def __init__(self):
+        self.pos = None
+
+    def setPos(self, *a):
+        self.pos = tuple(float(v) for v in (a[0] if len(a) == 1 else a))
+
+    set_pos = setPos
+
+
+def probe_light_position(fn):
+    """positioning_function(root_node, light_node) (panda3d_scene_renderer.py:121-133, types.py:104-114) -> (a, b) with
+    position = a * bounding_radius + b, found by calling it at radius 1, 2 and 4 with recording stand-ins."""
+    pts = []
+    for r in (1.0, 2.0, 4.0):
+        light = _ProbeLight()
+        fn(_ProbeRoot(r), light)
+        if light.pos is None:
+            raise NotImplementedError("positioning_function did not call setPos on the light node")
+        pts.append(np.asarray(light.pos, np.float64))
+    a = pts[1] - pts[0]
+    b = pts[0] - a
+    if np.abs(a * 4.0 + b - pts[2]).max() > 1e-9 * (1.0 + np.abs(pts[2]).max()):
+        raise NotImplementedError("positioning_function is not affine in the bounding radius")
+    return a, b
+
+
 def lights_from_datas(datas) -> "_Lights":
-    """List[Panda3dLightData-like] -> light struct.  Point lights are the 6 axis lights of make_scene_lights in order
-    (their positioning_function is a closure the oracle cannot call without panda3d)."""
+    """List[Panda3dLightData-like] -> light struct.  A point light's position comes from its positioning_function (probed, see
+    probe_light_position) or from an explicit `direction`; without either it is one of the 6 axis lights of make_scene_lights."""
     amb = np.zeros(3, np.float32)
-    dirs, cols = [], []
+    dirs, cols, offs = [], [], []
     k = 0
     for ld in datas:
         if ld.light_type == "ambient":
             amb += np.asarray(ld.color[:3], np.float32)
         elif ld.light_type == "point":
-            dirs.append(POINT_DIRS[k % 6])
+            fn = getattr(ld, "positioning_function", None)
+            d = getattr(ld, "direction", None)
+            if fn is not None:
+                a, b = probe_light_position(fn)
+                dirs.append(tuple(float(v) / 10.0 for v in a))
+                offs.append(tuple(float(v) for v in b))
+            else:
+                dirs.append(tuple(float(v) for v in d) if d is not None else POINT_DIRS[k % 6])
+                offs.append((0.0, 0.0, 0.0))
             cols.append(tuple(ld.color[:3]))
             k += 1
         else:
             raise NotImplementedError(ld.light_type)
-    return lights_struct(tuple(float(a) for a in amb), dirs, cols)
+    return lights_struct(tuple(float(a) for a in amb), dirs, cols, offs)

@@ -1,0 +1,177 @@
+// tests/raster_emul.cpp -- HOST emulation of the two rasteriser kernels (megapose6d_amd/csrc/raster.hip), TEST INFRASTRUCTURE ONLY.
+// It executes the same algorithm in the same order -- binning of the pieces into 8x8 tiles (+ the "large" list and the overflow
+// fallback), per-tile coverage with the lane arithmetic of raster_core.h (incl. the 32-bit small-piece path), one shading task
+// per (pixel, distinct winning piece), the 8-bit multisample resolve and the channel-run staging -- serially on the CPU, so that
+// the pixel contract implemented by the DEVICE code's shared core can be compared with the independent oracle (oracle/raster.c)
+// in the CPU test tier.  What it cannot cover is the device-only glue (wave broadcasts, LDS hand-offs, atomics): the -m gpu
+// tests compare the real kernels with the oracle bit for bit.
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -mfma -shared -fPIC -I megapose6d_amd/csrc tests/raster_emul.cpp
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "raster_core.h"
+
+using namespace mp::rc;
+
+namespace {
+constexpr int LARGE_TILES = 16;
+constexpr int TILE_WAVES = 4;
+
+struct Lists {
+  std::vector<int> tile_off, list, large;
+  bool overflow = false;
+};
+
+void tile_range(const Piece& p, int ns, int w, int h, int& tx0, int& ty0, int& tx1, int& ty1) {
+  int x0, y0, x1, y1;
+  piece_pixel_bbox(p, ns, w, h, x0, y0, x1, y1);
+  tx0 = x0 >> 3; ty0 = y0 >> 3; tx1 = x1 >> 3; ty1 = y1 >> 3;
+  if (x0 > x1 || y0 > y1) { tx1 = tx0 - 1; ty1 = ty0 - 1; }
+}
+
+Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, int ns, int cap_list) {
+  const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE, n_tiles = tiles_x * tiles_y;
+  Lists L;
+  std::vector<int> counts(n_tiles, 0);
+  const int F = view_finite(T, Kv) ? m.n_faces : 0;
+  for (int t = 0; t < F; ++t) {
+    int n_pieces = 1;
+    for (int which = 0; which < n_pieces; ++which) {
+      Piece p;
+      n_pieces = make_piece<false>(m, T, Kv, t, which, p);
+      if (p.id < 0) continue;
+      int tx0, ty0, tx1, ty1;
+      tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
+      if (tx0 > tx1 || ty0 > ty1) continue;
+      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) L.large.push_back(p.id);
+      else
+        for (int ty = ty0; ty <= ty1; ++ty)
+          for (int tx = tx0; tx <= tx1; ++tx) ++counts[ty * tiles_x + tx];
+    }
+  }
+  L.tile_off.assign(n_tiles + 1, 0);
+  for (int i = 0; i < n_tiles; ++i) L.tile_off[i + 1] = L.tile_off[i] + counts[i];
+  L.overflow = L.tile_off[n_tiles] > cap_list;
+  if (L.overflow) return L;
+  L.list.assign(L.tile_off[n_tiles], -1);
+  std::vector<int> cursor(L.tile_off.begin(), L.tile_off.end() - 1);
+  for (int t = 0; t < F; ++t) {
+    int n_pieces = 1;
+    for (int which = 0; which < n_pieces; ++which) {
+      Piece p;
+      n_pieces = make_piece<false>(m, T, Kv, t, which, p);
+      if (p.id < 0) continue;
+      int tx0, ty0, tx1, ty1;
+      tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
+      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) continue;
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) L.list[cursor[ty * tiles_x + tx]++] = p.id;
+    }
+  }
+  return L;
+}
+
+template <int NS>
+void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh_ids, const float* TCO, const float* K, int n_views, int h,
+                  int w, uint32_t flags, const Lights& lights, float* out, long long stride_v, int views_per_item, long long stride_view,
+                  long long stride_y, long long stride_x, int c_rgb, int c_normals, int c_depth, int cap_list, int reverse_lists) {
+  const bool do_norm = (flags & 1u) && c_normals >= 0, do_depth = (flags & 2u) && c_depth >= 0, gl_eye = flags & 4u;
+  const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE;
+  for (int view = 0; view < n_views; ++view) {
+    const int item = view / views_per_item, r = view % views_per_item;
+    const MeshRef& m = meshes[mesh_ids[view]];
+    const TexRef* tex = m.uvs ? &texs[mesh_ids[view]] : nullptr;
+    const float* T = TCO + (size_t)view * 16;
+    const float* Kv = K + (size_t)view * 9;
+    Lists L = bin_view(m, T, Kv, h, w, NS, cap_list);
+    if (reverse_lists) {  // the fill order of the device lists is not deterministic: the result must not depend on it
+      std::reverse(L.large.begin(), L.large.end());
+      for (int t = 0; t + 1 < (int)L.tile_off.size() && !L.overflow; ++t) std::reverse(L.list.begin() + L.tile_off[t], L.list.begin() + L.tile_off[t + 1]);
+    }
+    for (int ty = 0; ty < tiles_y; ++ty)
+      for (int tx = 0; tx < tiles_x; ++tx) {
+        const int tile = ty * tiles_x + tx, tile_x0 = tx * TILE, tile_y0 = ty * TILE;
+        Sample st[64][NS];
+        for (int l = 0; l < 64; ++l)
+          for (int s = 0; s < NS; ++s) { st[l][s].wsum = 0.f; st[l][s].id = -1; }
+        std::vector<int> entries;
+        if (L.overflow) for (int i = 0; i < 2 * m.n_faces; ++i) entries.push_back(i);
+        else {
+          entries.assign(L.list.begin() + L.tile_off[tile], L.list.begin() + L.tile_off[tile + 1]);
+          entries.insert(entries.end(), L.large.begin(), L.large.end());
+        }
+        for (int idx : entries) {
+          Piece p;
+          piece_from_index<false>(m, T, Kv, idx, p);
+          if (p.id < 0) continue;
+          const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
+          const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
+          const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
+          if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) continue;
+          bool any = true;
+          if (NS > 1 && piece_is_small(p, tile_x0, tile_y0)) {
+            Edges32 e;
+            piece_edges32(p, e);
+            any = false;
+            for (int l = 0; l < 64; ++l) any = any || maybe_covered32(e, tile_x0 + (l & 7), tile_y0 + (l >> 3));
+          }
+          if (!any) continue;
+          for (int l = 0; l < 64; ++l) cover_lane<NS>(p, tile_x0, tile_y0, tile_x0 + (l & 7), tile_y0 + (l >> 3), st[l]);
+        }
+        // tasks + shading + resolve
+        for (int l = 0; l < 64; ++l) {
+          const int px = tile_x0 + (l & 7), py = tile_y0 + (l >> 3);
+          if (px >= w || py >= h) continue;
+          float q[NS][6];
+          float acc[6] = {0, 0, 0, 0, 0, 0};
+          for (int s = 0; s < NS; ++s) {
+            if (st[l][s].id < 0) continue;
+            int src = s;
+            for (int k = s - 1; k >= 0; --k)
+              if (st[l][k].id == st[l][s].id) src = k;
+            if (src == s) {
+              Piece pf;
+              piece_from_index<true>(m, T, Kv, st[l][s].id, pf);
+              float c255[3], n255[3];
+              shade(m, tex, lights, T, gl_eye, do_norm, pf, px, py, c255, n255);
+              for (int c = 0; c < 3; ++c) { q[s][c] = (float)(unsigned)q255(c255[c]); q[s][3 + c] = (float)(unsigned)q255(n255[c]); }
+            }
+            for (int c = 0; c < 6; ++c) acc[c] += q[src][c];
+          }
+          float* o = out + (size_t)item * stride_v + (size_t)py * stride_y + (size_t)px * stride_x + (long long)r * stride_view;
+          if (c_rgb >= 0) for (int c = 0; c < 3; ++c) o[c_rgb + c] = resolve_channel(acc[c], NS, false);
+          if (do_norm) for (int c = 0; c < 3; ++c) o[c_normals + c] = resolve_channel(acc[3 + c], NS, false);
+          if (do_depth) o[c_depth] = st[l][0].id >= 0 ? 1.0f / st[l][0].wsum : 0.f;
+        }
+      }
+  }
+}
+}  // namespace
+
+extern "C" void raster_emul_render(const float* verts, const float* normals, const float* colors, const int32_t* faces, int n_verts, int n_faces,
+                                   float radius, const float* uvs, const uint32_t* texels, int tex_w, int tex_h, int tex_levels,
+                                   const float* TCO, const float* K, int n_views, int h, int w, uint32_t flags, const Lights* lights, float* out,
+                                   long long stride_v, int views_per_item, long long stride_view, long long stride_y, long long stride_x,
+                                   int c_rgb, int c_normals, int c_depth, int cap_list, int reverse_lists) {
+  MeshRef m;
+  m.verts = verts; m.normals = normals; m.colors = colors; m.faces = faces; m.n_verts = n_verts; m.n_faces = n_faces; m.radius = radius;
+  m.uvs = (uvs && texels) ? uvs : nullptr;
+  TexRef tx;
+  memset(&tx, 0, sizeof(tx));
+  tx.texels = texels; tx.tex_w = tex_w; tx.tex_h = tex_h; tx.tex_levels = tex_levels;
+  int off = 0;
+  for (int l = 0; l < tex_levels && l < MP_TEX_MAX_LEVELS; ++l) {
+    tx.tex_off[l] = off;
+    off += std::max(1, tex_w >> l) * std::max(1, tex_h >> l);
+  }
+  std::vector<int32_t> ids(n_views, 0);
+  if (cap_list <= 0) cap_list = 4 * n_faces + 2048;
+  if (flags & 16u)
+    render_views<4>(&m, &tx, ids.data(), TCO, K, n_views, h, w, flags, *lights, out, stride_v, views_per_item, stride_view, stride_y, stride_x,
+                    c_rgb, c_normals, c_depth, cap_list, reverse_lists);
+  else
+    render_views<1>(&m, &tx, ids.data(), TCO, K, n_views, h, w, flags, *lights, out, stride_v, views_per_item, stride_view, stride_y, stride_x,
+                    c_rgb, c_normals, c_depth, cap_list, reverse_lists);
+}

@@ -178,8 +178,9 @@ def _mesh_db(eng, engine_meshes):
     return eng.MeshDB(engine_meshes)
 
 
-@pytest.mark.parametrize("flags", [1, 3, 1 | 4, 0])
-def test_raster_bit_exact_vs_oracle(eng, engine_meshes, flags):
+@pytest.mark.parametrize("flags,lit", [(1, False), (3, False), (1 | 4, False), (0, True), (16 | 3, False), (16 | 1 | 4, False), (16, True)])
+def test_raster_bit_exact_vs_oracle(eng, engine_meshes, flags, lit):
+    """flags: 1 normals, 2 depth, 4 GL eye axes, 16 = 4x MSAA (the reference's configuration); lit = ambient + 6 point lights"""
     from megapose6d_amd import synthetic as syn
     from oracle import raster as orr
 
@@ -193,11 +194,12 @@ def test_raster_bit_exact_vs_oracle(eng, engine_meshes, flags):
     T[3, 0, 3] = np.nan  # invalid pose -> zeros (panda3d_batch_renderer.py:109-135)
     h, w = 240, 320
     out = torch.full((n, h, w, 8), -1.0, device="cuda")
-    if flags == 0:
+    if lit:
         dirs = orr.POINT_DIRS
         cols = [(0.4, 0.4, 0.4)] * 6
-        L = eng.make_lights((0.1, 0.1, 0.1), dirs, cols)
-        Lo = orr.lights_struct((0.1, 0.1, 0.1), dirs, cols)
+        offs = [(0.0, 0.0, 0.01 * k) for k in range(6)]
+        L = eng.make_lights((0.1, 0.1, 0.1), dirs, cols, offs)
+        Lo = orr.lights_struct((0.1, 0.1, 0.1), dirs, cols, offs)
     else:
         L, Lo = eng.make_lights(), orr.lights_struct()
     eng.raster_render(db, torch.from_numpy(mesh_ids).cuda(), torch.from_numpy(T).cuda(), torch.from_numpy(K).cuda(), h, w, flags,
@@ -208,7 +210,7 @@ def test_raster_bit_exact_vs_oracle(eng, engine_meshes, flags):
         rgb, nrm, dep = orr.render(engine_meshes[mesh_ids[i]], T[i : i + 1], K[i : i + 1], h, w, flags, Lo)
         if i != 3:
             assert (rgb[0].sum(-1) > 0).mean() > 0.02, "object should be visible"
-        if flags == 0:  # point lights use sqrt/div chains: allow 1 LSB of the uint8 quantisation on a few pixels
+        if lit:  # point lights use sqrt/div chains: allow 1 LSB of the uint8 quantisation on a few pixels
             d = np.abs(got[i, :, :, 0:3] - rgb[0])
             assert d.max() <= 1.0 / 255 + 1e-7 and (d > 0).mean() < 1e-3
         else:
@@ -229,17 +231,19 @@ def test_raster_large_triangles_and_close_camera(eng):
     col = np.random.RandomState(0).rand(5, 3).astype(np.float32)
     mesh = {"vertices": v, "normals": nrm.astype(np.float32), "colors": col, "faces": f}
     db = eng.MeshDB([mesh])
-    T = np.tile(np.eye(4, dtype=np.float32), (3, 1, 1))
-    T[:, 2, 3] = [0.3, 0.15, 0.11]
+    T = np.tile(np.eye(4, dtype=np.float32), (5, 1, 1))
+    T[:, 2, 3] = [0.3, 0.15, 0.11, 0.07, 0.09]          # the last two put part of the pyramid behind the near plane (clipping)
     T[1, :3, :3] = np.array([[0.8, 0, 0.6], [0, 1, 0], [-0.6, 0, 0.8]], np.float32)
-    K = np.tile(np.array([[300, 0, 160], [0, 300, 120], [0, 0, 1]], np.float32), (3, 1, 1))
-    out = torch.zeros(3, 240, 320, 8, device="cuda")
-    eng.raster_render(db, torch.zeros(3, dtype=torch.int32, device="cuda"), torch.from_numpy(T).cuda(), torch.from_numpy(K).cuda(),
-                      240, 320, 3, eng.make_lights(), out, 240 * 320 * 8, 320 * 8, 8, 0, 3, 6)
-    got = out.cpu().numpy()
-    rgb, nr, dep = orr.render(mesh, T, K, 240, 320, 3)
-    assert np.array_equal(got[..., 0:3], rgb) and np.array_equal(got[..., 3:6], nr) and np.array_equal(got[..., 6], dep)
-    assert (dep[0] > 0).mean() > 0.1
+    T[4, :3, :3] = np.array([[0.8, 0, 0.6], [0, 1, 0], [-0.6, 0, 0.8]], np.float32)
+    K = np.tile(np.array([[300, 0, 160], [0, 300, 120], [0, 0, 1]], np.float32), (5, 1, 1))
+    for flags in (3, 16 | 3):
+        out = torch.zeros(5, 240, 320, 8, device="cuda")
+        eng.raster_render(db, torch.zeros(5, dtype=torch.int32, device="cuda"), torch.from_numpy(T).cuda(), torch.from_numpy(K).cuda(),
+                          240, 320, flags, eng.make_lights(), out, 240 * 320 * 8, 320 * 8, 8, 0, 3, 6)
+        got = out.cpu().numpy()
+        rgb, nr, dep = orr.render(mesh, T, K, 240, 320, flags)
+        assert np.array_equal(got[..., 0:3], rgb) and np.array_equal(got[..., 3:6], nr) and np.array_equal(got[..., 6], dep)
+        assert (dep[0] > 0).mean() > 0.1 and (dep[3] > 0).mean() > 0.1 and dep[3][dep[3] > 0].min() >= 0.1 - 1e-6
 
 
 @pytest.mark.parametrize("C", [3, 4])
