@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2c2
+mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_textures.py -x -q -k "raster or textured or crop" > $O/pytest_raster.log 2>&1; echo "rc=$?" >> $O/pytest_raster.log
+timeout 120 scripts/microbench/mfma_power > $O/mfma_power.log 2>&1
+timeout 200 python scripts/conv_data_power.py > $O/conv_data.log 2>&1
+timeout 200 python scripts/bench_raster.py 1 17 3 19 > $O/raster.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
+timeout 600 python bench.py --no-extras > $O/bench.json 2> $O/bench.err; echo "rc=$?" >> $O/bench.err
+timeout 300 python bench.py --cpu-thread-sweep 4,8,12,16,24 > $O/sweep.log 2>&1
