@@ -66,6 +66,38 @@ __device__ __forceinline__ void tile_range(const Piece& p, int ns, int w, int h,
   if (x0 > x1 || y0 > y1) { tx1 = tx0 - 1; ty1 = ty0 - 1; }  // empty
 }
 
+// Can the piece own a sample inside tile (tx, ty)?  Conservative separating-edge test: for every edge, the sample-rectangle corner
+// that maximises the edge function must not be strictly outside.  (Exact integers in fp64: |values| < 2^53.)
+struct TileTest {
+  double A[3], B[3], C[3];
+  int omin, omax;
+};
+__device__ __forceinline__ TileTest tile_test_setup(const Piece& p, int ns) {
+  TileTest t;
+  const int a[3] = {1, 2, 0}, b[3] = {2, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double dx = (double)(p.X[b[i]] - p.X[a[i]]), dy = (double)(p.Y[b[i]] - p.Y[a[i]]);
+    t.A[i] = -dy;
+    t.B[i] = dx;
+    t.C[i] = dy * (double)p.X[a[i]] - dx * (double)p.Y[a[i]];
+  }
+  t.omin = rc::sample_off_min(ns);
+  t.omax = rc::sample_off_max(ns);
+  return t;
+}
+__device__ __forceinline__ bool tile_touched(const TileTest& t, int tx, int ty) {
+  const double x_lo = (double)(tx * TILE * SUBPIX + t.omin), x_hi = (double)((tx * TILE + TILE - 1) * SUBPIX + t.omax);
+  const double y_lo = (double)(ty * TILE * SUBPIX + t.omin), y_hi = (double)((ty * TILE + TILE - 1) * SUBPIX + t.omax);
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double e = fma(t.A[i], t.A[i] >= 0.0 ? x_hi : x_lo, fma(t.B[i], t.B[i] >= 0.0 ? y_hi : y_lo, t.C[i]));
+    ok = ok && (e >= 0.0);
+  }
+  return ok;
+}
+
 __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
                                                           const float* __restrict__ TCO, const float* __restrict__ K, int h, int w, int ns,
                                                           int* __restrict__ ws, BinLayout lay) {
@@ -99,8 +131,10 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) {
         large[atomicAdd(&s_nlarge, 1)] = p.id;   // piece index == depth-tie id
       } else {
+        const TileTest tt = tile_test_setup(p, ns);
         for (int ty = ty0; ty <= ty1; ++ty)
-          for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&counts[ty * lay.tiles_x + tx], 1);
+          for (int tx = tx0; tx <= tx1; ++tx)
+            if (tile_touched(tt, tx, ty)) atomicAdd(&counts[ty * lay.tiles_x + tx], 1);
       }
     }
   }
@@ -146,8 +180,10 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) continue;
+      const TileTest tt = tile_test_setup(p, ns);
       for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = p.id;
+        for (int tx = tx0; tx <= tx1; ++tx)
+          if (tile_touched(tt, tx, ty)) list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = p.id;
     }
   }
 }
@@ -159,20 +195,58 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// One wave-uniform piece against the 64 pixels (x NS samples) of a tile.  (px, py) = this lane's pixel.
+constexpr int SCATTER_MAX_AREA = 32;  // footprint (pixels of bbox ∩ tile) up to which a lane rasterises its own piece
+
+// ---- coverage form 1: lane-per-piece scatter.  Every lane owns one small piece of the batch and walks the pixels of the piece's
+// bbox inside the tile; covered samples go to the wave's LDS z-buffer with a 64-bit max (key = depth bits | ~piece id). ----------
 template <int NS>
-__device__ __forceinline__ void cover_piece(const Piece& p, int tile_x0, int tile_y0, int px, int py, Sample (&st)[NS]) {
-  // uniform reject: the piece's bbox against the tile's sample area
+__device__ __forceinline__ void scatter_piece(const Piece& p, bool active, int x0, int y0, int x1, int y1, int tile_x0, int tile_y0,
+                                              unsigned long long* zb) {
+  rc::Edges32 e;
+  rc::piece_edges32(p, e);
+  const int bw = x1 - x0 + 1;
+  const int n = active ? bw * (y1 - y0 + 1) : 0;
+  int px = x0, py = y0;
+  // all lanes iterate to the largest footprint in the wave (<= SCATTER_MAX_AREA)
+  int n_max = n;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off));
+  for (int k = 0; k < n_max; ++k) {
+    if (k < n) {
+      const int local = ((py - tile_y0) << 3) | (px - tile_x0);
+      rc::cover_pixel32<NS>(p, e, px, py, [&](int s, float wsum) {
+        const unsigned long long key = rc::depth_key(wsum, p.id);
+        unsigned long long* slot = zb + local * NS + s;
+        if (key > *slot) atomicMax(slot, key);   // the plain read only skips atomics that cannot win (values only grow)
+      });
+      ++px;
+      if (px > x1) { px = x0; ++py; }
+    }
+  }
+}
+
+// ---- coverage form 2: wave-per-piece sweep for pieces with a large footprint in the tile (or too large for the 32-bit edge
+// functions): the piece is wave-uniform, lane l tests ITS pixel and updates its own z-buffer slots (no conflicts). ---------------
+template <int NS>
+__device__ __forceinline__ void sweep_piece(const Piece& p, int tile_x0, int tile_y0, int px, int py, int lane, unsigned long long* zb) {
   const int Xmin = min(p.X[0], min(p.X[1], p.X[2])), Xmax = max(p.X[0], max(p.X[1], p.X[2]));
   const int Ymin = min(p.Y[0], min(p.Y[1], p.Y[2])), Ymax = max(p.Y[0], max(p.Y[1], p.Y[2]));
   const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
   if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) return;
-  if (NS > 1 && rc::piece_is_small(p, tile_x0, tile_y0)) {  // wave-level early out: no lane can own a covered sample
+  auto emit = [&](int s, float wsum) {
+    const unsigned long long key = rc::depth_key(wsum, p.id);
+    unsigned long long* slot = zb + lane * NS + s;
+    if (key > *slot) *slot = key;
+  };
+  if (rc::piece_is_small(p, tile_x0, tile_y0)) {
     rc::Edges32 e;
     rc::piece_edges32(p, e);
-    if (__ballot(rc::maybe_covered32(e, px, py)) == 0ull) return;
+    rc::cover_pixel32<NS>(p, e, px, py, emit);
+  } else {
+    rc::Edges e;
+    rc::piece_edges(p, e);
+    rc::cover_pixel64<NS>(p, e, px, py, emit);
   }
-  rc::cover_lane<NS>(p, tile_x0, tile_y0, px, py, st);
 }
 
 template <int NS>
@@ -181,154 +255,173 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
     float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
     long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop) {
-  extern __shared__ __attribute__((aligned(16))) float stage[];  // [TILE_WAVES * 64][run] then the per-wave task / result arrays
-  unsigned* tasks_all = (unsigned*)(stage + (size_t)TILE_WAVES * 64 * run);   // [TILE_WAVES][64 * NS]
-  uint2* res_all = (uint2*)(tasks_all + TILE_WAVES * 64 * NS);                // [TILE_WAVES][64][NS]
+  // LDS per wave: stage [64][run] floats | zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t per_wave = (size_t)64 * NS * (sizeof(unsigned long long) + sizeof(unsigned)) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15);
+  unsigned char* mine = lds_raw + (size_t)wave * per_wave;
+  unsigned long long* zb = (unsigned long long*)mine;
+  uint2* res = (uint2*)mine;                                    // aliases zb once the samples are in registers
+  unsigned* tasks = (unsigned*)(mine + (size_t)64 * NS * sizeof(unsigned long long));
+  float* stage = (float*)(mine + (size_t)64 * NS * (sizeof(unsigned long long) + sizeof(unsigned)));
+  float* my_stage = stage + (size_t)lane * run;
   const int groups_x = (lay.tiles_x + TILE_WAVES - 1) / TILE_WAVES;
   int b = blockIdx.x;
   const int gx = b % groups_x; b /= groups_x;
   const int ty = b % lay.tiles_y;
   const int item = b / lay.tiles_y;
   const int tx = gx * TILE_WAVES + wave;
+  if (tx >= lay.tiles_x) return;   // (no workgroup-level barrier below: waves are independent)
   const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
   const int px = tile_x0 + (lane & 7), py = tile_y0 + (lane >> 3);
-  const bool wave_active = tx < lay.tiles_x;
-  float* my_stage = stage + (size_t)(wave * 64 + lane) * run;
-  unsigned* tasks = tasks_all + wave * 64 * NS;
-  uint2* res = res_all + (size_t)wave * 64 * NS;
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0;
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
 
-  if (wave_active) {
-    for (int r = 0; r < views_per_item; ++r) {
-      const int view = item * views_per_item + r;
-      const int mesh_id = mesh_ids[view];
-      const MeshDev m = meshes[mesh_id];
-      const float* T = TCO + (size_t)view * 16;
-      const float* Kv = K + (size_t)view * 9;
-      const int* hdr = ws + (size_t)view * lay.view_ints;
-      const int* tile_off = hdr + HDR_INTS;
-      const int* list = tile_off + lay.n_tiles + 1;
-      const int* large = list + lay.cap_list;
-      const int tile = ty * lay.tiles_x + tx;
-      const bool overflow = hdr[2] != 0;
-      const int begin = overflow ? 0 : tile_off[tile];
-      const int n_list = overflow ? 2 * m.n_faces : tile_off[tile + 1] - begin;
-      const int n_large = overflow ? 0 : hdr[0];
-      const int n_total = n_list + n_large;
-      Sample st[NS];
+  for (int r = 0; r < views_per_item; ++r) {
+    const int view = item * views_per_item + r;
+    const int mesh_id = mesh_ids[view];
+    const MeshDev m = meshes[mesh_id];
+    const float* T = TCO + (size_t)view * 16;
+    const float* Kv = K + (size_t)view * 9;
+    const int* hdr = ws + (size_t)view * lay.view_ints;
+    const int* tile_off = hdr + HDR_INTS;
+    const int* list = tile_off + lay.n_tiles + 1;
+    const int* large = list + lay.cap_list;
+    const int tile = ty * lay.tiles_x + tx;
+    const bool overflow = hdr[2] != 0;
+    const int begin = overflow ? 0 : tile_off[tile];
+    const int n_list = overflow ? 2 * m.n_faces : tile_off[tile + 1] - begin;
+    const int n_large = overflow ? 0 : hdr[0];
+    const int n_total = n_list + n_large;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) { st[s].wsum = 0.f; st[s].id = -1; }
-      // ---- coverage + depth: 64 listed pieces are set up lane-parallel, then broadcast one at a time ---------------------------
-      for (int base = 0; base < n_total; base += 64) {
-        const int e = base + lane;
-        int idx = -1;
-        if (e < n_list) idx = overflow ? e : list[begin + e];
-        else if (e < n_total) idx = large[e - n_list];
-        Piece mine;
-        mine.id = -1;
-        if (idx >= 0) rc::piece_from_index<false>(m, T, Kv, idx, mine);
-        const int n_here = min(64, n_total - base);
-        for (int j = 0; j < n_here; ++j) {
-          Piece p;
-          p.id = rl(mine.id, j);
-          if (p.id < 0) continue;
-          p.X[0] = rl(mine.X[0], j); p.Y[0] = rl(mine.Y[0], j);
-          p.X[1] = rl(mine.X[1], j); p.Y[1] = rl(mine.Y[1], j);
-          p.X[2] = rl(mine.X[2], j); p.Y[2] = rl(mine.Y[2], j);
-          p.iz[0] = rlf(mine.iz[0], j); p.iz[1] = rlf(mine.iz[1], j); p.iz[2] = rlf(mine.iz[2], j);
-          cover_piece<NS>(p, tile_x0, tile_y0, px, py, st);
-        }
+    for (int s = 0; s < NS; ++s) zb[lane * NS + s] = 0ull;
+    wave_lds_fence();
+    // ---- coverage + depth: 64 listed pieces are set up lane-parallel; small footprints are scattered by their own lane, the
+    //      rest is broadcast (v_readlane) and swept by the whole wave ---------------------------------------------------------
+    for (int base = 0; base < n_total; base += 64) {
+      const int e = base + lane;
+      int idx = -1;
+      if (e < n_list) idx = overflow ? e : list[begin + e];
+      else if (e < n_total) idx = large[e - n_list];
+      Piece mine_p;
+      mine_p.id = -1;
+      if (idx >= 0) rc::piece_from_index<false>(m, T, Kv, idx, mine_p);
+      int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+      bool small = false;
+      if (mine_p.id >= 0) {
+        rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
+        x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
+        small = rc::piece_is_small(mine_p, tile_x0, tile_y0);
       }
-      // ---- shading tasks: one per (pixel, distinct winning piece), ordered by (sample, lane) -----------------------------------
-      int n_tasks = 0;
-      bool is_new[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        bool nw = st[s].id >= 0;
-#pragma unroll
-        for (int k = 0; k < s; ++k) nw = nw && !(st[k].id == st[s].id);
-        is_new[s] = nw;
-        const unsigned long long mask = __ballot(nw);
-        if (nw) tasks[n_tasks + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned)st[s].id << 8) | ((unsigned)s << 6) | (unsigned)lane;
-        n_tasks += __popcll(mask);
+      const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
+      const bool scat = hit && small && (x1 - x0 + 1) * (y1 - y0 + 1) <= SCATTER_MAX_AREA;
+      if (__ballot(scat) != 0ull) scatter_piece<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, zb);
+      wave_lds_fence();
+      unsigned long long big = __ballot(hit && !scat);
+      while (big) {
+        const int j = __ffsll((long long)big) - 1;
+        big &= big - 1ull;
+        Piece p;
+        p.id = rl(mine_p.id, j);
+        p.X[0] = rl(mine_p.X[0], j); p.Y[0] = rl(mine_p.Y[0], j);
+        p.X[1] = rl(mine_p.X[1], j); p.Y[1] = rl(mine_p.Y[1], j);
+        p.X[2] = rl(mine_p.X[2], j); p.Y[2] = rl(mine_p.Y[2], j);
+        p.iz[0] = rlf(mine_p.iz[0], j); p.iz[1] = rlf(mine_p.iz[1], j); p.iz[2] = rlf(mine_p.iz[2], j);
+        sweep_piece<NS>(p, tile_x0, tile_y0, px, py, lane, zb);
       }
       wave_lds_fence();
-      const TexDev* tex = m.uvs ? &texs[mesh_id] : nullptr;
-      for (int k0 = 0; k0 < n_tasks; k0 += 64) {
-        const int k = k0 + lane;
-        if (k < n_tasks) {
-          const unsigned tk = tasks[k];
-          const int tl = tk & 63, ts = (tk >> 6) & 3, id = (int)(tk >> 8);
-          Piece pf;
-          rc::piece_from_index<true>(m, T, Kv, id, pf);
-          float c255[3], n255[3];
-          rc::shade(m, tex, lights, T, gl_eye, do_norm, pf, tile_x0 + (tl & 7), tile_y0 + (tl >> 3), c255, n255);
-          uint2 q;
-          q.x = (unsigned)rc::q255(c255[0]) | ((unsigned)rc::q255(c255[1]) << 8) | ((unsigned)rc::q255(c255[2]) << 16);
-          q.y = (unsigned)rc::q255(n255[0]) | ((unsigned)rc::q255(n255[1]) << 8) | ((unsigned)rc::q255(n255[2]) << 16);
-          res[tl * NS + ts] = q;
-        }
-      }
-      wave_lds_fence();
-      // ---- resolve: mean of the samples' 8-bit values, background samples = 0 --------------------------------------------------
-      float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (st[s].id < 0) continue;
-        int src = s;
-#pragma unroll
-        for (int k = s - 1; k >= 0; --k)
-          if (st[k].id == st[s].id) src = k;   // ends at the first sample holding this piece (the one that was shaded)
-        const uint2 q = res[lane * NS + src];
-        acc[0] += (float)(q.x & 255u); acc[1] += (float)((q.x >> 8) & 255u); acc[2] += (float)((q.x >> 16) & 255u);
-        acc[3] += (float)(q.y & 255u); acc[4] += (float)((q.y >> 8) & 255u); acc[5] += (float)((q.y >> 16) & 255u);
-      }
-      (void)is_new;
-      const long long cv = (long long)r * stride_view;
-      if (c_rgb >= 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) my_stage[c_rgb + cv + c - c_lo] = rc::resolve_channel(acc[c], NS, false);
-      }
-      if (do_norm) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) my_stage[c_normals + cv + c - c_lo] = rc::resolve_channel(acc[3 + c], NS, false);
-      }
-      if (do_depth) my_stage[c_depth + cv - c_lo] = st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f;
-      wave_lds_fence();  // the task / result arrays are reused by the next view
     }
-    if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
-      const float* bx = crop.boxes + (size_t)item * 4;
-      const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
-      const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
-      const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
-      const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
-      float cvals[4];
-      if (crop.nhwc4) {
-        if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-        else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-      } else {
-        if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-        else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-      }
-      my_stage[crop.c0 - c_lo] = cvals[0]; my_stage[crop.c0 + 1 - c_lo] = cvals[1]; my_stage[crop.c0 + 2 - c_lo] = cvals[2];
-      if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cvals[3];
+    Sample st[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const unsigned long long key = zb[lane * NS + s];
+      st[s].wsum = rc::key_wsum(key);
+      st[s].id = rc::key_id(key);
     }
+    wave_lds_fence();   // zb is reused for the shading results below
+    // ---- shading tasks: one per (pixel, distinct winning piece), ordered by (sample, lane) -------------------------------------
+    int n_tasks = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bool nw = st[s].id >= 0;
+#pragma unroll
+      for (int k = 0; k < s; ++k) nw = nw && !(st[k].id == st[s].id);
+      const unsigned long long mask = __ballot(nw);
+      if (nw) tasks[n_tasks + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned)st[s].id << 8) | ((unsigned)s << 6) | (unsigned)lane;
+      n_tasks += __popcll(mask);
+    }
+    wave_lds_fence();
+    const TexDev* tex = m.uvs ? &texs[mesh_id] : nullptr;
+    for (int k0 = 0; k0 < n_tasks; k0 += 64) {
+      const int k = k0 + lane;
+      if (k < n_tasks) {
+        const unsigned tk = tasks[k];
+        const int tl = tk & 63, ts = (tk >> 6) & 3, id = (int)(tk >> 8);
+        Piece pf;
+        rc::piece_from_index<true>(m, T, Kv, id, pf);
+        float c255[3], n255[3];
+        rc::shade(m, tex, lights, T, gl_eye, do_norm, pf, tile_x0 + (tl & 7), tile_y0 + (tl >> 3), c255, n255);
+        uint2 q;
+        q.x = (unsigned)rc::q255(c255[0]) | ((unsigned)rc::q255(c255[1]) << 8) | ((unsigned)rc::q255(c255[2]) << 16);
+        q.y = (unsigned)rc::q255(n255[0]) | ((unsigned)rc::q255(n255[1]) << 8) | ((unsigned)rc::q255(n255[2]) << 16);
+        res[tl * NS + ts] = q;
+      }
+    }
+    wave_lds_fence();
+    // ---- resolve: mean of the samples' 8-bit values, background samples = 0 ----------------------------------------------------
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (st[s].id < 0) continue;
+      int src = s;
+#pragma unroll
+      for (int k = s - 1; k >= 0; --k)
+        if (st[k].id == st[s].id) src = k;   // ends at the first sample holding this piece (the one that was shaded)
+      const uint2 q = res[lane * NS + src];
+      acc[0] += (float)(q.x & 255u); acc[1] += (float)((q.x >> 8) & 255u); acc[2] += (float)((q.x >> 16) & 255u);
+      acc[3] += (float)(q.y & 255u); acc[4] += (float)((q.y >> 8) & 255u); acc[5] += (float)((q.y >> 16) & 255u);
+    }
+    const long long cv = (long long)r * stride_view;
+    if (c_rgb >= 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) my_stage[c_rgb + cv + c - c_lo] = rc::resolve_channel(acc[c], NS, false);
+    }
+    if (do_norm) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) my_stage[c_normals + cv + c - c_lo] = rc::resolve_channel(acc[3 + c], NS, false);
+    }
+    if (do_depth) my_stage[c_depth + cv - c_lo] = st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f;
+    wave_lds_fence();  // the z-buffer / task arrays are reused by the next view
   }
-  __syncthreads();
-  // ---- store: the strip's pixels leave as contiguous channel runs (row-major over the 8 rows x 32 pixels x run floats) ----------
+  if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
+    const float* bx = crop.boxes + (size_t)item * 4;
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
+    const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
+    const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
+    float cvals[4];
+    if (crop.nhwc4) {
+      if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+      else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+    } else {
+      if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+      else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+    }
+    my_stage[crop.c0 - c_lo] = cvals[0]; my_stage[crop.c0 + 1 - c_lo] = cvals[1]; my_stage[crop.c0 + 2 - c_lo] = cvals[2];
+    if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cvals[3];
+  }
+  wave_lds_fence();
+  // ---- store: each of the tile's 8 rows leaves as one contiguous run of 8 pixels x `run` channels (only written channels) -------
   float* out_item = out + (size_t)item * stride_v + c_lo;
-  const int strip_w = min(TILE_WAVES * TILE, w - gx * TILE_WAVES * TILE);   // pixels of this strip inside the image
-  const int rows = min(TILE, h - tile_y0);
-  const int per_row = strip_w * run;
-  for (int i = threadIdx.x; i < rows * per_row; i += 64 * TILE_WAVES) {
-    const int row = i / per_row, rem = i - row * per_row;
-    const int x = rem / run, c = rem - x * run;
+  const int cols = min(TILE, w - tile_x0), rows = min(TILE, h - tile_y0);
+  const int per_row = cols * run;   // <= 256 floats
+  for (int i = lane; i < per_row; i += 64) {
+    const int x = i / run, c = i - x * run;   // once per lane and 64-float slice, reused for all 8 rows
     if (!((run_mask >> c) & 1u)) continue;
-    const int wv = x >> 3, ln = (row << 3) | (x & 7);
-    out_item[(size_t)(tile_y0 + row) * stride_y + (size_t)(gx * TILE_WAVES * TILE + x) * stride_x + c] = stage[(size_t)(wv * 64 + ln) * run + c];
+    float* o = out_item + (size_t)tile_y0 * stride_y + (size_t)(tile_x0 + x) * stride_x + c;
+    const float* sp = stage + (size_t)x * run + c;
+    for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = sp[(size_t)row * 8 * run];
   }
 }
 
@@ -519,7 +612,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
   const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
   MP_REQUIRE(n_wg < (1LL << 31), "mp_raster_render: grid too large");
-  const size_t lds = (size_t)TILE_WAVES * 64 * run * sizeof(float) + (size_t)TILE_WAVES * 64 * ns * (sizeof(unsigned) + sizeof(uint2));
+  const size_t lds = (size_t)TILE_WAVES * ((size_t)64 * ns * (sizeof(unsigned long long) + sizeof(unsigned)) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15));
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)

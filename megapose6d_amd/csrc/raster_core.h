@@ -16,6 +16,12 @@
 #define MP_HD static inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MP_MUL24(a, b) __mul24((a), (b))   // full-rate 24-bit multiply; callers guarantee |a|, |b| < 2^23 and |a * b| < 2^31
+#else
+#define MP_MUL24(a, b) ((a) * (b))
+#endif
+
 #ifndef MP_TEX_MAX_LEVELS
 #define MP_TEX_MAX_LEVELS 15
 #endif
@@ -289,7 +295,7 @@ MP_HD void piece_edges32(const Piece& p, Edges32& e) {
 }
 
 // E_i at sample (sx, sy), int32 (valid under piece_is_small)
-MP_HD int edge32(const Edges32& e, int i, int sx, int sy) { return e.dx[i] * (sy - e.ay[i]) - e.dy[i] * (sx - e.ax[i]); }
+MP_HD int edge32(const Edges32& e, int i, int sx, int sy) { return MP_MUL24(e.dx[i], sy - e.ay[i]) - MP_MUL24(e.dy[i], sx - e.ax[i]); }
 
 // conservative per-lane test of the 32-bit path: can ANY sample of pixel (px, py) be inside the (small) piece?
 // (no sample is farther than 96/256 px from the pixel centre in x or y)
@@ -301,44 +307,77 @@ MP_HD bool maybe_covered32(const Edges32& e, int px, int py) {
   return maybe;
 }
 
+// One SMALL piece (piece_is_small for the pixel's tile) against the NS samples of pixel (px, py): emit(s, wsum) is called for every
+// sample that is covered (top-left rule) and inside the depth range.  This is the arithmetic of both coverage forms of the kernel:
+// the wave-per-piece sweep (64 lanes = the tile's pixels) and the lane-per-piece scatter (a lane walks its piece's bbox).
+template <int NS, class Emit>
+MP_HD void cover_pixel32(const Piece& p, const Edges32& e, int px, int py, Emit&& emit) {
+  const int cx = px * SUBPIX + 128, cy = py * SUBPIX + 128;
+  int ec[3];
+  bool maybe = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ec[i] = edge32(e, i, cx, cy);
+    if (NS > 1) maybe = maybe && (ec[i] + (abs(e.dx[i]) + abs(e.dy[i])) * 96 >= e.thr[i]);
+  }
+  if (!maybe) return;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int ox = sample_off_x(NS, s) - 128, oy = sample_off_y(NS, s) - 128;
+    int es[3];
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      es[i] = ec[i] + (e.dx[i] * oy - e.dy[i] * ox);
+      inside = inside && (es[i] >= e.thr[i]);
+    }
+    if (inside) {
+      const float b0 = (float)es[0] * e.inv_area, b1 = (float)es[1] * e.inv_area, b2 = (float)es[2] * e.inv_area;
+      const float wsum = fmaf(b2, p.iz[2], fmaf(b1, p.iz[1], b0 * p.iz[0]));
+      if (depth_in_range(wsum)) emit(s, wsum);
+    }
+  }
+}
+
+// the general (64-bit) form for pieces that are not small
+template <int NS, class Emit>
+MP_HD void cover_pixel64(const Piece& p, const Edges& e, int px, int py, Emit&& emit) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float b[3], wsum;
+    const bool inside = eval_at(p, e, (long long)(px * SUBPIX + sample_off_x(NS, s)), (long long)(py * SUBPIX + sample_off_y(NS, s)), b, wsum);
+    if (inside && depth_in_range(wsum)) emit(s, wsum);
+  }
+}
+
+// 64-bit z-buffer key of a covered sample: larger wsum (nearer) wins, equal depth -> lower piece id wins; 0 = empty.
+// (wsum > 0 inside the depth range, so its bit pattern orders like the value)
+MP_HD unsigned long long depth_key(float wsum, int id) {
+  uint32_t wb;
+  memcpy(&wb, &wsum, 4);
+  return ((unsigned long long)wb << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+}
+MP_HD float key_wsum(unsigned long long key) {
+  const uint32_t wb = (uint32_t)(key >> 32);
+  float f;
+  memcpy(&f, &wb, 4);
+  return f;
+}
+MP_HD int key_id(unsigned long long key) { return key ? (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu)) : -1; }
+
 // One piece against the NS samples of pixel (px, py) of the tile at (tile_x0, tile_y0): coverage, depth range, depth test.
 template <int NS>
 MP_HD void cover_lane(const Piece& p, int tile_x0, int tile_y0, int px, int py, Sample (&st)[NS]) {
   if (piece_is_small(p, tile_x0, tile_y0)) {
     Edges32 e;
     piece_edges32(p, e);
-    const int cx = px * SUBPIX + 128, cy = py * SUBPIX + 128;
-    int ec[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ec[i] = edge32(e, i, cx, cy);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int ox = sample_off_x(NS, s) - 128, oy = sample_off_y(NS, s) - 128;
-      int es[3];
-      bool inside = true;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        es[i] = ec[i] + (e.dx[i] * oy - e.dy[i] * ox);
-        inside = inside && (es[i] >= e.thr[i]);
-      }
-      if (inside) {
-        const float b0 = (float)es[0] * e.inv_area, b1 = (float)es[1] * e.inv_area, b2 = (float)es[2] * e.inv_area;
-        const float wsum = fmaf(b2, p.iz[2], fmaf(b1, p.iz[1], b0 * p.iz[0]));
-        if (depth_in_range(wsum)) sample_update(st[s], wsum, p.id);
-      }
-    }
+    cover_pixel32<NS>(p, e, px, py, [&](int s, float wsum) { sample_update(st[s], wsum, p.id); });
   } else {
     Edges e;
     piece_edges(p, e);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      float b[3], wsum;
-      const bool inside = eval_at(p, e, (long long)(px * SUBPIX + sample_off_x(NS, s)), (long long)(py * SUBPIX + sample_off_y(NS, s)), b, wsum);
-      if (inside && depth_in_range(wsum)) sample_update(st[s], wsum, p.id);
-    }
+    cover_pixel64<NS>(p, e, px, py, [&](int s, float wsum) { sample_update(st[s], wsum, p.id); });
   }
 }
-
 
 // piece index (in the [0, 2F) space) from a depth-tie id: they coincide (first piece: tri, second: F + tri)
 MP_HD int index_of_id(int id) { return id; }

@@ -18,6 +18,7 @@ using namespace mp::rc;
 namespace {
 constexpr int LARGE_TILES = 16;
 constexpr int TILE_WAVES = 4;
+constexpr int SCATTER_MAX_AREA = 32;
 
 struct Lists {
   std::vector<int> tile_off, list, large;
@@ -29,6 +30,29 @@ void tile_range(const Piece& p, int ns, int w, int h, int& tx0, int& ty0, int& t
   piece_pixel_bbox(p, ns, w, h, x0, y0, x1, y1);
   tx0 = x0 >> 3; ty0 = y0 >> 3; tx1 = x1 >> 3; ty1 = y1 >> 3;
   if (x0 > x1 || y0 > y1) { tx1 = tx0 - 1; ty1 = ty0 - 1; }
+}
+
+// the binning kernel's conservative tile test (exact integers)
+struct TileTest {
+  long long A[3], B[3], C[3];
+  int omin, omax;
+};
+TileTest tile_test_setup(const Piece& p, int ns) {
+  TileTest t;
+  const int a[3] = {1, 2, 0}, b[3] = {2, 0, 1};
+  for (int i = 0; i < 3; ++i) {
+    const long long dx = p.X[b[i]] - p.X[a[i]], dy = p.Y[b[i]] - p.Y[a[i]];
+    t.A[i] = -dy; t.B[i] = dx; t.C[i] = dy * p.X[a[i]] - dx * p.Y[a[i]];
+  }
+  t.omin = sample_off_min(ns); t.omax = sample_off_max(ns);
+  return t;
+}
+bool tile_touched(const TileTest& t, int tx, int ty) {
+  const long long x_lo = tx * TILE * SUBPIX + t.omin, x_hi = (tx * TILE + TILE - 1) * SUBPIX + t.omax;
+  const long long y_lo = ty * TILE * SUBPIX + t.omin, y_hi = (ty * TILE + TILE - 1) * SUBPIX + t.omax;
+  for (int i = 0; i < 3; ++i)
+    if (t.A[i] * (t.A[i] >= 0 ? x_hi : x_lo) + t.B[i] * (t.B[i] >= 0 ? y_hi : y_lo) + t.C[i] < 0) return false;
+  return true;
 }
 
 Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, int ns, int cap_list) {
@@ -46,9 +70,12 @@ Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, 
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1) continue;
       if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) L.large.push_back(p.id);
-      else
+      else {
+        const TileTest tt = tile_test_setup(p, ns);
         for (int ty = ty0; ty <= ty1; ++ty)
-          for (int tx = tx0; tx <= tx1; ++tx) ++counts[ty * tiles_x + tx];
+          for (int tx = tx0; tx <= tx1; ++tx)
+            if (tile_touched(tt, tx, ty)) ++counts[ty * tiles_x + tx];
+      }
     }
   }
   L.tile_off.assign(n_tiles + 1, 0);
@@ -66,8 +93,10 @@ Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, 
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) continue;
+      const TileTest tt = tile_test_setup(p, ns);
       for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) L.list[cursor[ty * tiles_x + tx]++] = p.id;
+        for (int tx = tx0; tx <= tx1; ++tx)
+          if (tile_touched(tt, tx, ty)) L.list[cursor[ty * tiles_x + tx]++] = p.id;
     }
   }
   return L;
@@ -93,9 +122,9 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
     for (int ty = 0; ty < tiles_y; ++ty)
       for (int tx = 0; tx < tiles_x; ++tx) {
         const int tile = ty * tiles_x + tx, tile_x0 = tx * TILE, tile_y0 = ty * TILE;
-        Sample st[64][NS];
-        for (int l = 0; l < 64; ++l)
-          for (int s = 0; s < NS; ++s) { st[l][s].wsum = 0.f; st[l][s].id = -1; }
+        // the wave's z-buffer: 64-bit keys, as in the kernel (scatter form for small footprints, sweep form for the rest)
+        unsigned long long zb[64 * NS];
+        for (int i = 0; i < 64 * NS; ++i) zb[i] = 0ull;
         std::vector<int> entries;
         if (L.overflow) for (int i = 0; i < 2 * m.n_faces; ++i) entries.push_back(i);
         else {
@@ -106,20 +135,47 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
           Piece p;
           piece_from_index<false>(m, T, Kv, idx, p);
           if (p.id < 0) continue;
-          const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
-          const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
-          const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
-          if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) continue;
-          bool any = true;
-          if (NS > 1 && piece_is_small(p, tile_x0, tile_y0)) {
+          int x0, y0, x1, y1;
+          piece_pixel_bbox(p, NS, w, h, x0, y0, x1, y1);
+          x0 = imax(x0, tile_x0); y0 = imax(y0, tile_y0); x1 = imin(x1, tile_x0 + TILE - 1); y1 = imin(y1, tile_y0 + TILE - 1);
+          if (x0 > x1 || y0 > y1) continue;
+          const bool small = piece_is_small(p, tile_x0, tile_y0);
+          if (small && (x1 - x0 + 1) * (y1 - y0 + 1) <= SCATTER_MAX_AREA) {   // scatter form
             Edges32 e;
             piece_edges32(p, e);
-            any = false;
-            for (int l = 0; l < 64; ++l) any = any || maybe_covered32(e, tile_x0 + (l & 7), tile_y0 + (l >> 3));
+            for (int py = y0; py <= y1; ++py)
+              for (int px = x0; px <= x1; ++px) {
+                const int local = ((py - tile_y0) << 3) | (px - tile_x0);
+                cover_pixel32<NS>(p, e, px, py, [&](int s, float wsum) {
+                  const unsigned long long key = depth_key(wsum, p.id);
+                  if (key > zb[local * NS + s]) zb[local * NS + s] = key;
+                });
+              }
+          } else {                                                             // sweep form
+            const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
+            const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
+            const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
+            if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) continue;
+            for (int l = 0; l < 64; ++l) {
+              auto emit = [&](int s, float wsum) {
+                const unsigned long long key = depth_key(wsum, p.id);
+                if (key > zb[l * NS + s]) zb[l * NS + s] = key;
+              };
+              if (small) {
+                Edges32 e;
+                piece_edges32(p, e);
+                cover_pixel32<NS>(p, e, tile_x0 + (l & 7), tile_y0 + (l >> 3), emit);
+              } else {
+                Edges e;
+                piece_edges(p, e);
+                cover_pixel64<NS>(p, e, tile_x0 + (l & 7), tile_y0 + (l >> 3), emit);
+              }
+            }
           }
-          if (!any) continue;
-          for (int l = 0; l < 64; ++l) cover_lane<NS>(p, tile_x0, tile_y0, tile_x0 + (l & 7), tile_y0 + (l >> 3), st[l]);
         }
+        Sample st[64][NS];
+        for (int l = 0; l < 64; ++l)
+          for (int s = 0; s < NS; ++s) { st[l][s].wsum = key_wsum(zb[l * NS + s]); st[l][s].id = key_id(zb[l * NS + s]); }
         // tasks + shading + resolve
         for (int l = 0; l < 64; ++l) {
           const int px = tile_x0 + (l & 7), py = tile_y0 + (l >> 3);
