@@ -290,11 +290,13 @@ int mp_pose_update(const float* d_TCO /*[b,4,4]*/, const float* d_K_crop /*[b,3,
 /* projective point-to-plane ICP with the same budget / acceptance rule (csrc/icp.hip).     */
 /* d_depth_meas [n_images,H,W] metres (0 = invalid), d_depth_rend [n_rows,H,W] rendered at  */
 /* d_TCO, d_K_images [n_images,3,3], d_K_rows [n_rows,3,3].  retval[n] = 0 ok / -1 kept.    */
+/* user_masks != 0: the caller's segmentation masks have been applied to d_depth_meas and     */
+/* the |measured - rendered| <= 0.1 m test is skipped (icp_refiner.py:249-250).               */
 /* ------------------------------------------------------------------------------------ */
 size_t mp_icp_workspace_bytes(int n_images, int n_rows, int H, int W);
 int mp_icp_refine(const float* d_depth_meas, int n_images, const int32_t* d_im_ids, const float* d_depth_rend,
                   const float* d_K_images, const float* d_K_rows, const float* d_TCO, int n_rows, int H, int W,
-                  int n_iterations, int n_levels, float tolerance, int n_min_points, float* d_TCO_out,
+                  int n_iterations, int n_levels, float tolerance, int n_min_points, int user_masks, float* d_TCO_out,
                   int32_t* d_retval, float* d_residual, void* d_workspace, size_t workspace_bytes, mp_stream stream);
 
 #ifdef __cplusplus

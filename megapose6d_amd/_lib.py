@@ -111,7 +111,7 @@ SIGNATURES = {
     "mp_pose_prepare": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp]),
     "mp_icp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "mp_icp_refine": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_icp_refine": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_pose_update": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
 }
 

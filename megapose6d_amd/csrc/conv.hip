@@ -261,6 +261,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
     const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
     const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
+    if constexpr ((VARIANT & 2048) != 0) {
+      // Fragment prefetch: the 16-byte A/B fragments of k-group kk + 1 are read from LDS while the 16 MFMAs of group kk run
+      // (1024 SIMD cycles of cover), so the only exposed LDS latency per chunk is the first group's, right after the barrier.
+      float4 afr[2][TM], bfr[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) afr[0][i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT);
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        if (kk + 1 < BK / 8) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) afr[(kk + 1) & 1][i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT + (kk + 1) * 8);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[(kk + 1) & 1][j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT + (kk + 1) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the reads above stay ahead of this group's MFMAs
+        constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
+        if (kk == STORE_KK) {
+          MP_CONV_STORE(buf ^ 1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].x, bfr[kk & 1][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].y, bfr[kk & 1][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].z, bfr[kk & 1][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].w, bfr[kk & 1][j].w, acc[i][j], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
@@ -293,6 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
           }
       }
+    }
     }
     if constexpr (SBUF) {
       __syncthreads();  // every wave is done reading this chunk
@@ -612,6 +647,8 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
     case 1: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
     case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
+    case 2305: return small ? launch<128, 64, 64, 32, 2305>(p, s, alg_k) : launch<128, 128, 64, 64, 2305>(p, s, alg_k);  // + LDS fragment prefetch
+    case 2817: return small ? launch<128, 64, 64, 32, 2817>(p, s, alg_k) : launch<128, 128, 64, 64, 2817>(p, s, alg_k);  // same, LDS store under group 1
     default: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);
   }
 }

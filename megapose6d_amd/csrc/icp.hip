@@ -28,10 +28,11 @@ struct IcpRow {        // per object state, device resident
   float residual;      // RMS point-to-plane residual of the last iteration
 };
 
-__device__ __forceinline__ bool mask_at(const float* dm, const float* dr, int idx) {
+__device__ __forceinline__ bool mask_at(const float* dm, const float* dr, int idx, float delta_thresh) {
   const float m = dm[idx], r = dr[idx];
-  // refiner_utils.py:45-51 (threshold mask) and icp_refiner.py:142-143 (0.2 < depth < 5)
-  return m > 0.f && r > 0.f && fabsf(m - r) <= 0.1f && m > 0.2f && m < 5.0f;
+  // refiner_utils.py:45-51 (threshold mask; delta_thresh = +inf when the caller supplied its own masks: icp_refiner.py:249-250
+  // then uses that mask alone, which the host has already applied to the measured depth) and :142-143 (0.2 < depth < 5)
+  return m > 0.f && r > 0.f && fabsf(m - r) <= delta_thresh && m > 0.2f && m < 5.0f;
 }
 
 // normals of the measured depth images (one per frame): cross product of central differences of back-projected points
@@ -75,7 +76,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // mask size + centroids of target / source points (icp_refiner.py:157-162)
 __global__ __launch_bounds__(256) void icp_stats(const float* __restrict__ depth_meas, const int32_t* __restrict__ im_ids,
                                                  const float* __restrict__ depth_rend, const float* __restrict__ K, int H, int W,
-                                                 IcpRow* __restrict__ rows) {
+                                                 float delta_thresh, IcpRow* __restrict__ rows) {
   __shared__ float red[4];
   const int n = blockIdx.y;
   const float* dm = depth_meas + (size_t)im_ids[n] * H * W;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void icp_stats(const float* __restrict__ depth
   const float ifx = 1.0f / Kn[0], ify = 1.0f / Kn[4], cx = Kn[2], cy = Kn[5];
   float v[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
-    if (!mask_at(dm, dr, idx)) continue;
+    if (!mask_at(dm, dr, idx, delta_thresh)) continue;
     const float u = (float)(idx % W) - cx, w_ = (float)(idx / W) - cy;
     const float zt = dm[idx], zs = dr[idx];
     v[0] += 1.f;
@@ -117,7 +118,7 @@ __global__ void icp_init(IcpRow* __restrict__ rows, int N, int n_min_points) {
 __global__ __launch_bounds__(256) void icp_accumulate(const float* __restrict__ depth_meas, const float* __restrict__ normals,
                                                       const int32_t* __restrict__ im_ids, const float* __restrict__ depth_rend,
                                                       const float* __restrict__ K, int H, int W, int stride, float d_max,
-                                                      IcpRow* __restrict__ rows) {
+                                                      float delta_thresh, IcpRow* __restrict__ rows) {
   __shared__ float red[4];
   const int n = blockIdx.y;
   if (rows[n].status == 0) return;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void icp_accumulate(const float* __restrict__ 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hs * Ws; i += gridDim.x * blockDim.x) {
     const int y = (i / Ws) * stride, x = (i % Ws) * stride;
     const int idx = y * W + x;
-    if (!mask_at(dm, dr, idx)) continue;
+    if (!mask_at(dm, dr, idx, delta_thresh)) continue;
     const float zs = dr[idx];
     const float px = ((float)x - cx) * zs * ifx, py = ((float)y - cy) * zs * ify;
     const float sx = T[0] * px + T[1] * py + T[2] * zs + T[3];
@@ -255,7 +256,7 @@ extern "C" size_t mp_icp_workspace_bytes(int n_images, int n_rows, int H, int W)
 
 extern "C" int mp_icp_refine(const float* d_depth_meas, int n_images, const int32_t* d_im_ids, const float* d_depth_rend,
                              const float* d_K_images, const float* d_K_rows, const float* d_TCO, int n_rows, int H, int W,
-                             int n_iterations, int n_levels, float tolerance, int n_min_points, float* d_TCO_out,
+                             int n_iterations, int n_levels, float tolerance, int n_min_points, int user_masks, float* d_TCO_out,
                              int32_t* d_retval, float* d_residual, void* d_ws, size_t ws_bytes, mp_stream stream) {
   MP_REQUIRE(d_depth_meas && d_im_ids && d_depth_rend && d_K_images && d_K_rows && d_TCO && d_TCO_out && d_ws, "mp_icp_refine: null pointer");
   MP_REQUIRE(n_images > 0 && n_rows >= 0 && H > 0 && W > 0 && n_iterations > 0 && n_levels >= 1 && n_levels <= 8, "mp_icp_refine: bad size");
@@ -268,7 +269,9 @@ extern "C" int mp_icp_refine(const float* d_depth_meas, int n_images, const int3
   MP_CHECK_HIP(hipMemsetAsync(rows, 0, (size_t)n_rows * sizeof(IcpRow), s));
   ProfScope prof("icp_refine", 0.0, (double)n_rows * H * W * 8.0 * n_iterations, s);
   hipLaunchKernelGGL(icp_target_normals, dim3(ceil_div((long)H * W, 256), n_images), dim3(256), 0, s, d_depth_meas, d_K_images, H, W, normals);
-  hipLaunchKernelGGL(icp_stats, dim3(ICP_STAT_BLOCKS, n_rows), dim3(256), 0, s, d_depth_meas, d_im_ids, d_depth_rend, d_K_rows, H, W, rows);
+  // user_masks: the caller's masks were already applied to d_depth_meas; the |measured - rendered| <= 0.1 m test is then skipped
+  const float delta_thresh = user_masks ? INFINITY : 0.1f;
+  hipLaunchKernelGGL(icp_stats, dim3(ICP_STAT_BLOCKS, n_rows), dim3(256), 0, s, d_depth_meas, d_im_ids, d_depth_rend, d_K_rows, H, W, delta_thresh, rows);
   hipLaunchKernelGGL(icp_init, dim3(ceil_div(n_rows, 64)), dim3(64), 0, s, rows, n_rows, n_min_points);
   const int per_level = ceil_div(n_iterations, n_levels);
   for (int l = 0; l < n_levels; ++l) {
@@ -276,7 +279,7 @@ extern "C" int mp_icp_refine(const float* d_depth_meas, int n_images, const int3
     const float d_max = tolerance * (float)(n_levels - l);  // 0.20, 0.15, 0.10, 0.05 for the reference's (0.05, 4 levels)
     for (int it = 0; it < per_level; ++it) {
       hipLaunchKernelGGL(icp_accumulate, dim3(ICP_ACC_BLOCKS, n_rows), dim3(256), 0, s, d_depth_meas, normals, d_im_ids, d_depth_rend, d_K_rows, H, W,
-                         stride, d_max, rows);
+                         stride, d_max, delta_thresh, rows);
       hipLaunchKernelGGL(icp_solve, dim3(ceil_div(n_rows, 64)), dim3(64), 0, s, rows, n_rows, 50.0f);
     }
   }

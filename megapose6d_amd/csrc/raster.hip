@@ -195,6 +195,20 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef MP_RASTER_PROF   // scripts/microbench build only (never in libmp_engine.so): per-phase shader-cycle totals of raster_tiles
+__device__ unsigned long long g_raster_prof[16];
+#define PROF_T0 unsigned long long prof_t = __builtin_readcyclecounter();
+#define PROF(slot)                                                                  \
+  {                                                                                 \
+    const unsigned long long prof_n = __builtin_readcyclecounter();                 \
+    if (lane == 0) atomicAdd(&g_raster_prof[slot], prof_n - prof_t);                \
+    prof_t = prof_n;                                                                \
+  }
+#else
+#define PROF_T0
+#define PROF(slot)
+#endif
+
 constexpr int SCATTER_MAX_AREA = 32;  // footprint (pixels of bbox ∩ tile) up to which a lane rasterises its own piece
 
 // ---- coverage form 1: lane-per-piece scatter.  Every lane owns one small piece of the batch and walks the pixels of the piece's
@@ -278,6 +292,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
 
+  PROF_T0
   for (int r = 0; r < views_per_item; ++r) {
     const int view = item * views_per_item + r;
     const int mesh_id = mesh_ids[view];
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
       else if (e < n_total) idx = large[e - n_list];
       Piece mine_p;
       mine_p.id = -1;
+      PROF(0)
       if (idx >= 0) rc::piece_from_index<false>(m, T, Kv, idx, mine_p);
       int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
       bool small = false;
@@ -316,8 +332,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
       }
       const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
       const bool scat = hit && small && (x1 - x0 + 1) * (y1 - y0 + 1) <= SCATTER_MAX_AREA;
+      PROF(1)
       if (__ballot(scat) != 0ull) scatter_piece<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, zb);
       wave_lds_fence();
+      PROF(2)
       unsigned long long big = __ballot(hit && !scat);
       while (big) {
         const int j = __ffsll((long long)big) - 1;
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
         sweep_piece<NS>(p, tile_x0, tile_y0, px, py, lane, zb);
       }
       wave_lds_fence();
+      PROF(3)
     }
     Sample st[NS];
 #pragma unroll
@@ -342,9 +361,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     wave_lds_fence();   // zb is reused for the shading results below
     // ---- shading tasks: one per (pixel, distinct winning piece), ordered by (sample, lane) -------------------------------------
     int n_tasks = 0;
+    const bool need_shade = c_rgb >= 0 || do_norm;   // a depth-only render (the depth refiner's) has nothing to shade
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      bool nw = st[s].id >= 0;
+      bool nw = need_shade && st[s].id >= 0;
 #pragma unroll
       for (int k = 0; k < s; ++k) nw = nw && !(st[k].id == st[s].id);
       const unsigned long long mask = __ballot(nw);
@@ -352,6 +372,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
       n_tasks += __popcll(mask);
     }
     wave_lds_fence();
+    PROF(4)
     const TexDev* tex = m.uvs ? &texs[mesh_id] : nullptr;
     for (int k0 = 0; k0 < n_tasks; k0 += 64) {
       const int k = k0 + lane;
@@ -369,11 +390,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
       }
     }
     wave_lds_fence();
+    PROF(5)
     // ---- resolve: mean of the samples' 8-bit values, background samples = 0 ----------------------------------------------------
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (st[s].id < 0) continue;
+      if (st[s].id < 0 || !need_shade) continue;
       int src = s;
 #pragma unroll
       for (int k = s - 1; k >= 0; --k)
@@ -393,6 +415,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     }
     if (do_depth) my_stage[c_depth + cv - c_lo] = st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f;
     wave_lds_fence();  // the z-buffer / task arrays are reused by the next view
+    PROF(6)
   }
   if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
     const float* bx = crop.boxes + (size_t)item * 4;
@@ -412,6 +435,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cvals[3];
   }
   wave_lds_fence();
+  PROF(7)
   // ---- store: each of the tile's 8 rows leaves as one contiguous run of 8 pixels x `run` channels (only written channels) -------
   float* out_item = out + (size_t)item * stride_v + c_lo;
   const int cols = min(TILE, w - tile_x0), rows = min(TILE, h - tile_y0);
@@ -423,6 +447,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     const float* sp = stage + (size_t)x * run + c;
     for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = sp[(size_t)row * 8 * run];
   }
+  PROF(8)
 }
 
 }  // namespace mp
@@ -630,6 +655,18 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
+
+#ifdef MP_RASTER_PROF
+extern "C" int mp_raster_prof_read(unsigned long long* out16, int reset) {
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_raster_prof), 16 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_raster_prof), z, sizeof(z)));
+  }
+  return MP_OK;
+}
+#endif
 
 extern "C" int mp_raster_render(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
                                 int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,

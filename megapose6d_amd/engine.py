@@ -407,8 +407,10 @@ def pose_update(TCO, K_crop, out9, tCR, k_stride_floats: int = 9) -> torch.Tenso
 
 
 def icp_refine(depth_meas: torch.Tensor, im_ids: torch.Tensor, depth_rend: torch.Tensor, K_images: torch.Tensor, K_rows: torch.Tensor,
-               TCO: torch.Tensor, n_iterations: int = 100, n_levels: int = 4, tolerance: float = 0.05, n_min_points: int = 1000):
-    """-> (TCO_refined [N,4,4], retval [N] int32 (0 ok / -1 input pose kept), residual [N])"""
+               TCO: torch.Tensor, n_iterations: int = 100, n_levels: int = 4, tolerance: float = 0.05, n_min_points: int = 1000,
+               user_masks: bool = False):
+    """-> (TCO_refined [N,4,4], retval [N] int32 (0 ok / -1 input pose kept), residual [N]).  `user_masks`: the caller's masks
+    are already applied to depth_meas; the 0.1 m measured-vs-rendered threshold mask is then not used (icp_refiner.py:249-250)."""
     lib = _lib.load()
     depth_meas, depth_rend = _dev_f32(depth_meas), _dev_f32(depth_rend)
     K_images, K_rows, TCO = _dev_f32(K_images), _dev_f32(K_rows), _dev_f32(TCO)
@@ -421,6 +423,6 @@ def icp_refine(depth_meas: torch.Tensor, im_ids: torch.Tensor, depth_rend: torch
     residual = torch.empty(N, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.mp_icp_workspace_bytes(n_im, N, H, W), dtype=torch.uint8, device=dev)
     check(lib.mp_icp_refine(depth_meas.data_ptr(), n_im, _dev_i32(im_ids).data_ptr(), depth_rend.data_ptr(), K_images.data_ptr(),
-                            K_rows.data_ptr(), TCO.data_ptr(), N, H, W, n_iterations, n_levels, tolerance, n_min_points, out.data_ptr(),
+                            K_rows.data_ptr(), TCO.data_ptr(), N, H, W, n_iterations, n_levels, tolerance, n_min_points, int(user_masks), out.data_ptr(),
                             retval.data_ptr(), residual.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out, retval, residual

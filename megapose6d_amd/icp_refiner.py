@@ -46,13 +46,13 @@ class ICPRefiner(DepthRefiner):
         TCO_ = predictions.poses.to(device=device, dtype=torch.float32)
         K_ = K[im_ids.long()].float()
         resolution = tuple(depth.shape[-2:])
-        out = self.renderer.render(labels, TCO=TCO_, K=K_, light_datas=[self.light_datas] * N, resolution=resolution, render_depth=True)
-        depth_rendered = out.depths[:, 0].contiguous()
+        # depth at the pixel centres (not the off-centre sample a multisample depth resolve returns): it is back-projected below
+        depth_rendered = self.renderer.render_depth(labels, TCO_, K_, resolution).contiguous()
         depth_meas = depth.float()
-        if masks is not None:  # user masks restrict the measured depth (icp_refiner.py:249-250)
+        if masks is not None:  # the caller's masks REPLACE the threshold mask (icp_refiner.py:249-250)
             depth_meas = depth_meas * (masks.to(depth_meas.dtype) > 0)
         refined, retval, residual = eng.icp_refine(depth_meas.contiguous(), im_ids, depth_rendered, K.float(), K_, TCO_, self.n_iterations,
-                                                   self.n_levels, self.tolerance, self.n_min_points)
+                                                   self.n_levels, self.tolerance, self.n_min_points, user_masks=masks is not None)
         if "poses_input" in predictions_refined.tensors:
             predictions_refined.poses_input = predictions.poses.clone()
         else:

@@ -100,12 +100,12 @@ class Panda3dBatchRenderer:
     def render_into(self, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, lights: Sequence[Panda3dLightData],
                     resolution: Resolution, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int,
                     c_normals: int, c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0,
-                    slot: int = 0, crop=None) -> None:
+                    slot: int = 0, crop=None, msaa: Optional[int] = None) -> None:
         db = self._ensure_db()
         flags = (eng.RASTER_NORMALS if c_normals >= 0 else 0) | (eng.RASTER_DEPTH if c_depth >= 0 else 0)
         if self._gl_eye:
             flags |= eng.RASTER_NORMALS_GL
-        if self.msaa == 4:
+        if (self.msaa if msaa is None else msaa) == 4:
             flags |= eng.RASTER_MSAA4
         h, w = resolution
         eng.raster_render(db, mesh_ids, TCO, K, h, w, flags, _to_engine_lights(lights), out, stride_v, stride_y, stride_x, c_rgb,
@@ -145,6 +145,19 @@ class Panda3dBatchRenderer:
         nchw = out.permute(0, 3, 1, 2)  # views with NCHW shape; memory stays NHWC
         return BatchRenderOutput(rgbs=nchw[:, 0:3], normals=nchw[:, 3:6] if render_normals else None,
                                  depths=nchw[:, 6:7] if render_depth else None)
+
+    def render_depth(self, labels: List[str], TCO: torch.Tensor, K: torch.Tensor, resolution: Resolution) -> torch.Tensor:
+        """Metric depth maps [n, h, w] sampled at the PIXEL CENTRES (one sample per pixel) -- what a geometric consumer (the depth
+        refiner) back-projects.  `render(..., render_depth=True)` under 4x multisampling returns sample 0's depth, which sits
+        (0.375, 0.125) px off the centre like a resolved multisample depth buffer."""
+        bsz = TCO.shape[0]
+        device = TCO.device if TCO.is_cuda else torch.device("cuda")
+        TCO = TCO.detach().to(device=device, dtype=torch.float32)
+        K = K.detach().to(device=device, dtype=torch.float32)
+        h, w = resolution
+        out = torch.empty(bsz, h, w, 1, dtype=torch.float32, device=device)
+        self.render_into(self.label_ids(labels, device), TCO, K, [Panda3dLightData("ambient")], resolution, out, h * w, w, 1, -1, -1, 0, msaa=1)
+        return out[..., 0]
 
     def stop(self) -> None:
         if self._is_closed:

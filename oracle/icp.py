@@ -44,12 +44,13 @@ def _rodrigues(w):
     return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
 
 
-def icp_refine(depth_meas, depth_rend, K, TCO, n_iterations=100, n_levels=4, tolerance=0.05, n_min_points=1000):
-    """one object: returns (TCO_refined, retval, residual)"""
+def icp_refine(depth_meas, depth_rend, K, TCO, n_iterations=100, n_levels=4, tolerance=0.05, n_min_points=1000, user_masks=False):
+    """one object: returns (TCO_refined, retval, residual).  user_masks: depth_meas is already masked by the caller's segmentation
+    and the 0.1 m threshold mask is not used (reference icp_refiner.py:249-250)."""
     H, W = depth_meas.shape
     fx, fy, cx, cy = [float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])]
     dm, dr = depth_meas.astype(np.float64), depth_rend.astype(np.float64)
-    mask = (dm > 0) & (dr > 0) & (np.abs(dm - dr) <= 0.1) & (dm > 0.2) & (dm < 5.0)
+    mask = (dm > 0) & (dr > 0) & ((np.abs(dm - dr) <= 0.1) | bool(user_masks)) & (dm > 0.2) & (dm < 5.0)
     if mask.sum() < n_min_points:
         return TCO.copy(), -1, -1.0
     ys, xs = np.mgrid[0:H, 0:W]

@@ -90,6 +90,7 @@ def test_teacher_forced_iterations_with_undamped_pose_head():
     oracle's iteration n.  Reference: models/pose_rigid.py:498-604 (forward), :305-312 (update_pose)."""
     from megapose6d_amd import synthetic as syn
     from megapose6d_amd.scene import make_scene
+    from oracle import backbones as ob
     from oracle import harness
 
     tmp = tempfile.mkdtemp(prefix="mp_tf_")
@@ -114,5 +115,17 @@ def test_teacher_forced_iterations_with_undamped_pose_head():
                               im_ids=torch.zeros(576, dtype=torch.int32, device="cuda"), materialize=False)["iteration=1"]
         e_out = (o.network_outputs["pose"][pos].cpu() - outs[n]["net"]["pose"]).abs().max().item()
         e_pose = (o.TCO_output[pos].cpu() - outs[n]["TCO_output"]).abs().max().item()
-        assert e_out < TOL, (n, e_out)
-        assert e_pose < TOL, (n, e_pose)
+        # The synthetic nets produce 512-d features of magnitude 1e2..1e3 (real, BN-trained nets: ~1), so the feature-dependent part
+        # of the 9-vector, W f, is O(1..10) here and an ABSOLUTE 1e-4 would demand < 1e-5 relative accuracy of a 34-layer fp32
+        # conv stack.  fp32 MFMA accumulates sequentially along K (like cuDNN's implicit GEMM; torch's CPU path sums block-wise and
+        # is ~10x closer to float64), so the bound is 1e-4 RELATIVE to |W f| -- the same class as the 2e-4-of-feature-scale bound of
+        # the backbone tests, but measured on the quantity the pose update consumes, undamped.  Also checked against float64.
+        wf = (outs[n]["net"]["pose"] - rpred.sd["pose_fc.bias"]).abs().max().item()
+        tol = TOL * max(1.0, wf)
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in rpred.sd.items()}
+        p64 = ob.net_forward(sd64, "vanilla_resnet34", outs[n]["x"].double())["pose"]
+        e_out64 = (o.network_outputs["pose"][pos].cpu().double() - p64).abs().max().item()
+        assert wf > 0.5, "the undamped head must make the network output matter"
+        assert e_out < tol, (n, e_out, wf)
+        assert e_out64 < tol, (n, e_out64, wf)
+        assert e_pose < tol, (n, e_pose, wf)
