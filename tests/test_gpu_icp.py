@@ -23,7 +23,7 @@ def _scene():
     gt[1, 0, 3] += 0.15
     labels = [o.label for o in ds.list_objects]
     amb = [[Panda3dLightData("ambient")]] * 2
-    d = r.render(labels, torch.from_numpy(gt).cuda(), K[None].repeat(2, 1, 1), amb, (480, 640), render_depth=True).depths[:, 0]
+    d = r.render_depth(labels, torch.from_numpy(gt).cuda(), K[None].repeat(2, 1, 1), (480, 640))
     depth = torch.where((d[0] > 0) & ((d[1] == 0) | (d[0] < d[1])), d[0], d[1])
     g = torch.Generator().manual_seed(0)
     depth = torch.where(depth > 0, depth + (torch.randn(480, 640, generator=g) * 0.001).cuda(), depth)
@@ -61,7 +61,7 @@ def test_icp_refiner_vs_oracle_and_ground_truth():
     assert torch.equal(out.poses[2], preds.poses[2])  # rejected -> input pose kept (icp_refiner.py:257-258)
     # oracle of the same algorithm on the same rendered depth
     amb = [[Panda3dLightData("ambient")]] * 3
-    rend = r.render(lab3, torch.from_numpy(init).cuda(), K[None].repeat(3, 1, 1), amb, (480, 640), render_depth=True).depths[:, 0].cpu().numpy()
+    rend = r.render_depth(lab3, torch.from_numpy(init).cuda(), K[None].repeat(3, 1, 1), (480, 640)).cpu().numpy()
     dm = depth.cpu().numpy()
     Kn = K.cpu().numpy()
     for n in range(3):
@@ -90,3 +90,67 @@ def test_pipeline_with_depth_refiner():
     final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=1, n_pose_hypotheses=1, run_depth_refiner=True)
     assert "depth_refiner" in extra and len(final) == 1 and torch.isfinite(final.poses).all()
     assert "depth refiner=" in extra["timing_str"]
+
+
+def test_gpu_refiner_vs_opencv_icp_restatement_on_12_scenes():
+    """The reference's refiner = get_normal + OpenCV ppf_match_3d ICP (kd-tree association, robust rejection, 4-level pyramid),
+    restated in oracle/icp_opencv.py (inference/icp_refiner.py:37-175).  The engine's on-device refiner associates projectively.
+    Stated bounds on 12 synthetic scenes (noise, occluders, one 30 cm-off pose): IDENTICAL accept/reject decisions; accepted poses
+    within 1 mm / 2 degrees of the OpenCV-style result and within 1 mm of the ground-truth translation."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_icp_oracles_cpu import _rot_err_deg, make_icp_scenes
+
+    from megapose6d_amd.icp_refiner import ICPRefiner
+    from megapose6d_amd.renderer import Panda3dBatchRenderer
+    from megapose6d_amd.tcoll import PandasTensorCollection
+    from oracle import icp_opencv as ocv
+    from oracle import raster as orr
+
+    ds, scenes = make_icp_scenes(12)
+    r = Panda3dBatchRenderer(ds, n_workers=1)
+    ref = ICPRefiner(None, r)
+    K = torch.from_numpy(scenes[0][1]).cuda()
+    depth = torch.from_numpy(np.stack([s[0] for s in scenes])).cuda()            # one frame per scene
+    init = np.stack([s[2] for s in scenes])
+    preds = PandasTensorCollection(pd.DataFrame(dict(label=[s[5] for s in scenes], batch_im_id=np.arange(12), instance_id=0)),
+                                   poses=torch.from_numpy(init).cuda())
+    out, extra = ref.refine_poses(preds, depth=depth, K=K[None].repeat(12, 1, 1))
+    retval = extra["retval"].cpu().numpy()
+    n_rejected = 0
+    for n, (dm, Kn, T0, gt, mesh, _) in enumerate(scenes):
+        dr = orr.render(mesh, T0[None], Kn[None], 480, 640, 2)[2][0]
+        T_cv, rv_cv, _ = ocv.icp_refinement(dm, dr, ocv.compute_masks_threshold(dr, dm), Kn, T0)
+        assert rv_cv == retval[n], (n, rv_cv, retval[n])
+        T_g = out.poses[n].cpu().numpy()
+        if rv_cv == 0:
+            assert np.linalg.norm(T_g[:3, 3] - T_cv[:3, 3]) < 1e-3 and _rot_err_deg(T_g, T_cv) < 2.0, n
+            assert np.linalg.norm(T_g[:3, 3] - gt[:3, 3]) < 1e-3, n
+        else:
+            n_rejected += 1
+            assert np.array_equal(T_g, T0)
+    assert n_rejected == 1
+
+
+def test_user_masks_replace_threshold_mask_on_device():
+    """icp_refiner.py:249-250: with caller masks a pose 15 cm off in depth is refined (the threshold mask alone would reject it)"""
+    from megapose6d_amd import synthetic as syn
+    from megapose6d_amd.icp_refiner import ICPRefiner
+    from megapose6d_amd.renderer import Panda3dBatchRenderer
+    from megapose6d_amd.tcoll import PandasTensorCollection
+
+    ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_icp_m_"), n_objects=1, seed=31)
+    r = Panda3dBatchRenderer(ds, n_workers=1)
+    K = torch.from_numpy(syn.K_EXAMPLE.astype(np.float32)).cuda()
+    gt = syn.random_pose(np.random.RandomState(5), (0.42, 0.45), 0.05)
+    depth = r.render_depth([ds[0].label], torch.from_numpy(gt[None]).cuda(), K[None], (480, 640))
+    off = gt.copy()
+    off[2, 3] += 0.15
+    preds = PandasTensorCollection(pd.DataFrame(dict(label=[ds[0].label], batch_im_id=0, instance_id=0)), poses=torch.from_numpy(off[None]).cuda())
+    ref = ICPRefiner(None, r)
+    _, e0 = ref.refine_poses(preds, depth=depth, K=K[None])
+    assert e0["retval"].item() == -1
+    out, e1 = ref.refine_poses(preds, masks=(depth > 0), depth=depth, K=K[None])
+    assert e1["retval"].item() == 0 and np.linalg.norm(out.poses[0].cpu().numpy()[:3, 3] - gt[:3, 3]) < 5e-3
