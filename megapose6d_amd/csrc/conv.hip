@@ -59,6 +59,10 @@ struct ConvParams {
   int m_part_begin;  // first output row held by `partial` (rows before it belong to the single-pass launch)
 };
 
+#ifdef MP_RASTER_PROF   // scripts/microbench build only: shader cycles vs 100 MHz real-time ticks spent inside the conv kernels
+__device__ unsigned long long g_conv_clk[2];
+#endif
+
 template <int TM, int TN, bool RES, bool RELU, bool ACT>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[TM][TN], const int* row_off, int row0, int n_first) {
 #pragma unroll
@@ -108,6 +112,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
   constexpr int B_LD4 = BN / 32;
 
+#ifdef MP_RASTER_PROF
+  const unsigned long long prof_c0 = __builtin_readcyclecounter(), prof_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [NBUF][BM][LDT]
   float* Bs = smem + NBUF * BM * LDT;        // [NBUF][BN][LDT]
@@ -343,6 +350,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 #undef MP_LD4
 #undef MP_ST4
 
+#ifdef MP_RASTER_PROF
+  if (threadIdx.x == 0) {   // main loop only (prologue + K loop), one sample per workgroup
+    atomicAdd(&g_conv_clk[0], __builtin_readcyclecounter() - prof_c0);
+    atomicAdd(&g_conv_clk[1], __builtin_amdgcn_s_memrealtime() - prof_r0);
+  }
+#endif
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   // (compile-time flags: one straight-line store loop per fused mode instead of four data-dependent branches per element)
   const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
@@ -480,6 +493,18 @@ static inline int conv_bn_tile(int Cout) { return Cout <= 64 ? 64 : 128; }
 }  // namespace mp
 
 using namespace mp;
+
+#ifdef MP_RASTER_PROF
+extern "C" int mp_conv_prof_read(unsigned long long* out2, int reset) {
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_conv_clk), 2 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[2] = {0, 0};
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_clk), z, sizeof(z)));
+  }
+  return MP_OK;
+}
+#endif
 
 extern "C" size_t mp_conv_packed_floats(int Cin_p, int Cout, int KH, int KW) {
   const int BN = conv_bn_tile(Cout);

@@ -54,9 +54,12 @@ struct CropArgs {
   int C, H, W, c0, nhwc4;
 };
 
-struct BinLayout {   // per-view workspace (ints): [hdr HDR_INTS][tile_off n_tiles + 1][list cap_list][large 2 * max_faces]
+// per-view workspace, in ints (every section starts 16-byte aligned):
+//   [hdr HDR_INTS][tile_off n_tiles + 1][large: piece indices, 2 * max_faces][list: cap_list TileRec records of 8 ints]
+struct BinLayout {
   long long view_ints;
   int n_tiles, tiles_x, tiles_y, cap_list, max_faces;
+  int off_large, off_list;   // int offsets of the two sections inside a view's block
 };
 
 __device__ __forceinline__ void tile_range(const Piece& p, int ns, int w, int h, int& tx0, int& ty0, int& tx1, int& ty1) {
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
   const int tid = threadIdx.x;
   int* hdr = ws + (size_t)view * lay.view_ints;
   int* tile_off = hdr + HDR_INTS;
-  int* list = tile_off + lay.n_tiles + 1;
-  int* large = list + lay.cap_list;
+  int* large = hdr + lay.off_large;
+  rc::TileRec* list = reinterpret_cast<rc::TileRec*>(hdr + lay.off_list);
   const MeshDev m = meshes[mesh_ids[view]];
   const float* T = TCO + (size_t)view * 16;
   const float* Kv = K + (size_t)view * 9;
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1) continue;
-      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) {
-        large[atomicAdd(&s_nlarge, 1)] = p.id;   // piece index == depth-tie id
+      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT) {
+        large[atomicAdd(&s_nlarge, 1)] = p.id;   // piece index == depth-tie id; every tile recomputes and sweeps these
       } else {
         const TileTest tt = tile_test_setup(p, ns);
         for (int ty = ty0; ty <= ty1; ++ty)
@@ -179,11 +182,11 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       if (p.id < 0) continue;
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
-      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) continue;
+      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT) continue;
       const TileTest tt = tile_test_setup(p, ns);
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx)
-          if (tile_touched(tt, tx, ty)) list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = p.id;
+          if (tile_touched(tt, tx, ty)) list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = rc::pack_tile_rec(p, tx * TILE, ty * TILE);
     }
   }
 }
@@ -264,7 +267,7 @@ __device__ __forceinline__ void sweep_piece(const Piece& p, int tile_x0, int til
 }
 
 template <int NS>
-__global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_tiles(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
     float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
@@ -301,8 +304,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     const float* Kv = K + (size_t)view * 9;
     const int* hdr = ws + (size_t)view * lay.view_ints;
     const int* tile_off = hdr + HDR_INTS;
-    const int* list = tile_off + lay.n_tiles + 1;
-    const int* large = list + lay.cap_list;
+    const int* large = hdr + lay.off_large;
+    const rc::TileRec* list = reinterpret_cast<const rc::TileRec*>(hdr + lay.off_list);
     const int tile = ty * lay.tiles_x + tx;
     const bool overflow = hdr[2] != 0;
     const int begin = overflow ? 0 : tile_off[tile];
@@ -316,11 +319,15 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void raster_tiles(
     //      rest is broadcast (v_readlane) and swept by the whole wave ---------------------------------------------------------
     for (int base = 0; base < n_total; base += 64) {
       const int e = base + lane;
-      int idx = -1;
-      if (e < n_list) idx = overflow ? e : list[begin + e];
-      else if (e < n_total) idx = large[e - n_list];
       Piece mine_p;
       mine_p.id = -1;
+      if (e < n_list && !overflow) {           // a binned record: two coalesced 16-byte loads, nothing to recompute
+        const rc::TileRec rec = list[begin + e];
+        rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
+      }
+      int idx = -1;
+      if (e < n_list && overflow) idx = e;
+      else if (e >= n_list && e < n_total) idx = large[e - n_list];
       PROF(0)
       if (idx >= 0) rc::piece_from_index<false>(m, T, Kv, idx, mine_p);
       int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
@@ -571,8 +578,10 @@ static BinLayout bin_layout(const mp_mesh_db* db, int h, int w) {
   lay.tiles_y = ceil_div(h, TILE);
   lay.n_tiles = lay.tiles_x * lay.tiles_y;
   lay.max_faces = db->max_faces;
-  lay.cap_list = 4 * db->max_faces + 2048;
-  lay.view_ints = ((long long)HDR_INTS + lay.n_tiles + 1 + lay.cap_list + 2LL * db->max_faces + 3) & ~3LL;
+  lay.cap_list = 3 * db->max_faces + 2048;
+  lay.off_large = (HDR_INTS + lay.n_tiles + 1 + 3) & ~3;
+  lay.off_list = (lay.off_large + 2 * db->max_faces + 3) & ~3;
+  lay.view_ints = (long long)lay.off_list + (long long)lay.cap_list * (long long)(sizeof(rc::TileRec) / sizeof(int));
   return lay;
 }
 

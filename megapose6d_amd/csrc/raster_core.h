@@ -245,6 +245,49 @@ MP_HD bool eval_at(const Piece& p, const Edges& e, long long sx, long long sy, f
   return inside;
 }
 
+// ---- tile-list records -------------------------------------------------------------------------------------------------------
+// The binning pass stores, for every (small piece, touched tile) pair, the piece as the coverage pass needs it: screen coordinates
+// RELATIVE to the tile's first sample column / row (they fit 16 bits for a small piece), 1/z per vertex and the depth-tie id --
+// 32 bytes, read back with two coalesced 16-byte loads (no index -> faces -> vertices pointer chase, no re-transformation).
+struct __attribute__((aligned(16))) TileRec {
+  short rx0, ry0, rx1, ry1, rx2, ry2;
+  short pad0, pad1;
+  float iz0, iz1, iz2;
+  int id;
+};
+static_assert(sizeof(TileRec) == 32, "TileRec is two 16-byte words");
+
+// a piece whose extent is <= SMALL_EXTENT sub-pixel units is "small" (piece_is_small) for EVERY tile its sample bbox touches
+constexpr int SMALL_EXTENT = 23170 - 2048 - 256;
+
+MP_HD int piece_extent(const Piece& p) {
+  const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
+  const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
+  return imax(Xmax - Xmin, Ymax - Ymin);
+}
+
+MP_HD TileRec pack_tile_rec(const Piece& p, int tile_x0, int tile_y0) {
+  TileRec r;
+  const int ox = tile_x0 * SUBPIX, oy = tile_y0 * SUBPIX;
+  r.rx0 = (short)(p.X[0] - ox); r.ry0 = (short)(p.Y[0] - oy);
+  r.rx1 = (short)(p.X[1] - ox); r.ry1 = (short)(p.Y[1] - oy);
+  r.rx2 = (short)(p.X[2] - ox); r.ry2 = (short)(p.Y[2] - oy);
+  r.pad0 = r.pad1 = 0;
+  r.iz0 = p.iz[0]; r.iz1 = p.iz[1]; r.iz2 = p.iz[2];
+  r.id = p.id;
+  return r;
+}
+
+MP_HD void unpack_tile_rec(const TileRec& r, int tile_x0, int tile_y0, Piece& p) {
+  const int ox = tile_x0 * SUBPIX, oy = tile_y0 * SUBPIX;
+  p.X[0] = ox + r.rx0; p.Y[0] = oy + r.ry0;
+  p.X[1] = ox + r.rx1; p.Y[1] = oy + r.ry1;
+  p.X[2] = ox + r.rx2; p.Y[2] = oy + r.ry2;
+  p.iz[0] = r.iz0; p.iz[1] = r.iz1; p.iz[2] = r.iz2;
+  p.id = r.id;
+  p.tri = -1;
+}
+
 struct Sample {
   float wsum;
   int id;  // < 0: empty

@@ -21,7 +21,8 @@ constexpr int TILE_WAVES = 4;
 constexpr int SCATTER_MAX_AREA = 32;
 
 struct Lists {
-  std::vector<int> tile_off, list, large;
+  std::vector<int> tile_off, large;
+  std::vector<TileRec> list;     // per (small piece, touched tile) records, as the binning kernel stores them
   bool overflow = false;
 };
 
@@ -69,7 +70,7 @@ Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, 
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1) continue;
-      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) L.large.push_back(p.id);
+      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || piece_extent(p) > SMALL_EXTENT) L.large.push_back(p.id);
       else {
         const TileTest tt = tile_test_setup(p, ns);
         for (int ty = ty0; ty <= ty1; ++ty)
@@ -82,7 +83,7 @@ Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, 
   for (int i = 0; i < n_tiles; ++i) L.tile_off[i + 1] = L.tile_off[i] + counts[i];
   L.overflow = L.tile_off[n_tiles] > cap_list;
   if (L.overflow) return L;
-  L.list.assign(L.tile_off[n_tiles], -1);
+  L.list.assign(L.tile_off[n_tiles], TileRec{});
   std::vector<int> cursor(L.tile_off.begin(), L.tile_off.end() - 1);
   for (int t = 0; t < F; ++t) {
     int n_pieces = 1;
@@ -92,11 +93,11 @@ Lists bin_view(const MeshRef& m, const float* T, const float* Kv, int h, int w, 
       if (p.id < 0) continue;
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
-      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES) continue;
+      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || piece_extent(p) > SMALL_EXTENT) continue;
       const TileTest tt = tile_test_setup(p, ns);
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx)
-          if (tile_touched(tt, tx, ty)) L.list[cursor[ty * tiles_x + tx]++] = p.id;
+          if (tile_touched(tt, tx, ty)) L.list[cursor[ty * tiles_x + tx]++] = pack_tile_rec(p, tx * TILE, ty * TILE);
     }
   }
   return L;
@@ -125,15 +126,14 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
         // the wave's z-buffer: 64-bit keys, as in the kernel (scatter form for small footprints, sweep form for the rest)
         unsigned long long zb[64 * NS];
         for (int i = 0; i < 64 * NS; ++i) zb[i] = 0ull;
-        std::vector<int> entries;
-        if (L.overflow) for (int i = 0; i < 2 * m.n_faces; ++i) entries.push_back(i);
-        else {
-          entries.assign(L.list.begin() + L.tile_off[tile], L.list.begin() + L.tile_off[tile + 1]);
-          entries.insert(entries.end(), L.large.begin(), L.large.end());
+        std::vector<Piece> entries;   // binned records first (unpacked relative to THIS tile), then the recomputed large pieces
+        if (L.overflow) {
+          for (int i = 0; i < 2 * m.n_faces; ++i) { Piece q; piece_from_index<false>(m, T, Kv, i, q); entries.push_back(q); }
+        } else {
+          for (int e = L.tile_off[tile]; e < L.tile_off[tile + 1]; ++e) { Piece q; unpack_tile_rec(L.list[e], tile_x0, tile_y0, q); entries.push_back(q); }
+          for (int idx : L.large) { Piece q; piece_from_index<false>(m, T, Kv, idx, q); entries.push_back(q); }
         }
-        for (int idx : entries) {
-          Piece p;
-          piece_from_index<false>(m, T, Kv, idx, p);
+        for (const Piece& p : entries) {
           if (p.id < 0) continue;
           int x0, y0, x1, y1;
           piece_pixel_bbox(p, NS, w, h, x0, y0, x1, y1);
