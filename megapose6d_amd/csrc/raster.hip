@@ -198,34 +198,39 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-#ifdef MP_RASTER_PROF   // scripts/microbench build only (never in libmp_engine.so): per-phase shader-cycle totals of raster_tiles
+#ifdef MP_RASTER_PROF   // scripts/microbench build only (never in libmp_engine.so): per-phase shader-cycle totals of raster_tiles,
+// accumulated in registers and flushed once per wave by every 32nd workgroup (so the probe does not perturb what it measures)
 __device__ unsigned long long g_raster_prof[16];
-#define PROF_T0 unsigned long long prof_t = __builtin_readcyclecounter();
-#define PROF(slot)                                                                  \
-  {                                                                                 \
-    const unsigned long long prof_n = __builtin_readcyclecounter();                 \
-    if (lane == 0) atomicAdd(&g_raster_prof[slot], prof_n - prof_t);                \
-    prof_t = prof_n;                                                                \
+#define PROF_T0                                              \
+  unsigned long long prof_t = __builtin_readcyclecounter(); \
+  unsigned long long prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(slot)                                                  \
+  {                                                                 \
+    const unsigned long long prof_n = __builtin_readcyclecounter(); \
+    prof_acc[slot] += prof_n - prof_t;                              \
+    prof_t = prof_n;                                                \
+  }
+#define PROF_FLUSH                                                                  \
+  if (lane == 0 && (blockIdx.x & 31) == 0) {                                        \
+    for (int k = 0; k < 9; ++k) atomicAdd(&g_raster_prof[k], prof_acc[k]);          \
   }
 #else
 #define PROF_T0
 #define PROF(slot)
+#define PROF_FLUSH
 #endif
 
-constexpr int SCATTER_MAX_AREA = 32;  // footprint (pixels of bbox ∩ tile) up to which a lane rasterises its own piece
-
-// ---- coverage form 1: lane-per-piece scatter.  Every lane owns one small piece of the batch and walks the pixels of the piece's
-// bbox inside the tile; covered samples go to the wave's LDS z-buffer with a 64-bit max (key = depth bits | ~piece id). ----------
+// ---- coverage form 1 (every binned record): lane-per-piece scatter.  Each lane owns one piece of the batch and walks the pixels
+// of the piece's bbox inside the tile (<= 64); covered samples go to the wave's LDS z-buffer with a 64-bit max
+// (key = depth bits | ~piece id).  Binned pieces are "small" for their tile, so the 32-bit edge functions apply. -------------------
 template <int NS>
 __device__ __forceinline__ void scatter_piece(const Piece& p, bool active, int x0, int y0, int x1, int y1, int tile_x0, int tile_y0,
                                               unsigned long long* zb) {
   rc::Edges32 e;
   rc::piece_edges32(p, e);
-  const int bw = x1 - x0 + 1;
-  const int n = active ? bw * (y1 - y0 + 1) : 0;
+  const int n = active ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
   int px = x0, py = y0;
-  // all lanes iterate to the largest footprint in the wave (<= SCATTER_MAX_AREA)
-  int n_max = n;
+  int n_max = n;   // all lanes iterate to the largest footprint in the wave
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off));
   for (int k = 0; k < n_max; ++k) {
@@ -242,28 +247,52 @@ __device__ __forceinline__ void scatter_piece(const Piece& p, bool active, int x
   }
 }
 
-// ---- coverage form 2: wave-per-piece sweep for pieces with a large footprint in the tile (or too large for the 32-bit edge
-// functions): the piece is wave-uniform, lane l tests ITS pixel and updates its own z-buffer slots (no conflicts). ---------------
+// ---- coverage form 2 (the view's "large" list and the overflow fallback only): wave-per-piece sweep with the 64-bit edge functions.
+// The piece is wave-uniform, lane l tests ITS pixel and updates its own z-buffer slots (no conflicts). ----------------------------
 template <int NS>
-__device__ __forceinline__ void sweep_piece(const Piece& p, int tile_x0, int tile_y0, int px, int py, int lane, unsigned long long* zb) {
+__device__ __noinline__ void sweep_piece(const Piece& p, int tile_x0, int tile_y0, int px, int py, int lane, unsigned long long* zb) {
   const int Xmin = min(p.X[0], min(p.X[1], p.X[2])), Xmax = max(p.X[0], max(p.X[1], p.X[2]));
   const int Ymin = min(p.Y[0], min(p.Y[1], p.Y[2])), Ymax = max(p.Y[0], max(p.Y[1], p.Y[2]));
   const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
   if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) return;
-  auto emit = [&](int s, float wsum) {
+  rc::Edges e;
+  rc::piece_edges(p, e);
+  rc::cover_pixel64<NS>(p, e, px, py, [&](int s, float wsum) {
     const unsigned long long key = rc::depth_key(wsum, p.id);
     unsigned long long* slot = zb + lane * NS + s;
     if (key > *slot) *slot = key;
-  };
-  if (rc::piece_is_small(p, tile_x0, tile_y0)) {
-    rc::Edges32 e;
-    rc::piece_edges32(p, e);
-    rc::cover_pixel32<NS>(p, e, px, py, emit);
+  });
+}
+
+// roi_align of one output pixel; one instance for the four (C, layout) cases (code size)
+__device__ __noinline__ void crop_lane(const CropArgs& crop, int item, int h, int w, int px, int py, float (&cvals)[4]) {
+  const float* bx = crop.boxes + (size_t)item * 4;
+  const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+  const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
+  const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
+  const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
+  cvals[3] = 0.f;
+  if (crop.nhwc4) {
+    if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+    else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
   } else {
-    rc::Edges e;
-    rc::piece_edges(p, e);
-    rc::cover_pixel64<NS>(p, e, px, py, emit);
+    if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
+    else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
   }
+}
+
+struct ViewHdr {   // what a wave needs to know about one view's lists for its tile (wave-uniform)
+  int begin, n_list, n_large, overflow;
+};
+__device__ __forceinline__ ViewHdr load_view_hdr(const int* __restrict__ ws, const BinLayout& lay, int view, int tile, int n_faces) {
+  const int* hdr = ws + (size_t)view * lay.view_ints;
+  const int* tile_off = hdr + HDR_INTS;
+  ViewHdr v;
+  v.overflow = hdr[2];
+  v.begin = v.overflow ? 0 : tile_off[tile];
+  v.n_list = v.overflow ? 2 * n_faces : tile_off[tile + 1] - v.begin;
+  v.n_large = v.overflow ? 0 : hdr[0];
+  return v;
 }
 
 template <int NS>
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
     float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
     long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop) {
-  // LDS per wave: stage [64][run] floats | zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32
+  // LDS per wave: zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32 | stage [64][run] floats
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t per_wave = (size_t)64 * NS * (sizeof(unsigned long long) + sizeof(unsigned)) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15);
@@ -290,60 +319,78 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   const int tx = gx * TILE_WAVES + wave;
   if (tx >= lay.tiles_x) return;   // (no workgroup-level barrier below: waves are independent)
   const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
+  const int tile = ty * lay.tiles_x + tx;
   const int px = tile_x0 + (lane & 7), py = tile_y0 + (lane >> 3);
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0;
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
-
+  const bool need_shade = c_rgb >= 0 || do_norm;   // a depth-only render (the depth refiner's) has nothing to shade
   PROF_T0
+
+  // Software pipeline over the item's views (memory latency, not arithmetic, bounds this kernel): the list header of view r + 1 and
+  // the first 64 records of view r + 1 are requested before view r is processed.
+  const int view0 = item * views_per_item;
+  ViewHdr hdr_cur = load_view_hdr(ws, lay, view0, tile, meshes[mesh_ids[view0]].n_faces);
+  ViewHdr hdr_nxt = hdr_cur;
+  if (views_per_item > 1) hdr_nxt = load_view_hdr(ws, lay, view0 + 1, tile, meshes[mesh_ids[view0 + 1]].n_faces);
+  rc::TileRec rec_nxt;
+  rec_nxt.id = -1;
+  {
+    const rc::TileRec* list0 = reinterpret_cast<const rc::TileRec*>(ws + (size_t)view0 * lay.view_ints + lay.off_list);
+    if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = list0[hdr_cur.begin + lane];
+  }
   for (int r = 0; r < views_per_item; ++r) {
-    const int view = item * views_per_item + r;
+    const int view = view0 + r;
     const int mesh_id = mesh_ids[view];
     const MeshDev m = meshes[mesh_id];
     const float* T = TCO + (size_t)view * 16;
     const float* Kv = K + (size_t)view * 9;
-    const int* hdr = ws + (size_t)view * lay.view_ints;
-    const int* tile_off = hdr + HDR_INTS;
-    const int* large = hdr + lay.off_large;
-    const rc::TileRec* list = reinterpret_cast<const rc::TileRec*>(hdr + lay.off_list);
-    const int tile = ty * lay.tiles_x + tx;
-    const bool overflow = hdr[2] != 0;
-    const int begin = overflow ? 0 : tile_off[tile];
-    const int n_list = overflow ? 2 * m.n_faces : tile_off[tile + 1] - begin;
-    const int n_large = overflow ? 0 : hdr[0];
-    const int n_total = n_list + n_large;
+    const int* vhdr = ws + (size_t)view * lay.view_ints;
+    const int* large = vhdr + lay.off_large;
+    const rc::TileRec* list = reinterpret_cast<const rc::TileRec*>(vhdr + lay.off_list);
+    const ViewHdr vh = hdr_cur;
+    const rc::TileRec rec_first = rec_nxt;
+    hdr_cur = hdr_nxt;
+    if (r + 1 < views_per_item) {   // prefetch: first records of the next view, header of the one after
+      const rc::TileRec* list_n = reinterpret_cast<const rc::TileRec*>(ws + (size_t)(view + 1) * lay.view_ints + lay.off_list);
+      rec_nxt.id = -1;
+      if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = list_n[hdr_cur.begin + lane];
+      if (r + 2 < views_per_item) hdr_nxt = load_view_hdr(ws, lay, view + 2, tile, meshes[mesh_ids[view + 2]].n_faces);
+    }
+    const int n_total = vh.n_list + vh.n_large;
 #pragma unroll
     for (int s = 0; s < NS; ++s) zb[lane * NS + s] = 0ull;
     wave_lds_fence();
-    // ---- coverage + depth: 64 listed pieces are set up lane-parallel; small footprints are scattered by their own lane, the
-    //      rest is broadcast (v_readlane) and swept by the whole wave ---------------------------------------------------------
+    PROF(0)
+    // ---- coverage + depth -------------------------------------------------------------------------------------------------------
     for (int base = 0; base < n_total; base += 64) {
       const int e = base + lane;
       Piece mine_p;
       mine_p.id = -1;
-      if (e < n_list && !overflow) {           // a binned record: two coalesced 16-byte loads, nothing to recompute
-        const rc::TileRec rec = list[begin + e];
+      bool binned = false;
+      if (e < vh.n_list && !vh.overflow) {     // a binned record: two coalesced 16-byte loads, nothing to recompute
+        const rc::TileRec rec = base == 0 ? rec_first : list[vh.begin + e];
         rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
+        binned = true;
       }
       int idx = -1;
-      if (e < n_list && overflow) idx = e;
-      else if (e >= n_list && e < n_total) idx = large[e - n_list];
-      PROF(0)
-      if (idx >= 0) rc::piece_from_index<false>(m, T, Kv, idx, mine_p);
+      if (e < vh.n_list && vh.overflow) idx = e;
+      else if (e >= vh.n_list && e < n_total) idx = large[e - vh.n_list];
+      if (__ballot(idx >= 0) != 0ull) {         // rare: large pieces / overflow fallback are recomputed from the mesh
+        if (idx >= 0) rc::piece_from_index<true>(m, T, Kv, idx, mine_p);
+      }
+      PROF(1)
       int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-      bool small = false;
       if (mine_p.id >= 0) {
         rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
         x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
-        small = rc::piece_is_small(mine_p, tile_x0, tile_y0);
       }
       const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
-      const bool scat = hit && small && (x1 - x0 + 1) * (y1 - y0 + 1) <= SCATTER_MAX_AREA;
-      PROF(1)
+      const bool scat = hit && binned;
       if (__ballot(scat) != 0ull) scatter_piece<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, zb);
       wave_lds_fence();
       PROF(2)
-      unsigned long long big = __ballot(hit && !scat);
+      unsigned long long big = __ballot(hit && !binned);
       while (big) {
         const int j = __ffsll((long long)big) - 1;
         big &= big - 1ull;
@@ -368,7 +415,6 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     wave_lds_fence();   // zb is reused for the shading results below
     // ---- shading tasks: one per (pixel, distinct winning piece), ordered by (sample, lane) -------------------------------------
     int n_tasks = 0;
-    const bool need_shade = c_rgb >= 0 || do_norm;   // a depth-only render (the depth refiner's) has nothing to shade
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       bool nw = need_shade && st[s].id >= 0;
@@ -425,19 +471,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     PROF(6)
   }
   if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
-    const float* bx = crop.boxes + (size_t)item * 4;
-    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
-    const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
-    const float bin_h = roi_h / (float)h, bin_w = roi_w / (float)w;
-    const float* img = crop.images + (size_t)crop.im_ids[item] * (crop.nhwc4 ? 4 : crop.C) * crop.H * crop.W;
     float cvals[4];
-    if (crop.nhwc4) {
-      if (crop.C == 4) crop_pixel<4, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-      else crop_pixel<3, true>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-    } else {
-      if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-      else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
-    }
+    crop_lane(crop, item, h, w, px, py, cvals);
     my_stage[crop.c0 - c_lo] = cvals[0]; my_stage[crop.c0 + 1 - c_lo] = cvals[1]; my_stage[crop.c0 + 2 - c_lo] = cvals[2];
     if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cvals[3];
   }
@@ -455,6 +490,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = sp[(size_t)row * 8 * run];
   }
   PROF(8)
+  PROF_FLUSH
 }
 
 }  // namespace mp

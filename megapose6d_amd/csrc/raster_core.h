@@ -163,30 +163,37 @@ MP_HD int make_piece(const MeshRef& m, const float* T, const float* Kv, int tri,
   }
   const bool in0 = c0.z >= Z_NEAR, in1 = c1.z >= Z_NEAR, in2 = c2.z >= Z_NEAR;
   const int n_in = (int)in0 + (int)in1 + (int)in2;
-  if (n_in == 3) {
-    if (which == 0) finish_piece<WITH_BARY>(c0, c1, c2, Kv, tri, tri, p);
-    return 1;
-  }
   if (n_in == 0) return 0;
-  // rotate the corners (cyclic order kept) so that r0 is the single inside vertex (n_in == 1) or r2 the single outside one
-  const int k = n_in == 1 ? (in0 ? 0 : (in1 ? 1 : 2)) : (!in0 ? 1 : (!in1 ? 2 : 0));
-  const CVert r0 = sel(k == 0, c0, sel(k == 1, c1, c2));
-  const CVert r1 = sel(k == 0, c1, sel(k == 1, c2, c0));
-  const CVert r2 = sel(k == 0, c2, sel(k == 1, c0, c1));
-  if (n_in == 1) {
-    if (which != 0) return 1;
-    const CVert P = clip_edge(r0, r1), Q = clip_edge(r0, r2);
-    finish_piece<WITH_BARY>(r0, P, Q, Kv, tri, tri, p);
-    return 1;
+  // the piece's three vertices (a, b, c) and its id; ONE finish_piece call at the end (code size: the kernels inline all of this)
+  CVert a = c0, b = c1, c = c2;
+  int id = tri, n_pieces = 1;
+  bool exists = which == 0;
+  if (n_in != 3) {
+    // rotate the corners (cyclic order kept) so that r0 is the single inside vertex (n_in == 1) or r2 the single outside one
+    const int k = n_in == 1 ? (in0 ? 0 : (in1 ? 1 : 2)) : (!in0 ? 1 : (!in1 ? 2 : 0));
+    const CVert r0 = sel(k == 0, c0, sel(k == 1, c1, c2));
+    const CVert r1 = sel(k == 0, c1, sel(k == 1, c2, c0));
+    const CVert r2 = sel(k == 0, c2, sel(k == 1, c0, c1));
+    a = r0;
+    if (n_in == 1) {
+      b = clip_edge(r0, r1);
+      c = clip_edge(r0, r2);
+    } else {
+      n_pieces = 2;
+      exists = true;
+      const CVert P = clip_edge(r1, r2);
+      if (which == 0) {
+        b = r1;
+        c = P;
+      } else {
+        b = P;
+        c = clip_edge(r0, r2);
+        id = m.n_faces + tri;
+      }
+    }
   }
-  const CVert P = clip_edge(r1, r2);
-  if (which == 0) {
-    finish_piece<WITH_BARY>(r0, r1, P, Kv, tri, tri, p);
-  } else {
-    const CVert Q = clip_edge(r0, r2);
-    finish_piece<WITH_BARY>(r0, P, Q, Kv, tri, m.n_faces + tri, p);
-  }
-  return 2;
+  if (exists) finish_piece<WITH_BARY>(a, b, c, Kv, tri, id, p);
+  return n_pieces;
 }
 
 // piece index space of a view: [0, F) first pieces, [F, 2F) second pieces

@@ -7,6 +7,8 @@ import pandas as pd
 import pytest
 import torch
 
+from conftest import assert_logits_close  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -69,7 +71,7 @@ def test_multi_frame_multi_instance_vs_oracle(multi_scene):
     res = _oracle(tmp, ds).run(obs.images.cpu(), obs.K.cpu(), infos, det.bboxes.cpu(), n_refiner_iterations=2, n_pose_hypotheses=2)
     lg = extra["coarse"]["data"]["logits"].flatten().cpu()
     scale = max(1.0, res["coarse_logits"].abs().max().item())
-    assert (lg - res["coarse_logits"]).abs().max().item() < 1e-4 * scale
+    assert_logits_close(lg.numpy(), res["coarse_logits"].numpy(), scale)
     key = lambda df: list(zip(df["batch_im_id"], df["label"], df["instance_id"], df["hypothesis_id"]))
     got_f = extra["coarse_filter"]["preds"]
     assert sorted(key(got_f.infos)) == sorted(key(res["filtered_infos"]))

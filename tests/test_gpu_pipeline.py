@@ -9,6 +9,8 @@ import pandas as pd
 import pytest
 import torch
 
+from conftest import assert_logits_close  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -42,7 +44,7 @@ def test_pipeline_matches_reference_golden(scene72):
     assert np.abs(cd["preds"].poses.cpu().numpy() - g["coarse_TCO"]).max() < 1e-5
     lg = cd["data"]["logits"].cpu().numpy().flatten()
     scale = max(1.0, float(np.abs(g["coarse_logits"]).max()))
-    assert np.abs(lg - g["coarse_logits"].flatten()).max() < 1e-4 * scale
+    assert_logits_close(lg, g["coarse_logits"], scale)
     hyp = extra["coarse_filter"]["preds"].infos["hypothesis_id"].tolist()
     assert sorted(hyp) == sorted(g["filtered_hyp_ids"].tolist())
     order = [hyp.index(h) for h in g["filtered_hyp_ids"].tolist()]
@@ -53,7 +55,7 @@ def test_pipeline_matches_reference_golden(scene72):
         assert (np.abs(kc - kg) / np.maximum(np.abs(kg), 1)).max() < 1e-4
         assert np.abs(p.boxes_crop.cpu().numpy()[order] - g[f"refiner_boxes_crop_{n}"]).max() < 0.05
     sl = extra["scoring"]["data"]["logits"].cpu().numpy().flatten()[order]
-    assert np.abs(sl - g["scoring_logits"].flatten()).max() < 1e-4 * scale
+    assert_logits_close(sl, g["scoring_logits"], scale)
     assert np.abs(final.poses.cpu().numpy() - g["final_TCO"]).max() < 1e-4
     # API surface
     assert list(final.infos.columns) == g["final_columns"].tolist()
@@ -179,7 +181,7 @@ def test_rgbd_and_wide_resnet_pipeline_vs_oracle():
     res = oest.run(obs.images.cpu(), obs.K.cpu(), det.infos.copy(), det.bboxes.cpu(), n_refiner_iterations=2, n_pose_hypotheses=1)
     lg = extra["coarse"]["data"]["logits"].flatten().cpu()
     scale = max(1.0, res["coarse_logits"].abs().max().item())
-    assert (lg - res["coarse_logits"]).abs().max().item() < 1e-4 * scale
+    assert_logits_close(lg.numpy(), res["coarse_logits"].numpy(), scale)
     assert extra["coarse_filter"]["preds"].infos["hypothesis_id"].tolist() == res["filtered_infos"]["hypothesis_id"].tolist()
     for n in range(2):
         p = extra["refiner_all_hypotheses"]["preds"][f"iteration={n + 1}"].poses.cpu()
@@ -257,7 +259,7 @@ def test_pipeline_split_precision_modes_match_reference_golden(precision):
     final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=3, n_pose_hypotheses=2)
     scale = max(1.0, float(np.abs(g["coarse_logits"]).max()))
     lg = extra["coarse"]["data"]["logits"].cpu().numpy().flatten()
-    assert np.abs(lg - g["coarse_logits"].flatten()).max() < 1e-4 * scale
+    assert_logits_close(lg, g["coarse_logits"], scale)
     hyp = extra["coarse_filter"]["preds"].infos["hypothesis_id"].tolist()
     assert sorted(hyp) == sorted(g["filtered_hyp_ids"].tolist())
     order = [hyp.index(h) for h in g["filtered_hyp_ids"].tolist()]
