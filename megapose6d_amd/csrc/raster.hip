@@ -40,6 +40,9 @@ typedef rc::MeshRef MeshDev;
 typedef rc::TexRef TexDev;
 typedef rc::Lights LightsDev;
 
+#ifndef MP_RASTER_WAVES
+#define MP_RASTER_WAVES 4   // waves per SIMD the tile kernel is compiled for (register budget 512 / MP_RASTER_WAVES)
+#endif
 constexpr int BIN_THREADS = 512;
 constexpr int LARGE_TILES = 16;    // a piece whose bbox touches more tiles is not replicated into tile lists
 constexpr int TILE_WAVES = 4;      // tiles (waves) per workgroup of raster_tiles: a 32 x 8 pixel strip
@@ -220,29 +223,70 @@ __device__ unsigned long long g_raster_prof[16];
 #define PROF_FLUSH
 #endif
 
-// ---- coverage form 1 (every binned record): lane-per-piece scatter.  Each lane owns one piece of the batch and walks the pixels
-// of the piece's bbox inside the tile (<= 64); covered samples go to the wave's LDS z-buffer with a 64-bit max
-// (key = depth bits | ~piece id).  Binned pieces are "small" for their tile, so the 32-bit edge functions apply. -------------------
+// ---- coverage form 1 (every binned record): load-balanced scatter.  The batch's <= 64 pieces sit one per lane with their edge
+// set-up in registers; the work items are the (piece, pixel of the piece's bbox inside the tile) pairs, numbered piece-major and
+// dealt round-robin to the 64 lanes, so a wave needs ceil(sum of footprints / 64) rounds however uneven the footprints are (a tile
+// list typically holds ~20 pieces of ~6 pixels: 2 rounds instead of 16+ with one piece per lane).  A lane finds the piece of its
+// item by binary search over the footprint prefix sums and fetches the piece's registers from its owner lane (ds_bpermute); covered
+// samples go to the wave's LDS z-buffer with a 64-bit max (key = depth bits | ~piece id).  Binned pieces are "small" for their
+// tile, so the 32-bit edge functions apply. ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src); }
+
 template <int NS>
-__device__ __forceinline__ void scatter_piece(const Piece& p, bool active, int x0, int y0, int x1, int y1, int tile_x0, int tile_y0,
-                                              unsigned long long* zb) {
+__device__ __forceinline__ void scatter_batch(const Piece& p, bool active, int x0, int y0, int x1, int y1, int tile_x0, int tile_y0,
+                                              int lane, unsigned long long* zb) {
   rc::Edges32 e;
   rc::piece_edges32(p, e);
-  const int n = active ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
-  int px = x0, py = y0;
-  int n_max = n;   // all lanes iterate to the largest footprint in the wave
+  const int bw = x1 - x0 + 1;
+  const int n = active ? bw * (y1 - y0 + 1) : 0;
+  // inclusive prefix sum of the footprints over the lanes
+  int incl = n;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off));
-  for (int k = 0; k < n_max; ++k) {
-    if (k < n) {
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int total = __shfl(incl, 63);
+  const int excl = incl - n;
+  const int thr_bits = e.thr[0] | (e.thr[1] << 1) | (e.thr[2] << 2);
+  const int box = x0 | (y0 << 12) | (bw << 24);   // pixel coordinates < 1024 (launch check), bw <= 8
+  for (int t = lane; t - lane < total; t += 64) {   // uniform trip count: every lane runs the shuffles of every round
+    const bool live = t < total;
+    const int tt = live ? t : 0;
+    // owner j = first lane whose inclusive sum exceeds the item number
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+      const int mid = (lo + hi) >> 1;
+      const int pm = shfl_i(incl, mid);
+      if (pm > tt) hi = mid; else lo = mid + 1;
+    }
+    const int j = lo;
+    Piece q;
+    rc::Edges32 f;
+    const int k = tt - shfl_i(excl, j);
+    const int qbox = shfl_i(box, j);
+    const int tb = shfl_i(thr_bits, j);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f.dx[i] = shfl_i(e.dx[i], j); f.dy[i] = shfl_i(e.dy[i], j);
+      f.ax[i] = shfl_i(e.ax[i], j); f.ay[i] = shfl_i(e.ay[i], j);
+      f.thr[i] = (tb >> i) & 1;
+      q.iz[i] = shfl_f(p.iz[i], j);
+    }
+    f.inv_area = shfl_f(e.inv_area, j);
+    q.id = shfl_i(p.id, j);
+    if (live) {
+      const int qx0 = qbox & 0xFFF, qy0 = (qbox >> 12) & 0xFFF, qbw = qbox >> 24;
+      const int row = (k * ((1024 + qbw - 1) / qbw)) >> 10;   // k / qbw for k < 64, qbw <= 8 (exact; checked exhaustively)
+      const int px = qx0 + (k - row * qbw), py = qy0 + row;
       const int local = ((py - tile_y0) << 3) | (px - tile_x0);
-      rc::cover_pixel32<NS>(p, e, px, py, [&](int s, float wsum) {
-        const unsigned long long key = rc::depth_key(wsum, p.id);
+      rc::cover_pixel32<NS>(q, f, px, py, [&](int s, float wsum) {
+        const unsigned long long key = rc::depth_key(wsum, q.id);
         unsigned long long* slot = zb + local * NS + s;
         if (key > *slot) atomicMax(slot, key);   // the plain read only skips atomics that cannot win (values only grow)
       });
-      ++px;
-      if (px > x1) { px = x0; ++py; }
     }
   }
 }
@@ -296,7 +340,7 @@ __device__ __forceinline__ ViewHdr load_view_hdr(const int* __restrict__ ws, con
 }
 
 template <int NS>
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_tiles(
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(MP_RASTER_WAVES, MP_RASTER_WAVES))) void raster_tiles(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
     float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
@@ -387,7 +431,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       }
       const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
       const bool scat = hit && binned;
-      if (__ballot(scat) != 0ull) scatter_piece<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, zb);
+      if (__ballot(scat) != 0ull) scatter_batch<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, lane, zb);
       wave_lds_fence();
       PROF(2)
       unsigned long long big = __ballot(hit && !binned);
