@@ -196,8 +196,12 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+// Intra-wave LDS hand-off: the LDS unit executes one wave's DS operations in issue order, so all that is needed for lane A's write
+// to be seen by lane B's later read is that the compiler keeps the program order (the asm is a compiler barrier) and that pending DS
+// results have landed.  Unlike a workgroup-scope fence this does NOT wait for vmcnt: global loads issued as prefetches for the next
+// view stay in flight across it.
 __device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // s_waitcnt lgkmcnt(0): this wave's LDS writes are visible to its own lanes
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -432,9 +436,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
       const bool scat = hit && binned;
       if (__ballot(scat) != 0ull) scatter_batch<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, lane, zb);
-      wave_lds_fence();
       PROF(2)
       unsigned long long big = __ballot(hit && !binned);
+      if (big) wave_lds_fence();   // the sweep form reads and rewrites z-buffer slots the scatter may have just updated
       while (big) {
         const int j = __ffsll((long long)big) - 1;
         big &= big - 1ull;
