@@ -194,6 +194,19 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
   }
 }
 
+// a TileRec as two 16-byte loads (a struct copy is split into six ushort + four dword loads by the compiler)
+__device__ __forceinline__ rc::TileRec load_tile_rec(const rc::TileRec* __restrict__ p) {
+  const int4 a = reinterpret_cast<const int4*>(p)[0], b = reinterpret_cast<const int4*>(p)[1];
+  rc::TileRec r;
+  r.rx0 = (short)(a.x & 0xFFFF); r.ry0 = (short)(a.x >> 16);
+  r.rx1 = (short)(a.y & 0xFFFF); r.ry1 = (short)(a.y >> 16);
+  r.rx2 = (short)(a.z & 0xFFFF); r.ry2 = (short)(a.z >> 16);
+  r.pad0 = r.pad1 = 0;
+  r.iz0 = __int_as_float(b.x); r.iz1 = __int_as_float(b.y); r.iz2 = __int_as_float(b.z);
+  r.id = b.w;
+  return r;
+}
+
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 // Intra-wave LDS hand-off: the LDS unit executes one wave's DS operations in issue order, so all that is needed for lane A's write
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   rec_nxt.id = -1;
   {
     const rc::TileRec* list0 = reinterpret_cast<const rc::TileRec*>(ws + (size_t)view0 * lay.view_ints + lay.off_list);
-    if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = list0[hdr_cur.begin + lane];
+    if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = load_tile_rec(list0 + hdr_cur.begin + lane);
   }
   for (int r = 0; r < views_per_item; ++r) {
     const int view = view0 + r;
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     if (r + 1 < views_per_item) {   // prefetch: first records of the next view, header of the one after
       const rc::TileRec* list_n = reinterpret_cast<const rc::TileRec*>(ws + (size_t)(view + 1) * lay.view_ints + lay.off_list);
       rec_nxt.id = -1;
-      if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = list_n[hdr_cur.begin + lane];
+      if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = load_tile_rec(list_n + hdr_cur.begin + lane);
       if (r + 2 < views_per_item) hdr_nxt = load_view_hdr(ws, lay, view + 2, tile, meshes[mesh_ids[view + 2]].n_faces);
     }
     const int n_total = vh.n_list + vh.n_large;
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       mine_p.id = -1;
       bool binned = false;
       if (e < vh.n_list && !vh.overflow) {     // a binned record: two coalesced 16-byte loads, nothing to recompute
-        const rc::TileRec rec = base == 0 ? rec_first : list[vh.begin + e];
+        const rc::TileRec rec = base == 0 ? rec_first : load_tile_rec(list + vh.begin + e);
         rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
         binned = true;
       }
