@@ -252,7 +252,7 @@ __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src
 
 template <int NS>
 __device__ __forceinline__ void scatter_batch(const Piece& p, bool active, int x0, int y0, int x1, int y1, int tile_x0, int tile_y0,
-                                              int lane, unsigned long long* zb) {
+                                              int lane, int slot_base, unsigned long long* zb) {
   rc::Edges32 e;
   rc::piece_edges32(p, e);
   const int bw = x1 - x0 + 1;
@@ -299,8 +299,9 @@ __device__ __forceinline__ void scatter_batch(const Piece& p, bool active, int x
       const int row = (k * ((1024 + qbw - 1) / qbw)) >> 10;   // k / qbw for k < 64, qbw <= 8 (exact; checked exhaustively)
       const int px = qx0 + (k - row * qbw), py = qy0 + row;
       const int local = ((py - tile_y0) << 3) | (px - tile_x0);
+      const int qslot = min(slot_base + j, rc::SLOT_NONE);   // the owner's position in the tile's record list
       rc::cover_pixel32<NS>(q, f, px, py, [&](int s, float wsum) {
-        const unsigned long long key = rc::depth_key(wsum, q.id);
+        const unsigned long long key = rc::depth_key(wsum, q.id, qslot);
         unsigned long long* slot = zb + local * NS + s;
         if (key > *slot) atomicMax(slot, key);   // the plain read only skips atomics that cannot win (values only grow)
       });
@@ -319,7 +320,7 @@ __device__ __noinline__ void sweep_piece(const Piece& p, int tile_x0, int tile_y
   rc::Edges e;
   rc::piece_edges(p, e);
   rc::cover_pixel64<NS>(p, e, px, py, [&](int s, float wsum) {
-    const unsigned long long key = rc::depth_key(wsum, p.id);
+    const unsigned long long key = rc::depth_key(wsum, p.id, rc::SLOT_NONE);
     unsigned long long* slot = zb + lane * NS + s;
     if (key > *slot) *slot = key;
   });
@@ -419,6 +420,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       if (r + 2 < views_per_item) hdr_nxt = load_view_hdr(ws, lay, view + 2, tile, meshes[mesh_ids[view + 2]].n_faces);
     }
     const int n_total = vh.n_list + vh.n_large;
+    const long long cv = (long long)r * stride_view;
+    if (n_total == 0) {   // nothing of this view reaches the tile (most tiles of a crop): background
+      if (c_rgb >= 0) { my_stage[c_rgb + cv - c_lo] = 0.f; my_stage[c_rgb + cv + 1 - c_lo] = 0.f; my_stage[c_rgb + cv + 2 - c_lo] = 0.f; }
+      if (do_norm) { my_stage[c_normals + cv - c_lo] = 0.f; my_stage[c_normals + cv + 1 - c_lo] = 0.f; my_stage[c_normals + cv + 2 - c_lo] = 0.f; }
+      if (do_depth) my_stage[c_depth + cv - c_lo] = 0.f;
+      PROF(0)
+      continue;
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) zb[lane * NS + s] = 0ull;
     wave_lds_fence();
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       }
       const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
       const bool scat = hit && binned;
-      if (__ballot(scat) != 0ull) scatter_batch<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, lane, zb);
+      if (__ballot(scat) != 0ull) scatter_batch<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, lane, base, zb);
       PROF(2)
       unsigned long long big = __ballot(hit && !binned);
       if (big) wave_lds_fence();   // the sweep form reads and rewrites z-buffer slots the scatter may have just updated
@@ -467,11 +476,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       PROF(3)
     }
     Sample st[NS];
+    int st_slot[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const unsigned long long key = zb[lane * NS + s];
       st[s].wsum = rc::key_wsum(key);
       st[s].id = rc::key_id(key);
+      st_slot[s] = rc::key_slot(key);
     }
     wave_lds_fence();   // zb is reused for the shading results below
     // ---- shading tasks: one per (pixel, distinct winning piece), ordered by (sample, lane) -------------------------------------
@@ -482,7 +493,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int k = 0; k < s; ++k) nw = nw && !(st[k].id == st[s].id);
       const unsigned long long mask = __ballot(nw);
-      if (nw) tasks[n_tasks + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned)st[s].id << 8) | ((unsigned)s << 6) | (unsigned)lane;
+      // task word: lane | sample << 6 | (bit 31 set: record slot << 8) or (bit 31 clear: piece id << 8, for pieces without a record)
+      if (nw) tasks[n_tasks + __popcll(mask & ((1ull << lane) - 1ull))] =
+          (unsigned)lane | ((unsigned)s << 6) | (st_slot[s] != rc::SLOT_NONE ? (0x80000000u | ((unsigned)st_slot[s] << 8)) : ((unsigned)st[s].id << 8));
       n_tasks += __popcll(mask);
     }
     wave_lds_fence();
@@ -492,9 +505,17 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       const int k = k0 + lane;
       if (k < n_tasks) {
         const unsigned tk = tasks[k];
-        const int tl = tk & 63, ts = (tk >> 6) & 3, id = (int)(tk >> 8);
+        const int tl = tk & 63, ts = (tk >> 6) & 3;
+        int id = (int)((tk >> 8) & 0x7FFFFFu);
         Piece pf;
-        rc::piece_from_index<true>(m, T, Kv, id, pf);
+        pf.flags = 2;
+        if (tk & 0x80000000u) {   // the winner is a binned record: re-read it (L2-hot) instead of re-deriving the piece
+          rc::unpack_tile_rec(load_tile_rec(list + vh.begin + (int)((tk >> 8) & 511u)), tile_x0, tile_y0, pf);
+          id = pf.id;
+          pf.tri = id < m.n_faces ? id : id - m.n_faces;
+          rc::piece_bary_from_flags(pf);
+        }
+        if (pf.flags & 2) rc::piece_from_index<true>(m, T, Kv, id, pf);   // clipped pieces (their bary rows are not in the record), large-list pieces
         float c255[3], n255[3];
         rc::shade(m, tex, lights, T, gl_eye, do_norm, pf, tile_x0 + (tl & 7), tile_y0 + (tl >> 3), c255, n255);
         uint2 q;
@@ -518,7 +539,6 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       acc[0] += (float)(q.x & 255u); acc[1] += (float)((q.x >> 8) & 255u); acc[2] += (float)((q.x >> 16) & 255u);
       acc[3] += (float)(q.y & 255u); acc[4] += (float)((q.y >> 8) & 255u); acc[5] += (float)((q.y >> 16) & 255u);
     }
-    const long long cv = (long long)r * stride_view;
     if (c_rgb >= 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) my_stage[c_rgb + cv + c - c_lo] = rc::resolve_channel(acc[c], NS, false);

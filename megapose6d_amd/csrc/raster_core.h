@@ -69,10 +69,19 @@ struct Lights {
 struct Piece {
   int X[3], Y[3];
   float iz[3];
-  int id;   // < 0: no piece
+  int id;     // < 0: no piece
   int tri;
+  int flags;  // bit 0: vertices 1 and 2 were exchanged (negative screen orientation); bit 1: the piece was clipped
   float bary[3][3];
 };
+
+// bary rows of an UNCLIPPED piece: the permutation its orientation swap applied to the corners
+MP_HD void piece_bary_from_flags(Piece& p) {
+  const bool swap = (p.flags & 1) != 0;
+  p.bary[0][0] = 1.f; p.bary[0][1] = 0.f; p.bary[0][2] = 0.f;
+  p.bary[1][0] = 0.f; p.bary[1][1] = swap ? 0.f : 1.f; p.bary[1][2] = swap ? 1.f : 0.f;
+  p.bary[2][0] = 0.f; p.bary[2][1] = swap ? 1.f : 0.f; p.bary[2][2] = swap ? 0.f : 1.f;
+}
 
 MP_HD int imin(int a, int b) { return a < b ? a : b; }
 MP_HD int imax(int a, int b) { return a > b ? a : b; }
@@ -107,9 +116,10 @@ MP_HD CVert sel(bool c, const CVert& a, const CVert& b) {  // c ? a : b, field b
 
 // project + snap + orient; id < 0 on rejection
 template <bool WITH_BARY>
-MP_HD void finish_piece(const CVert& v0, const CVert& v1, const CVert& v2, const float* Kv, int tri, int id, Piece& p) {
+MP_HD void finish_piece(const CVert& v0, const CVert& v1, const CVert& v2, const float* Kv, int tri, int id, bool clipped, Piece& p) {
   p.id = -1;
   p.tri = tri;
+  p.flags = 0;
   const float iz0 = 1.0f / v0.z, iz1 = 1.0f / v1.z, iz2 = 1.0f / v2.z;
   const float sx0 = fmaf(Kv[0], v0.x * iz0, Kv[2]), sy0 = fmaf(Kv[4], v0.y * iz0, Kv[5]);
   const float sx1 = fmaf(Kv[0], v1.x * iz1, Kv[2]), sy1 = fmaf(Kv[4], v1.y * iz1, Kv[5]);
@@ -135,6 +145,7 @@ MP_HD void finish_piece(const CVert& v0, const CVert& v1, const CVert& v2, const
     }
   }
   p.id = id;
+  p.flags = (swap ? 1 : 0) | (clipped ? 2 : 0);
 }
 
 // Piece `which` (0 = first, 1 = second) of triangle `tri` under pose T / intrinsics Kv.  Stateless: the binning pass, the
@@ -145,6 +156,7 @@ template <bool WITH_BARY>
 MP_HD int make_piece(const MeshRef& m, const float* T, const float* Kv, int tri, int which, Piece& p) {
   p.id = -1;
   p.tri = tri;
+  p.flags = 0;
   CVert c0, c1, c2;
   {
     const int v0 = m.faces[3 * tri], v1 = m.faces[3 * tri + 1], v2 = m.faces[3 * tri + 2];
@@ -192,7 +204,7 @@ MP_HD int make_piece(const MeshRef& m, const float* T, const float* Kv, int tri,
       }
     }
   }
-  if (exists) finish_piece<WITH_BARY>(a, b, c, Kv, tri, id, p);
+  if (exists) finish_piece<WITH_BARY>(a, b, c, Kv, tri, id, n_in != 3, p);
   return n_pieces;
 }
 
@@ -279,7 +291,8 @@ MP_HD TileRec pack_tile_rec(const Piece& p, int tile_x0, int tile_y0) {
   r.rx0 = (short)(p.X[0] - ox); r.ry0 = (short)(p.Y[0] - oy);
   r.rx1 = (short)(p.X[1] - ox); r.ry1 = (short)(p.Y[1] - oy);
   r.rx2 = (short)(p.X[2] - ox); r.ry2 = (short)(p.Y[2] - oy);
-  r.pad0 = r.pad1 = 0;
+  r.pad0 = (short)p.flags;   // orientation swap / clipped: what the shading pass needs to map piece vertices to corners
+  r.pad1 = 0;
   r.iz0 = p.iz[0]; r.iz1 = p.iz[1]; r.iz2 = p.iz[2];
   r.id = p.id;
   return r;
@@ -292,7 +305,8 @@ MP_HD void unpack_tile_rec(const TileRec& r, int tile_x0, int tile_y0, Piece& p)
   p.X[2] = ox + r.rx2; p.Y[2] = oy + r.ry2;
   p.iz[0] = r.iz0; p.iz[1] = r.iz1; p.iz[2] = r.iz2;
   p.id = r.id;
-  p.tri = -1;
+  p.tri = -1;   // the caller derives it from the id (first piece: id, second: id - n_faces)
+  p.flags = r.pad0;
 }
 
 struct Sample {
@@ -401,11 +415,15 @@ MP_HD void cover_pixel64(const Piece& p, const Edges& e, int px, int py, Emit&& 
 }
 
 // 64-bit z-buffer key of a covered sample: larger wsum (nearer) wins, equal depth -> lower piece id wins; 0 = empty.
-// (wsum > 0 inside the depth range, so its bit pattern orders like the value)
-MP_HD unsigned long long depth_key(float wsum, int id) {
+// (wsum > 0 inside the depth range, so its bit pattern orders like the value.)  Layout: [63:32] wsum bits, [31:9] 0x7FFFFF - id
+// (ids < 2^23: meshes have < 2^22 faces), [8:0] the piece's position in the tile's record list (SLOT_NONE = not a binned record):
+// the shading pass re-reads that record instead of re-deriving the piece from the mesh.  The slot never decides a comparison
+// (equal depth and id = same piece = same slot).
+constexpr int SLOT_NONE = 511;
+MP_HD unsigned long long depth_key(float wsum, int id, int slot) {
   uint32_t wb;
   memcpy(&wb, &wsum, 4);
-  return ((unsigned long long)wb << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+  return ((unsigned long long)wb << 32) | ((unsigned long long)(0x7FFFFFu - (uint32_t)id) << 9) | (unsigned long long)(uint32_t)slot;
 }
 MP_HD float key_wsum(unsigned long long key) {
   const uint32_t wb = (uint32_t)(key >> 32);
@@ -413,9 +431,9 @@ MP_HD float key_wsum(unsigned long long key) {
   memcpy(&f, &wb, 4);
   return f;
 }
-MP_HD int key_id(unsigned long long key) { return key ? (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu)) : -1; }
+MP_HD int key_id(unsigned long long key) { return key ? (int)(0x7FFFFFu - (uint32_t)((key >> 9) & 0x7FFFFFu)) : -1; }
+MP_HD int key_slot(unsigned long long key) { return (int)(key & 511u); }
 
-// One piece against the NS samples of pixel (px, py) of the tile at (tile_x0, tile_y0): coverage, depth range, depth test.
 template <int NS>
 MP_HD void cover_lane(const Piece& p, int tile_x0, int tile_y0, int px, int py, Sample (&st)[NS]) {
   if (piece_is_small(p, tile_x0, tile_y0)) {
@@ -499,10 +517,29 @@ MP_HD float pv_attr(const Piece& p, int k, const float* attr, int i0, int i1, in
 // LUT values on the 0..255 scale.  (Barycentrics are extrapolated when the centre lies outside the piece.)
 MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const float* T, bool gl_eye, bool want_normals, const Piece& p,
                  int px, int py, float col255[3], float nrm255[3]) {
-  Edges e;
-  piece_edges(p, e);
-  float b[3], wsum;
-  (void)eval_at(p, e, (long long)px * SUBPIX + 128, (long long)py * SUBPIX + 128, b, wsum);
+  // barycentrics at the pixel centre and the edge slopes (for the texture derivatives): the 32-bit form for a piece that is small
+  // for the pixel's tile (the same integers as the 64-bit form, at a fifth of the instructions)
+  float b[3], wsum, inv_area;
+  long long eA[3], eB[3];
+  if (piece_is_small(p, px & ~(TILE - 1), py & ~(TILE - 1))) {
+    Edges32 e;
+    piece_edges32(p, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      b[i] = (float)edge32(e, i, px * SUBPIX + 128, py * SUBPIX + 128) * e.inv_area;
+      eA[i] = -(long long)e.dy[i];
+      eB[i] = (long long)e.dx[i];
+    }
+    inv_area = e.inv_area;
+    wsum = fmaf(b[2], p.iz[2], fmaf(b[1], p.iz[1], b[0] * p.iz[0]));
+  } else {
+    Edges e;
+    piece_edges(p, e);
+    (void)eval_at(p, e, (long long)px * SUBPIX + 128, (long long)py * SUBPIX + 128, b, wsum);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { eA[i] = e.A[i]; eB[i] = e.B[i]; }
+    inv_area = e.inv_area;
+  }
   const float w0 = b[0] * p.iz[0], w1 = b[1] * p.iz[1], w2 = b[2] * p.iz[2];
   const float z = 1.0f / wsum;
   const int i0 = m.faces[3 * p.tri], i1 = m.faces[3 * p.tri + 1], i2 = m.faces[3 * p.tri + 2];
@@ -525,8 +562,8 @@ MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const flo
     float dbx[3], dby[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      dbx[i] = (float)(e.A[i] * 256) * e.inv_area * p.iz[i];
-      dby[i] = (float)(e.B[i] * 256) * e.inv_area * p.iz[i];
+      dbx[i] = (float)(eA[i] * 256) * inv_area * p.iz[i];
+      dby[i] = (float)(eB[i] * 256) * inv_area * p.iz[i];
     }
     const float dDx = dbx[2] + (dbx[1] + dbx[0]), dDy = dby[2] + (dby[1] + dby[0]);
     const float dNux = fmaf(dbx[2], pu[2], fmaf(dbx[1], pu[1], dbx[0] * pu[0])), dNuy = fmaf(dby[2], pu[2], fmaf(dby[1], pu[1], dby[0] * pu[0]));

@@ -127,27 +127,36 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
         unsigned long long zb[64 * NS];
         for (int i = 0; i < 64 * NS; ++i) zb[i] = 0ull;
         std::vector<Piece> entries;   // binned records first (unpacked relative to THIS tile), then the recomputed large pieces
+        std::vector<int> slots;       // position in the tile's record list (SLOT_NONE for recomputed pieces), as carried by the keys
         if (L.overflow) {
-          for (int i = 0; i < 2 * m.n_faces; ++i) { Piece q; piece_from_index<false>(m, T, Kv, i, q); entries.push_back(q); }
+          for (int i = 0; i < 2 * m.n_faces; ++i) { Piece q; piece_from_index<true>(m, T, Kv, i, q); entries.push_back(q); slots.push_back(SLOT_NONE); }
         } else {
-          for (int e = L.tile_off[tile]; e < L.tile_off[tile + 1]; ++e) { Piece q; unpack_tile_rec(L.list[e], tile_x0, tile_y0, q); entries.push_back(q); }
-          for (int idx : L.large) { Piece q; piece_from_index<false>(m, T, Kv, idx, q); entries.push_back(q); }
+          for (int e = L.tile_off[tile]; e < L.tile_off[tile + 1]; ++e) {
+            Piece q;
+            unpack_tile_rec(L.list[e], tile_x0, tile_y0, q);
+            entries.push_back(q);
+            slots.push_back(imin(e - L.tile_off[tile], SLOT_NONE));
+          }
+          for (int idx : L.large) { Piece q; piece_from_index<true>(m, T, Kv, idx, q); entries.push_back(q); slots.push_back(SLOT_NONE); }
         }
-        for (const Piece& p : entries) {
+        for (size_t ei = 0; ei < entries.size(); ++ei) {
+          const Piece& p = entries[ei];
+          const int pslot = slots[ei];
+          const bool binned = !L.overflow && (int)ei < L.tile_off[tile + 1] - L.tile_off[tile];
           if (p.id < 0) continue;
           int x0, y0, x1, y1;
           piece_pixel_bbox(p, NS, w, h, x0, y0, x1, y1);
           x0 = imax(x0, tile_x0); y0 = imax(y0, tile_y0); x1 = imin(x1, tile_x0 + TILE - 1); y1 = imin(y1, tile_y0 + TILE - 1);
           if (x0 > x1 || y0 > y1) continue;
           const bool small = piece_is_small(p, tile_x0, tile_y0);
-          if (small && (x1 - x0 + 1) * (y1 - y0 + 1) <= SCATTER_MAX_AREA) {   // scatter form
+          if (binned) {   // scatter form (every binned record)
             Edges32 e;
             piece_edges32(p, e);
             for (int py = y0; py <= y1; ++py)
               for (int px = x0; px <= x1; ++px) {
                 const int local = ((py - tile_y0) << 3) | (px - tile_x0);
                 cover_pixel32<NS>(p, e, px, py, [&](int s, float wsum) {
-                  const unsigned long long key = depth_key(wsum, p.id);
+                  const unsigned long long key = depth_key(wsum, p.id, pslot);
                   if (key > zb[local * NS + s]) zb[local * NS + s] = key;
                 });
               }
@@ -158,7 +167,7 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
             if (Xmax < sx0 || Xmin >= sx0 + TILE * SUBPIX || Ymax < sy0 || Ymin >= sy0 + TILE * SUBPIX) continue;
             for (int l = 0; l < 64; ++l) {
               auto emit = [&](int s, float wsum) {
-                const unsigned long long key = depth_key(wsum, p.id);
+                const unsigned long long key = depth_key(wsum, p.id, SLOT_NONE);
                 if (key > zb[l * NS + s]) zb[l * NS + s] = key;
               };
               if (small) {
@@ -174,8 +183,9 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
           }
         }
         Sample st[64][NS];
+        int st_slot[64][NS];
         for (int l = 0; l < 64; ++l)
-          for (int s = 0; s < NS; ++s) { st[l][s].wsum = key_wsum(zb[l * NS + s]); st[l][s].id = key_id(zb[l * NS + s]); }
+          for (int s = 0; s < NS; ++s) { st[l][s].wsum = key_wsum(zb[l * NS + s]); st[l][s].id = key_id(zb[l * NS + s]); st_slot[l][s] = key_slot(zb[l * NS + s]); }
         // tasks + shading + resolve
         for (int l = 0; l < 64; ++l) {
           const int px = tile_x0 + (l & 7), py = tile_y0 + (l >> 3);
@@ -189,7 +199,13 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
               if (st[l][k].id == st[l][s].id) src = k;
             if (src == s) {
               Piece pf;
-              piece_from_index<true>(m, T, Kv, st[l][s].id, pf);
+              pf.flags = 2;
+              if (st_slot[l][s] != SLOT_NONE) {   // shade from the binned record, as the kernel does
+                unpack_tile_rec(L.list[L.tile_off[tile] + st_slot[l][s]], tile_x0, tile_y0, pf);
+                pf.tri = pf.id < m.n_faces ? pf.id : pf.id - m.n_faces;
+                piece_bary_from_flags(pf);
+              }
+              if (pf.flags & 2) piece_from_index<true>(m, T, Kv, st[l][s].id, pf);
               float c255[3], n255[3];
               shade(m, tex, lights, T, gl_eye, do_norm, pf, px, py, c255, n255);
               for (int c = 0; c < 3; ++c) { q[s][c] = (float)(unsigned)q255(c255[c]); q[s][3 + c] = (float)(unsigned)q255(n255[c]); }
