@@ -201,7 +201,8 @@ __device__ __forceinline__ rc::TileRec load_tile_rec(const rc::TileRec* __restri
   r.rx0 = (short)(a.x & 0xFFFF); r.ry0 = (short)(a.x >> 16);
   r.rx1 = (short)(a.y & 0xFFFF); r.ry1 = (short)(a.y >> 16);
   r.rx2 = (short)(a.z & 0xFFFF); r.ry2 = (short)(a.z >> 16);
-  r.pad0 = r.pad1 = 0;
+  r.pad0 = (short)(a.w & 0xFFFF);   // flags (orientation swap / clipped)
+  r.pad1 = 0;
   r.iz0 = __int_as_float(b.x); r.iz1 = __int_as_float(b.y); r.iz2 = __int_as_float(b.z);
   r.id = b.w;
   return r;
