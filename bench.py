@@ -146,6 +146,13 @@ def extras(est, obs, det, steps: int) -> dict:
         dt = timed(k)
         out[f"n_pose_hypotheses={k}"] = {"ms_per_call": dt * 1e3, "coarse_hypotheses_per_s": N_HYP / dt,
                                          "note": "576 coarse rows + K x 5 refine rows + K score rows (megapose-1.0-RGB[-multi-hypothesis] defaults)"}
+    rend = est.coarse_model.renderer   # one renderer serves both models
+    rend.msaa = 1
+    dt = timed(N_HYP)
+    rend.msaa = 4
+    out["single_sample_renders"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
+                                    "note": "Panda3dBatchRenderer(msaa=1): one centre sample per pixel instead of the reference's 4x multisampling "
+                                            "(panda3d_scene_renderer.py:73-74); what the rasteriser's multisampling costs end to end; never `value`"}
     est.n_streams = 3  # chunk interleave on 3 HIP streams: fills the tails of the conv grids and overlaps raster with MFMA work; not the
     dt = timed(N_HYP)  # default because overlapping kernels distort the per-kernel event timing the roofline figures rest on
     est.n_streams = 1

@@ -458,7 +458,10 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   q.n_nblocks = ceil_div(p.Cout, BN);
   constexpr int NBUF = (VARIANT & 4) ? 1 : 2;
   constexpr int LDT = LDS_LD;
-  const size_t lds = (size_t)(NBUF * BM * LDT + NBUF * BN * LDT) * sizeof(float) + BM * sizeof(int);
+  // MP_CONV_LDS_PAD_KB (tuning experiment): extra, unused LDS per workgroup -- e.g. 30 forces ONE workgroup per CU, which separates the
+  // main loop's own efficiency from the interplay of two co-resident workgroups (scripts/conv_slope.py)
+  static const size_t lds_pad = getenv("MP_CONV_LDS_PAD_KB") ? (size_t)atoi(getenv("MP_CONV_LDS_PAD_KB")) * 1024 : 0;
+  const size_t lds = (size_t)(NBUF * BM * LDT + NBUF * BN * LDT) * sizeof(float) + BM * sizeof(int) + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>,
