@@ -59,8 +59,19 @@ struct ConvParams {
   int m_part_begin;  // first output row held by `partial` (rows before it belong to the single-pass launch)
 };
 
-#ifdef MP_RASTER_PROF   // scripts/microbench build only: shader cycles vs 100 MHz real-time ticks spent inside the conv kernels
+#ifdef MP_RASTER_PROF   // scripts/microbench build only: shader cycles vs 100 MHz real-time ticks spent inside the conv kernels,
+// and where a wave's cycles go inside one K-loop iteration: 0 load issue, 1 MFMA groups 0-1, 2 wait for the global loads + LDS
+// writes, 3 MFMA groups 2-3, 4 barrier
 __device__ unsigned long long g_conv_clk[2];
+__device__ unsigned long long g_conv_seg[8];
+#define CPROF(slot)                                                    \
+  {                                                                    \
+    const unsigned long long cprof_n = __builtin_readcyclecounter();   \
+    cprof_acc[slot] += cprof_n - cprof_t;                              \
+    cprof_t = cprof_n;                                                 \
+  }
+#else
+#define CPROF(slot)
 #endif
 
 template <int TM, int TN, bool RES, bool RELU, bool ACT>
@@ -245,6 +256,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
   const int row_wrap = row_stride - p.run;
+#ifdef MP_RASTER_PROF
+  unsigned long long cprof_acc[5] = {0, 0, 0, 0, 0};
+  unsigned long long cprof_t = __builtin_readcyclecounter();
+#endif
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int buf = SBUF ? 0 : ((chunk - c_begin) & 1);
     if (chunk + 1 < c_end) {  // advance to the next chunk; the loads themselves are unconditional
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     }
     MP_CONV_LOAD(aoff, bp)
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
+    CPROF(0)
     const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
     const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
     if constexpr ((VARIANT & 2048) != 0) {
@@ -313,8 +329,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
         constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
         if (kk == STORE_KK) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
           __builtin_amdgcn_sched_barrier(0);
+          CPROF(1)
           MP_CONV_STORE(buf ^ 1)
           __builtin_amdgcn_sched_barrier(0);
+          CPROF(2)
         }
       }
       if constexpr ((VARIANT & 2) != 0) {
@@ -343,8 +361,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       __builtin_amdgcn_sched_barrier(0);
       MP_CONV_STORE(buf ^ 1)
     }
+    CPROF(3)
     __syncthreads();
+    CPROF(4)
   }
+#ifdef MP_RASTER_PROF
+  if (lane == 0 && (blockIdx.x & 15) == 0)
+    for (int k = 0; k < 5; ++k) atomicAdd(&g_conv_seg[k], cprof_acc[k]);
+#endif
 #undef MP_CONV_LOAD
 #undef MP_CONV_STORE
 #undef MP_LD4
@@ -501,9 +525,11 @@ using namespace mp;
 extern "C" int mp_conv_prof_read(unsigned long long* out2, int reset) {
   MP_CHECK_HIP(hipDeviceSynchronize());
   MP_CHECK_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_conv_clk), 2 * sizeof(unsigned long long)));
+  MP_CHECK_HIP(hipMemcpyFromSymbol(out2 + 2, HIP_SYMBOL(g_conv_seg), 8 * sizeof(unsigned long long)));   // out2 holds 10 words
   if (reset) {
-    unsigned long long z[2] = {0, 0};
-    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_clk), z, sizeof(z)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_clk), z, 2 * sizeof(unsigned long long)));
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_seg), z, sizeof(z)));
   }
   return MP_OK;
 }

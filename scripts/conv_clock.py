@@ -19,7 +19,7 @@ for name in ("random", "zeros", "random"):
         eng.padded_view(x, b, 240, 320, bb.c_in_p, bb.in_border)[..., :27] = torch.rand(b, 240, 320, 27, device="cuda")
     out = torch.empty(b, 9, device="cuda")
     bb.forward(x, b, 240, 320, out)
-    buf = (C.c_ulonglong * 2)()
+    buf = (C.c_ulonglong * 10)()
     lib.mp_conv_prof_read(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
