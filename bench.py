@@ -303,6 +303,8 @@ def main():
     assert len(final) == n_obj and torch.isfinite(final.poses).all()
     # stage times from HIP events: one extra, untimed call with cuda_timer=True (each stage fenced, DEVICE render/model times)
     _, extra_t = step(cuda_timer=True)
+    # sustained shader clock of THIS box under fp32-MFMA load (boxes of one pool differ by ~10 %): context for `roofline.frac`, not part of it
+    clk = eng.clock_probe(30.0)
 
     rc = 0
     if rank == 0:
@@ -341,7 +343,11 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": dom["bytes"] / dom["launches"], "launches": dom["launches"],
                          "avg_launch_ms": dom["ms"] / dom["launches"], "avg_launch_gflop": dom["flops"] / dom["launches"] / 1e9,
-                         "all_conv_kernels_tflops": all_conv_tf, "per_kernel_tflops": conv_tf},
+                         "all_conv_kernels_tflops": all_conv_tf, "per_kernel_tflops": conv_tf,
+                         "shader_clock_mhz": clk["shader_mhz"], "mfma_probe_tflops": clk["mfma_tflops"],
+                         "frac_at_measured_clock": achieved / (PEAK_FP32_MFMA_TFLOPS * clk["shader_mhz"] / 2400.0) if clk["shader_mhz"] > 0 else None,
+                         "clock_note": "register-only v_mfma_f32_32x32x2_f32 loop (mp_clock_probe) right after the timed region: s_memtime / "
+                                       "s_memrealtime; `peak` is the 2400 MHz figure, `frac` = achieved / peak as the contract defines it"},
             "raster": None if rb is None else {"bound": "hbm", "kernel": rb_name, "achieved": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9,
                                                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                                "traffic": r_traffic, "alg_bytes_per_launch": rb["bytes"] / rb["launches"],

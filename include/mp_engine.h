@@ -43,6 +43,12 @@ int mp_profile_end(void);
 int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
                      double* total_bytes);
 
+/* Shader clock under fp32-MFMA load: runs a register-only v_mfma_f32_32x32x2_f32 loop on every CU for `ms_target` milliseconds
+ * (two workgroups of four waves per CU, operands rotating every instruction), synchronises, and returns the effective shader clock
+ * = delta(s_memtime) / delta(s_memrealtime at 100 MHz) in MHz and the loop's own TFLOP/s (NULL to skip either).  bench.py states
+ * the clock its roofline fraction was measured at: boxes of the same pool differ by ~10 % in sustained clock. */
+int mp_clock_probe(double ms_target, double* shader_mhz, double* mfma_tflops, mp_stream stream);
+
 /* number of CUs etc. of the current device; fails loudly when no gfx950 device is usable */
 int mp_device_info(int* n_cus, int* lds_bytes, char* arch_name, int arch_name_len);
 

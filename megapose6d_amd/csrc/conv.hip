@@ -260,64 +260,103 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   unsigned long long cprof_acc[5] = {0, 0, 0, 0, 0};
   unsigned long long cprof_t = __builtin_readcyclecounter();
 #endif
+// advance the load position to the next chunk (guarded by COND; the loads themselves are unconditional, the last one is repeated)
+#define MP_CONV_ADVANCE(COND)                                                                                      \
+  if (COND) {                                                                                                      \
+    bp += BN * BK;                                                                                                 \
+    aoff += BK;                                                                                                    \
+    if constexpr (RAGGED) {                                                                                        \
+      j += BK;                                                                                                     \
+      while (j >= p.run) { /* crossed into the next kernel row(s) (runs shorter than BK wrap more than once) */    \
+        j -= p.run;                                                                                                \
+        aoff += row_wrap;                                                                                          \
+      }                                                                                                            \
+    } else {                                                                                                       \
+      ju += BK;                                                                                                    \
+      if (ju == p.run) {                                                                                           \
+        ju = 0;                                                                                                    \
+        aoff += row_wrap;                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+  if constexpr ((VARIANT & 4096) != 0) {
+    // Two-chunks-ahead pipeline, ONE barrier per chunk placed before the LAST MFMA group:
+    //   registers G hold chunk c+1 (requested a whole chunk ago), fragments of k-group g+1 are read from LDS under the 16 MFMAs of
+    //   group g -- across the chunk boundary too: the barrier sits where (i) every wave has written chunk c+1 to the other buffer
+    //   (under group 0) and (ii) every wave has READ its last fragments of chunk c (requested under group 2), so after it the other
+    //   buffer may be read (group 0 of chunk c+1, under group 3 of chunk c) and this buffer may be overwritten (top of chunk c+1).
+    static_assert(BK == 32, "four k-groups per chunk");
+    MP_CONV_ADVANCE(c_begin + 1 < c_end)
+    MP_CONV_LOAD(aoff, bp)
+    float4 afr[2][TM], bfr[2][TN];
+    {
+      const float* as0 = As + (wm * WM + frag_row) * LDT + frag_k;
+      const float* bs0 = Bs + (wn * WN + frag_row) * LDT + frag_k;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) afr[0][i] = *reinterpret_cast<const float4*>(as0 + i * 32 * LDT);
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bfr[0][jn] = *reinterpret_cast<const float4*>(bs0 + jn * 32 * LDT);
+    }
+#define MP_FRAG_READ(SLOT, AS, BS, KOFF)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) afr[SLOT][i] = *reinterpret_cast<const float4*>((AS) + i * 32 * LDT + (KOFF));  \
+  _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) bfr[SLOT][jn] = *reinterpret_cast<const float4*>((BS) + jn * 32 * LDT + (KOFF));
+#define MP_MFMA_ROW(SLOT, I)                                                                                       \
+  _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) {                                                              \
+    acc[I][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[SLOT][I].x, bfr[SLOT][jn].x, acc[I][jn], 0, 0, 0);       \
+    acc[I][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[SLOT][I].y, bfr[SLOT][jn].y, acc[I][jn], 0, 0, 0);       \
+    acc[I][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[SLOT][I].z, bfr[SLOT][jn].z, acc[I][jn], 0, 0, 0);       \
+    acc[I][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[SLOT][I].w, bfr[SLOT][jn].w, acc[I][jn], 0, 0, 0);       \
+  }
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const int buf = (chunk - c_begin) & 1;
+      const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
+      const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
+      const float* as_n = As + (buf ^ 1) * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
+      const float* bs_n = Bs + (buf ^ 1) * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
+      // group 0 (+ chunk c+1: registers -> other buffer; chunk c+2: global -> registers)
+      MP_FRAG_READ(1, as, bs, 8)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_MFMA_ROW(0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_CONV_STORE(buf ^ 1)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_MFMA_ROW(0, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_CONV_ADVANCE(chunk + 2 < c_end)
+      MP_CONV_LOAD(aoff, bp)
+      __builtin_amdgcn_sched_barrier(0);
+      // group 1
+      MP_FRAG_READ(0, as, bs, 16)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_MFMA_ROW(1, 0)
+      MP_MFMA_ROW(1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      // group 2
+      MP_FRAG_READ(1, as, bs, 24)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_MFMA_ROW(0, 0)
+      MP_MFMA_ROW(0, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      // group 3, with the first fragments of the next chunk
+      MP_FRAG_READ(0, as_n, bs_n, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      MP_MFMA_ROW(1, 0)
+      MP_MFMA_ROW(1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef MP_FRAG_READ
+#undef MP_MFMA_ROW
+  } else
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int buf = SBUF ? 0 : ((chunk - c_begin) & 1);
-    if (chunk + 1 < c_end) {  // advance to the next chunk; the loads themselves are unconditional
-      bp += BN * BK;
-      aoff += BK;
-      if constexpr (RAGGED) {
-        j += BK;
-        while (j >= p.run) {  // crossed into the next kernel row(s) (runs shorter than BK wrap more than once)
-          j -= p.run;
-          aoff += row_wrap;
-        }
-      } else {
-        ju += BK;
-        if (ju == p.run) {
-          ju = 0;
-          aoff += row_wrap;
-        }
-      }
-    }
+    MP_CONV_ADVANCE(chunk + 1 < c_end)
     MP_CONV_LOAD(aoff, bp)
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
     CPROF(0)
     const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
     const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
-    if constexpr ((VARIANT & 2048) != 0) {
-      // Fragment prefetch: the 16-byte A/B fragments of k-group kk + 1 are read from LDS while the 16 MFMAs of group kk run
-      // (1024 SIMD cycles of cover), so the only exposed LDS latency per chunk is the first group's, right after the barrier.
-      float4 afr[2][TM], bfr[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) afr[0][i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT);
-#pragma unroll
-      for (int kk = 0; kk < BK / 8; ++kk) {
-        if (kk + 1 < BK / 8) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) afr[(kk + 1) & 1][i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT + (kk + 1) * 8);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[(kk + 1) & 1][j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT + (kk + 1) * 8);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // the reads above stay ahead of this group's MFMAs
-        constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
-        if (kk == STORE_KK) {
-          MP_CONV_STORE(buf ^ 1)
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].x, bfr[kk & 1][j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].y, bfr[kk & 1][j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].z, bfr[kk & 1][j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk & 1][i].w, bfr[kk & 1][j].w, acc[i][j], 0, 0, 0);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
+    {
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
@@ -371,6 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 #endif
 #undef MP_CONV_LOAD
 #undef MP_CONV_STORE
+#undef MP_CONV_ADVANCE
 #undef MP_LD4
 #undef MP_ST4
 
@@ -701,8 +741,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
     case 1: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
     case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
-    case 2305: return small ? launch<128, 64, 64, 32, 2305>(p, s, alg_k) : launch<128, 128, 64, 64, 2305>(p, s, alg_k);  // + LDS fragment prefetch
-    case 2817: return small ? launch<128, 64, 64, 32, 2817>(p, s, alg_k) : launch<128, 128, 64, 64, 2817>(p, s, alg_k);  // same, LDS store under group 1
+    case 4097: return small ? launch<128, 64, 64, 32, 4097>(p, s, alg_k) : launch<128, 128, 64, 64, 4097>(p, s, alg_k);  // two-chunks-ahead pipeline, barrier before the last group
     default: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);
   }
 }

@@ -73,6 +73,73 @@ extern "C" int mp_profile_query(int idx, char* name, int name_len, int64_t* laun
   return MP_OK;
 }
 
+namespace mp {
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void clock_probe_kernel(float* sink, unsigned long long* clk, int iters) {
+  probe_f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a[8], b[8];
+  for (int k = 0; k < 8; ++k) {   // operands that differ per lane and per instruction (bounded: the sums stay finite)
+    a[k] = (float)((threadIdx.x * 7 + k * 13) % 31 - 15) * 0.03125f;
+    b[k] = (float)((threadIdx.x * 5 + k * 11) % 29 - 14) * 0.03125f;
+  }
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + i) & 7], b[(u + 3 * i) & 7], acc[i], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) sink[0] = s;   // keeps the loop alive
+  if (threadIdx.x == 0) {
+    atomicAdd(&clk[0], c1 - c0);
+    atomicAdd(&clk[1], r1 - r0);
+  }
+}
+}  // namespace mp
+
+extern "C" int mp_clock_probe(double ms_target, double* shader_mhz, double* mfma_tflops, mp_stream stream) {
+  MP_REQUIRE(ms_target > 0.0 && ms_target <= 2000.0, "mp_clock_probe: ms_target out of range");
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0, n_cu = 0;
+  MP_CHECK_HIP(hipGetDevice(&dev));
+  MP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  float* sink = nullptr;
+  unsigned long long* clk = nullptr;
+  MP_CHECK_HIP(hipMalloc(&sink, sizeof(float)));
+  MP_CHECK_HIP(hipMalloc(&clk, 2 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  MP_CHECK_HIP(hipEventCreate(&e0));
+  MP_CHECK_HIP(hipEventCreate(&e1));
+  // 32 MFMAs of 64 cycles per iteration and wave, two waves per SIMD: 4096 cycles per iteration at full rate
+  const int iters = (int)(ms_target * 1e-3 * 2.4e9 / 4096.0) + 1;
+  const int grid = 2 * n_cu;
+  int rc = MP_OK;
+  float ms = 0.f;
+  unsigned long long h[2] = {0, 0};
+  for (int rep = 0; rep < 2 && rc == MP_OK; ++rep) {   // the first launch warms the clock up
+    if (hipMemsetAsync(clk, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) { rc = MP_ERR_HIP; break; }
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mp::clock_probe_kernel, dim3(grid), dim3(256), 0, s, sink, clk, iters);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = MP_ERR_HIP;
+  }
+  if (rc == MP_OK && hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) rc = MP_ERR_HIP;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  (void)hipFree(clk);
+  if (rc != MP_OK) { mp::set_error("mp_clock_probe: HIP error"); return rc; }
+  if (shader_mhz) *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+  if (mfma_tflops) *mfma_tflops = ms > 0.f ? (double)grid * 4.0 * iters * 32.0 * 4096.0 / (ms * 1e-3) * 1e-12 : 0.0;
+  return MP_OK;
+}
+
 extern "C" int mp_version(void) { return 100; }
 extern "C" const char* mp_last_error(void) { return mp::g_err; }
 

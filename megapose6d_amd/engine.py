@@ -47,6 +47,13 @@ def _dev_i32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def clock_probe(ms_target: float = 20.0) -> Dict[str, float]:
+    """Effective shader clock (MHz) under fp32-MFMA load and the probe loop's own TFLOP/s (synchronises; mp_clock_probe)."""
+    mhz, tf = C.c_double(0), C.c_double(0)
+    check(_lib.load().mp_clock_probe(float(ms_target), C.byref(mhz), C.byref(tf), _stream()))
+    return {"shader_mhz": mhz.value, "mfma_tflops": tf.value}
+
+
 def profile_begin() -> None:
     check(_lib.load().mp_profile_begin())
 
