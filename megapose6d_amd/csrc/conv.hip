@@ -111,12 +111,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
-// VARIANT bit 0: LDS store of the next chunk under an MFMA group (bit 8: the 3rd of 4); bit 1: interleaved MFMA order; bit 2: SINGLE LDS buffer
-// (half the LDS -> 3+ workgroups per CU, two barriers per chunk) -- bit 2 excludes bit 0.
+// VARIANT: 1 = the LDS store of the next chunk sits under the LAST MFMA group, | 256 = under the 3rd of 4; | 4096 = the two-chunks-ahead
+// pipeline (barrier before the last group); | 8192 = buffer loads (scalar resource + 32-bit offsets) instead of global loads.
 template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, bool SPLITK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 3 : 2, (VARIANT & 4) ? 3 : 2))) void conv_nhwc_f32_mfma(ConvParams p) {
-  constexpr bool SBUF = (VARIANT & 4) != 0;
-  constexpr int NBUF = SBUF ? 1 : 2;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma(ConvParams p) {
+  constexpr int NBUF = 2;
   constexpr int LDT = LDS_LD;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -174,6 +173,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 
   const int a_col = a_c4 * 4;  // this thread's float offset in a chunk row
   const float* b_ptr = p.w + (size_t)nblk * p.n_chunks * (BN * BK) + (tid >> 3) * BK + a_col;
+  // VARIANT bit 8192: buffer_load_dwordx4 (scalar resource + 32-bit lane offset + scalar chunk offset) instead of global_load_dwordx4
+  // with 64-bit lane addresses.  The A resource starts at the tile's first pixel (addresses ascend with the row index, the tile spans
+  // a few image rows), the B resource at this n-block's packed weights; neither range check can trigger (num_records = 2^32 - 1).
+  constexpr bool BUFLD = (VARIANT & 8192) != 0;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  int a_voff[A_LD4] = {0, 0, 0, 0};
+  int b_voff = 0;
+  __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
+  if constexpr (BUFLD) {
+    const int mb = m0 < p.M ? m0 : p.M - 1;
+    const int wo = mb % p.Wo;
+    const int t = mb / p.Wo;
+    const int ho = t % p.Ho;
+    const int n = t / p.Ho;
+    const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
+    const float* a_base = p.x + pix * p.C;
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, -1, 0x00020000);
+    b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)nblk * p.n_chunks * (BN * BK)), 0, -1, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) a_voff[i] = (int)((a_ptr[i] - a_base) * 4);
+    b_voff = ((tid >> 3) * BK + a_col) * 4;
+  }
   const int row_stride = p.Wp * p.C;  // floats between successive kh rows
 
   f32x16 acc[TM][TN];
@@ -190,16 +211,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 // (explicit scalars, not arrays: the arrays only become registers after loop unrolling, and the sched_barrier intrinsic
 //  that pins the prefetch is a memory barrier to the optimiser, which would leave them in scratch)
 #define MP_LD4(P) (*reinterpret_cast<const float4*>(P))
-#define MP_CONV_LOAD(AOFF, BP)                          \
-  a0 = MP_LD4(a_ptr0 + (AOFF));                         \
-  a1 = MP_LD4(a_ptr1 + (AOFF));                         \
-  a2 = MP_LD4(a_ptr2 + (AOFF));                         \
-  a3 = MP_LD4(a_ptr3 + (AOFF));                         \
-  b0 = MP_LD4((BP));                                    \
-  b1 = MP_LD4((BP) + 1024);                             \
-  if constexpr (B_LD4 > 2) {                            \
-    b2 = MP_LD4((BP) + 2048);                           \
-    b3 = MP_LD4((BP) + 3072);                           \
+#define MP_BUF4(R, V, S) ([&] { const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(R, V, S, 0);              \
+    return make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }())
+#define MP_CONV_LOAD(AOFF, BP)                                                                                     \
+  if constexpr (BUFLD) {                                                                                           \
+    /* RAGGED: the run position is per lane (vector offset); otherwise only a_col is, the rest rides in the scalar offset */ \
+    const int av_ = RAGGED ? (AOFF) * 4 : a_col * 4;                                                               \
+    const int as_ = RAGGED ? 0 : a_su * 4;   /* a_su / b_su: the wave-uniform parts of AOFF / BP, tracked separately */ \
+    const int bs_ = b_su * 4;                                                                                      \
+    a0 = MP_BUF4(a_rsrc, a_voff[0] + av_, as_);                                                                    \
+    a1 = MP_BUF4(a_rsrc, a_voff[1] + av_, as_);                                                                    \
+    a2 = MP_BUF4(a_rsrc, a_voff[2] + av_, as_);                                                                    \
+    a3 = MP_BUF4(a_rsrc, a_voff[3] + av_, as_);                                                                    \
+    b0 = MP_BUF4(b_rsrc, b_voff, bs_);                                                                             \
+    b1 = MP_BUF4(b_rsrc, b_voff, bs_ + 4096);                                                                      \
+    if constexpr (B_LD4 > 2) {                                                                                     \
+      b2 = MP_BUF4(b_rsrc, b_voff, bs_ + 8192);                                                                    \
+      b3 = MP_BUF4(b_rsrc, b_voff, bs_ + 12288);                                                                   \
+    }                                                                                                              \
+  } else {                                                                                                         \
+    a0 = MP_LD4(a_ptr0 + (AOFF));                                                                                  \
+    a1 = MP_LD4(a_ptr1 + (AOFF));                                                                                  \
+    a2 = MP_LD4(a_ptr2 + (AOFF));                                                                                  \
+    a3 = MP_LD4(a_ptr3 + (AOFF));                                                                                  \
+    b0 = MP_LD4((BP));                                                                                             \
+    b1 = MP_LD4((BP) + 1024);                                                                                      \
+    if constexpr (B_LD4 > 2) {                                                                                     \
+      b2 = MP_LD4((BP) + 2048);                                                                                    \
+      b3 = MP_LD4((BP) + 3072);                                                                                    \
+    }                                                                                                              \
   }
 #define MP_ST4(P, V) (*reinterpret_cast<float4*>(P) = (V))
 #define MP_CONV_STORE(BUF)                                                        \
@@ -230,12 +270,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
   // the bump is wave-uniform (scalar registers), which is what the 3x3 / 1x1 layers use.
   int j = a_col, aoff = a_col;
   int ju = 0;  // uniform run position (non-RAGGED)
+  int a_su = 0, b_su = 0;  // buffer-load variant: uniform float offsets of the current chunk (A: non-RAGGED only)
   const float* bp = b_ptr;
   int c_begin = 0, c_end = p.n_chunks;
   if constexpr (SPLITK) {
     c_begin = blockIdx.y * p.chunks_per_split;
     c_end = min(p.n_chunks, c_begin + p.chunks_per_split);
     bp += (size_t)c_begin * (BN * BK);
+    b_su = c_begin * (BN * BK);
     if constexpr (RAGGED) {
       const int jj = a_col + c_begin * BK;
       const int kh = jj / p.run;
@@ -245,6 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       const int kh = (c_begin * BK) / p.run;
       ju = c_begin * BK - kh * p.run;
       aoff = a_col + kh * row_stride + ju;
+      a_su = kh * row_stride + ju;
     }
   } else if constexpr (RAGGED) {
     while (j >= p.run) { j -= p.run; aoff += row_stride - p.run; }
@@ -264,7 +307,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 #define MP_CONV_ADVANCE(COND)                                                                                      \
   if (COND) {                                                                                                      \
     bp += BN * BK;                                                                                                 \
+    b_su += BN * BK;                                                                                               \
     aoff += BK;                                                                                                    \
+    a_su += BK;                                                                                                    \
     if constexpr (RAGGED) {                                                                                        \
       j += BK;                                                                                                     \
       while (j >= p.run) { /* crossed into the next kernel row(s) (runs shorter than BK wrap more than once) */    \
@@ -276,6 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       if (ju == p.run) {                                                                                           \
         ju = 0;                                                                                                    \
         aoff += row_wrap;                                                                                          \
+        a_su += row_wrap;                                                                                          \
       }                                                                                                            \
     }                                                                                                              \
   }
@@ -349,14 +395,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
 #undef MP_MFMA_ROW
   } else
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    const int buf = SBUF ? 0 : ((chunk - c_begin) & 1);
+    const int buf = (chunk - c_begin) & 1;
     MP_CONV_ADVANCE(chunk + 1 < c_end)
     MP_CONV_LOAD(aoff, bp)
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the end)
     CPROF(0)
     const float* as = As + buf * BM * LDT + (wm * WM + frag_row) * LDT + frag_k;
     const float* bs = Bs + buf * BN * LDT + (wn * WN + frag_row) * LDT + frag_k;
-    {
+    constexpr int STORE_KK = (VARIANT & 256) ? 2 : BK / 8 - 1;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[TM], bf[TN];
@@ -364,41 +410,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDT + kk * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDT + kk * 8);
-      if constexpr ((VARIANT & 1) != 0) {
-        constexpr int STORE_KK = (VARIANT & 256) ? 2 : (VARIANT & 512) ? 1 : BK / 8 - 1;
-        if (kk == STORE_KK) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
-          __builtin_amdgcn_sched_barrier(0);
-          CPROF(1)
-          MP_CONV_STORE(buf ^ 1)
-          __builtin_amdgcn_sched_barrier(0);
-          CPROF(2)
+      if (kk == STORE_KK) {  // write the prefetched chunk to the other buffer UNDER an MFMA group
+        __builtin_amdgcn_sched_barrier(0);
+        CPROF(1)
+        MP_CONV_STORE(buf ^ 1)
+        __builtin_amdgcn_sched_barrier(0);
+        CPROF(2)
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
-      }
-      if constexpr ((VARIANT & 2) != 0) {
-#define MP_MFMA_ALL(C)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].C, bf[j].C, acc[i][j], 0, 0, 0);
-        MP_MFMA_ALL(x) MP_MFMA_ALL(y) MP_MFMA_ALL(z) MP_MFMA_ALL(w)
-#undef MP_MFMA_ALL
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    }
-    }
-    if constexpr (SBUF) {
-      __syncthreads();  // every wave is done reading this chunk
-      MP_CONV_STORE(0)
-    } else if constexpr ((VARIANT & 1) == 0) {
-      __builtin_amdgcn_sched_barrier(0);
-      MP_CONV_STORE(buf ^ 1)
     }
     CPROF(3)
     __syncthreads();
@@ -409,6 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VARIANT & 
     for (int k = 0; k < 5; ++k) atomicAdd(&g_conv_seg[k], cprof_acc[k]);
 #endif
 #undef MP_CONV_LOAD
+#undef MP_BUF4
 #undef MP_CONV_STORE
 #undef MP_CONV_ADVANCE
 #undef MP_LD4
@@ -520,7 +548,7 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   ConvParams q = p;
   q.n_mblocks = ceil_div(p.M, BM);
   q.n_nblocks = ceil_div(p.Cout, BN);
-  constexpr int NBUF = (VARIANT & 4) ? 1 : 2;
+  constexpr int NBUF = 2;
   constexpr int LDT = LDS_LD;
   // MP_CONV_LDS_PAD_KB (tuning experiment): extra, unused LDS per workgroup -- e.g. 30 forces ONE workgroup per CU, which separates the
   // main loop's own efficiency from the interplay of two co-resident workgroups (scripts/conv_slope.py)
@@ -706,7 +734,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
-  static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 257;  // default: LDS store under the 3rd of 4 MFMA groups; others = tuning experiments
+  static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 8449;  // default: buffer loads, LDS store under the 3rd of 4 MFMA groups; others = A/B timing
   const bool small = conv_bn_tile(d->Cout) == 64;
   static const int splitk_on = getenv("MP_CONV_SPLITK") ? atoi(getenv("MP_CONV_SPLITK")) : 1;
   static const int tail_on = getenv("MP_CONV_TAIL") ? atoi(getenv("MP_CONV_TAIL")) : 1;
@@ -722,27 +750,26 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     p.chunks_per_split = plan.chunks_per_split;
     p.k_split = plan.k_split;
     p.partial = d->d_splitk_ws;
-    if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 1, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1, true>(p, s, alg_k);
-    return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
+    if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 8193, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193, true>(p, s, alg_k);
+    return small ? launch_splitk<128, 64, 64, 32, 8193>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193>(p, s, alg_k);
   }
   if (plan.mode == 2) {  // whole rounds single-pass, the tiles of the half-empty last round split along K
-    int rc2 = small ? launch<128, 64, 64, 32, 257>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 257>(p, s, alg_k, plan.n_main);
+    int rc2 = small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 8449>(p, s, alg_k, plan.n_main);
     if (rc2) return rc2;
     p.chunks_per_split = plan.chunks_per_split;
     p.k_split = plan.k_split;
     p.partial = d->d_splitk_ws;
     p.tile_begin = plan.n_main;
     p.m_part_begin = plan.m_begin;
-    return small ? launch_splitk<128, 64, 64, 32, 1>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 1>(p, s, alg_k);
+    return small ? launch_splitk<128, 64, 64, 32, 8193>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193>(p, s, alg_k);
   }
   if (p.run % BK != 0)  // ragged K (stems): per-lane K bookkeeping
-    return small ? launch<128, 64, 64, 32, 257, true>(p, s, alg_k) : launch<128, 128, 64, 64, 257, true>(p, s, alg_k);
-  switch (variant) {  // every variant computes the same result; 257 is the measured best, the others are kept for A/B timing
-    case 0: return small ? launch<128, 64, 64, 32, 0>(p, s, alg_k) : launch<128, 128, 64, 64, 0>(p, s, alg_k);
-    case 1: return small ? launch<128, 64, 64, 32, 1>(p, s, alg_k) : launch<128, 128, 64, 64, 1>(p, s, alg_k);
-    case 4: return small ? launch<128, 64, 64, 32, 4>(p, s, alg_k) : launch<128, 128, 64, 64, 4>(p, s, alg_k);
+    return small ? launch<128, 64, 64, 32, 8449, true>(p, s, alg_k) : launch<128, 128, 64, 64, 8449, true>(p, s, alg_k);
+  switch (variant) {  // every variant computes the same result; 8449 is the measured best, the others are kept for A/B timing
+    case 257: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);  // the default schedule with global_load (64-bit lane addresses)
+    case 12289: return small ? launch<128, 64, 64, 32, 12289>(p, s, alg_k) : launch<128, 128, 64, 64, 12289>(p, s, alg_k);  // 4097 with buffer loads
     case 4097: return small ? launch<128, 64, 64, 32, 4097>(p, s, alg_k) : launch<128, 128, 64, 64, 4097>(p, s, alg_k);  // two-chunks-ahead pipeline, barrier before the last group
-    default: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);
+    default: return small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k) : launch<128, 128, 64, 64, 8449>(p, s, alg_k);
   }
 }
 

@@ -5,6 +5,9 @@
 //   2  8 ds_write_b128 per chunk and thread (register -> other LDS buffer)
 //   4  one workgroup barrier per chunk
 //   8  8 global_load_dwordx4 per chunk and thread (4 scattered 128-B row pieces + 4 contiguous), consumed by the LDS writes when bit 2 is set
+//      (otherwise kept alive by an empty asm at the place of the writes)
+//  16  with 8: buffer_load_dwordx4 (scalar resource + 32-bit lane offsets) instead of global_load_dwordx4 (64-bit lane addresses)
+//  32  with 8: only the 4 contiguous loads
 // Run with 1 or 2 workgroups per CU (LDS padding).  Prints shader cycles per chunk (ideal 4096 per resident workgroup).
 // Build: hipcc -O3 --offload-arch=gfx950 conv_loop_parts.hip -o conv_loop_parts
 #include <hip/hip_runtime.h>
@@ -14,6 +17,7 @@
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDT = 36, BM = 128, BN = 128;
 
 #define SB __builtin_amdgcn_sched_barrier(0)
@@ -38,6 +42,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* ap[4];
   for (int i = 0; i < 4; ++i) ap[i] = gsrc + ((size_t)(blockIdx.x * 128 + a_r0 + 32 * i) * 2304) % (gfloats / 2) + a_c4 * 4;
   const float* bp = gsrc + gfloats / 2 + (size_t)(blockIdx.x % 2) * 65536 + (tid >> 3) * 32 + a_c4 * 4;
+  // the same addresses as byte offsets from the buffer base (the source is < 4 GB)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gsrc, 0, (int)(gfloats * 4 > 0x7fffffffull ? 0x7fffffff : gfloats * 4), 0x00020000);
+  int a_boff[4];
+  for (int i = 0; i < 4; ++i) a_boff[i] = (int)((ap[i] - gsrc) * 4);
+  const int b_boff = (int)((bp - gsrc) * 4);
   float4 g[8];
   for (int i = 0; i < 8; ++i) g[i] = make_float4(0.25f * i, 0.5f, -0.25f, 0.125f);
   float4 afr[2][2], bfr[2][2];
@@ -79,15 +88,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<float4*>(bs_w + i * 32 * LDT) = g[4 + i];
       }
     }
+    if constexpr ((PARTS & 2) == 0 && (PARTS & 8) != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(g[i].x), "v"(g[i].y), "v"(g[i].z), "v"(g[i].w));
+    }
     SB;
     MFMA_ROW(0, 1)
     SB;
     if constexpr ((PARTS & 8) != 0) {
       aoff = (aoff + 32) & 2047;
+      if constexpr ((PARTS & 16) != 0) {
+        if constexpr ((PARTS & 32) == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+          for (int i = 0; i < 4; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a_boff[i] + aoff * 4, 0, 0);
+            g[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+          }
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[4 + i] = *reinterpret_cast<const float4*>(bp + (size_t)(c & 15) * 4096 + i * 1024);
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, b_boff + ((c & 15) * 4096 + i * 1024) * 4, 0, 0);
+          g[4 + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+      } else {
+        if constexpr ((PARTS & 32) == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[4 + i] = *reinterpret_cast<const float4*>(bp + (size_t)(c & 15) * 4096 + i * 1024);
+      }
     }
     SB;
     FRAG_READ(0, as, bs, 16)
@@ -177,7 +207,11 @@ int main(int argc, char** argv) {
     run<5>("+ LDS fragment reads + barrier", w, gsrc, gfloats, out, clk, n_cu);
     run<3>("+ LDS reads + LDS writes", w, gsrc, gfloats, out, clk, n_cu);
     run<7>("+ LDS reads + LDS writes + barrier", w, gsrc, gfloats, out, clk, n_cu);
-    run<8>("+ global loads only", w, gsrc, gfloats, out, clk, n_cu);
+    run<8>("+ global loads only (kept alive, not stored)", w, gsrc, gfloats, out, clk, n_cu);
+    run<12>("+ global loads (not stored) + barrier", w, gsrc, gfloats, out, clk, n_cu);
+    run<13>("+ global loads (not stored) + LDS reads + barrier", w, gsrc, gfloats, out, clk, n_cu);
+    run<15 + 32>("everything, only the 4 contiguous loads", w, gsrc, gfloats, out, clk, n_cu);
+    run<15 + 16>("everything, buffer_load instead of global_load", w, gsrc, gfloats, out, clk, n_cu);
     run<15>("everything (the conv loop without its address arithmetic)", w, gsrc, gfloats, out, clk, n_cu);
     run<15>("everything, all-zero global data", w, gzero, gfloats, out, clk, n_cu);
   }
