@@ -49,6 +49,10 @@ int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, doubl
  * the clock its roofline fraction was measured at: boxes of the same pool differ by ~10 % in sustained clock. */
 int mp_clock_probe(double ms_target, double* shader_mhz, double* mfma_tflops, mp_stream stream);
 
+/* Effective shader clock (MHz) the fp32 convolution kernels ran at since the last reset: every 64th workgroup accumulates
+ * s_memtime cycles and s_memrealtime (100 MHz) ticks over its K loop.  Synchronises the device.  0.0 if no convolution ran. */
+int mp_conv_clock_read(double* shader_mhz, int reset);
+
 /* number of CUs etc. of the current device; fails loudly when no gfx950 device is usable */
 int mp_device_info(int* n_cus, int* lds_bytes, char* arch_name, int arch_name_len);
 

@@ -69,6 +69,7 @@ _vp, _i, _i64, _f, _sz, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_si
 SIGNATURES = {
     "mp_version": (_i, []),
     "mp_last_error": (C.c_char_p, []),
+    "mp_conv_clock_read": (_i, [C.POINTER(C.c_double), _i]),
     "mp_clock_probe": (_i, [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "mp_profile_begin": (_i, []),
     "mp_profile_end": (_i, []),

@@ -59,10 +59,12 @@ struct ConvParams {
   int m_part_begin;  // first output row held by `partial` (rows before it belong to the single-pass launch)
 };
 
-#ifdef MP_RASTER_PROF   // scripts/microbench build only: shader cycles vs 100 MHz real-time ticks spent inside the conv kernels,
-// and where a wave's cycles go inside one K-loop iteration: 0 load issue, 1 MFMA groups 0-1, 2 wait for the global loads + LDS
-// writes, 3 MFMA groups 2-3, 4 barrier
+// Clock telemetry (always on, ~free): every 64th workgroup adds the shader cycles (s_memtime) and the 100 MHz real-time ticks
+// (s_memrealtime) it spent in its K loop; mp_conv_clock_read turns the sums into the effective shader clock the convolutions ran at.
+// The fp32-MFMA peak scales with that clock, and under real (bit-toggling) operands this part sustains ~2.15 GHz, not 2.4.
 __device__ unsigned long long g_conv_clk[2];
+#ifdef MP_RASTER_PROF   // scripts/microbench build only: where a wave's cycles go inside one K-loop iteration: 0 load issue,
+// 1 MFMA groups 0-1, 2 wait for the global loads + LDS writes, 3 MFMA groups 2-3, 4 barrier
 __device__ unsigned long long g_conv_seg[8];
 #define CPROF(slot)                                                    \
   {                                                                    \
@@ -74,36 +76,65 @@ __device__ unsigned long long g_conv_seg[8];
 #define CPROF(slot)
 #endif
 
+// Fused epilogue through buffer instructions: one scalar resource per tensor based at the tile's first output row, one 32-bit
+// byte offset per (lane, tile row); rows past M and channels past Cout get an offset beyond num_records, which the hardware's range
+// check turns into "load 0 / drop the store" -- no per-element branches, no 64-bit lane addresses.
+// (Requesting the residual tile before the K loop, to hide its latency, was measured: 2 % slower -- the loads compete with the first
+// chunks and 32-64 registers stay live across the loop.)
+constexpr unsigned EPI_WINDOW = 0x40000000u;   // 1 GB window from the tile's first row: a tile spans a few image rows
+
+template <int TM>
+__device__ __forceinline__ void conv_row_offsets(const int* row_off, int row0, int n_first, int base, unsigned (&voff)[TM][16]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = row_off[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
+      voff[i][r] = o >= 0 ? (unsigned)(o - base + n_first) * 4u : EPI_WINDOW;
+    }
+}
+
 template <int TM, int TN, bool RES, bool RELU, bool ACT>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[TM][TN], const int* row_off, int row0, int n_first) {
+  const int base = __builtin_amdgcn_readfirstlane(row_off[0]);   // row 0 of a launched tile always exists
+  unsigned voff[TM][16];
+  conv_row_offsets<TM>(row_off, row0, n_first, base, voff);
+  float res[TM][TN][16];
+  if (RES) {   // every residual value of the wave's tile is requested before the first one is used: one exposed latency per tile
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual + base), 0, (int)EPI_WINDOW, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool n_ok = n_first + j * 32 < p.Cout;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          res[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_res, n_ok ? voff[i][r] + j * 128 : EPI_WINDOW, 0, 0));
+    }
+  }
+  const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + base : nullptr), 0, p.y ? (int)EPI_WINDOW : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_act =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? p.y_act + base : nullptr), 0, ACT ? (int)EPI_WINDOW : 0, 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n_first + j * 32;
-    if (n >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const bool n_ok = n < p.Cout;
+    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
     float sc = 1.f, sh = 0.f;
-    if (ACT) {
+    if (ACT && n_ok) {
       sc = p.act_scale[n];
       sh = p.act_shift[n];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      int offs[16];
-      float res[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) offs[r] = row_off[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
-      if (RES) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = offs[r] >= 0 ? p.residual[offs[r] + n] : 0.f;  // 16 loads in flight
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (offs[r] < 0) continue;
+        const unsigned vo = n_ok ? voff[i][r] + j * 128 : EPI_WINDOW;
         float v = acc[i][j][r] + bias;
-        if (RES) v += res[r];
+        if (RES) v += res[i][j][r];
         if (RELU) v = fmaxf(v, 0.f);
-        if (p.y) p.y[offs[r] + n] = v;
-        if (ACT) p.y_act[offs[r] + n] = fmaxf(fmaf(v, sc, sh), 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_y, vo, 0, 0);   // (a null y has num_records = 0: dropped)
+        if (ACT) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaf(v, sc, sh), 0.f)), r_act, vo, 0, 0);
       }
     }
   }
@@ -122,9 +153,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
   constexpr int B_LD4 = BN / 32;
 
-#ifdef MP_RASTER_PROF
-  const unsigned long long prof_c0 = __builtin_readcyclecounter(), prof_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  const bool clk_sample = threadIdx.x == 0 && (blockIdx.x & 63) == 0;
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [NBUF][BM][LDT]
   float* Bs = smem + NBUF * BM * LDT;        // [NBUF][BN][LDT]
@@ -442,12 +473,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef MP_LD4
 #undef MP_ST4
 
-#ifdef MP_RASTER_PROF
-  if (threadIdx.x == 0) {   // main loop only (prologue + K loop), one sample per workgroup
-    atomicAdd(&g_conv_clk[0], __builtin_readcyclecounter() - prof_c0);
-    atomicAdd(&g_conv_clk[1], __builtin_amdgcn_s_memrealtime() - prof_r0);
+  if (clk_sample) {   // prologue + K loop of this workgroup
+    atomicAdd(&g_conv_clk[0], __builtin_readcyclecounter() - clk_c0);
+    atomicAdd(&g_conv_clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
   }
-#endif
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   // (compile-time flags: one straight-line store loop per fused mode instead of four data-dependent branches per element)
   const int erow0 = wm * WM + (lane >> 5) * 4, en0 = n0 + wn * WN + (lane & 31);
@@ -588,6 +617,19 @@ static inline int conv_bn_tile(int Cout) { return Cout <= 64 ? 64 : 128; }
 }  // namespace mp
 
 using namespace mp;
+
+extern "C" int mp_conv_clock_read(double* shader_mhz, int reset) {
+  MP_REQUIRE(shader_mhz != nullptr, "mp_conv_clock_read: null output");
+  unsigned long long h[2] = {0, 0};
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_clk), sizeof(h)));
+  *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+  if (reset) {
+    const unsigned long long z[2] = {0, 0};
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_clk), z, sizeof(z)));
+  }
+  return MP_OK;
+}
 
 #ifdef MP_RASTER_PROF
 extern "C" int mp_conv_prof_read(unsigned long long* out2, int reset) {

@@ -23,12 +23,24 @@ struct ProfRec {
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;   // events are recycled: creating two per launch inside a timed region costs host time
+static hipEvent_t pool_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
   if (!g_prof_on) return;
   ProfRec r;
   r.name = name; r.flops = flops; r.bytes = bytes;
-  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  r.e0 = pool_event();
+  r.e1 = pool_event();
+  if (!r.e0 || !r.e1) return;
   (void)hipEventRecord(r.e0, s);
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
@@ -39,7 +51,7 @@ ProfScope::~ProfScope() {
 }  // namespace mp
 
 extern "C" int mp_profile_begin(void) {
-  for (auto& r : mp::g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& r : mp::g_prof) { mp::g_event_pool.push_back(r.e0); mp::g_event_pool.push_back(r.e1); }
   mp::g_prof.clear();
   mp::g_prof_on = true;
   return MP_OK;

@@ -54,6 +54,13 @@ def clock_probe(ms_target: float = 20.0) -> Dict[str, float]:
     return {"shader_mhz": mhz.value, "mfma_tflops": tf.value}
 
 
+def conv_clock(reset: bool = True) -> float:
+    """Effective shader clock (MHz) inside the convolution kernels since the last reset (synchronises; mp_conv_clock_read)."""
+    mhz = C.c_double(0)
+    check(_lib.load().mp_conv_clock_read(C.byref(mhz), 1 if reset else 0))
+    return mhz.value
+
+
 def profile_begin() -> None:
     check(_lib.load().mp_profile_begin())
 

@@ -7,13 +7,21 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from megapose6d_amd import engine as eng
+import ctypes as C
+
+from megapose6d_amd import _lib, engine as eng
+
+lib = _lib.load()
+PROF = hasattr(lib, "mp_conv_prof_read")   # profiling build (MP_ENGINE_LIB=scripts/microbench/_build/libmp_engine_prof.so): in-kernel clock
 
 n_cu = eng.device_info()[0]
-Cin = Cout = 256
+Cin = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+Cout = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 H = W = 16
 rounds = 4
-N = rounds * 2 * n_cu // 2 * 128 // (H * W)
+n_nblocks = (Cout + 127) // 128 if Cout > 64 else 1
+N = rounds * 2 * n_cu // n_nblocks * 128 // (H * W)
+print(f"Cin={Cin} Cout={Cout} N={N} ({rounds} rounds of resident workgroups)")
 for name in ("zeros", "ones", "randn", "randn", "zeros"):
     x = eng.padded_nhwc(N, H, W, Cin, 1, "cuda")
     if name == "ones":
@@ -31,6 +39,9 @@ for name in ("zeros", "ones", "randn", "randn", "zeros"):
         eng.conv2d_nhwc(x, N, H, W, Cin, 1, wp, bias, Cout, 3, 1, 1, y, 1, relu=True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    buf = (C.c_ulonglong * 10)()
+    if PROF:
+        lib.mp_conv_prof_read(buf, 1)
     e0.record()
     iters = 20
     for _ in range(iters):
@@ -38,4 +49,8 @@ for name in ("zeros", "ones", "randn", "randn", "zeros"):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print(f"{name:6s}: {ms * 1e3:8.1f} us per launch, {2.0 * N * H * W * Cout * 9 * Cin / ms / 1e9:6.1f} TFLOP/s", flush=True)
+    clk = ""
+    if PROF:
+        lib.mp_conv_prof_read(buf, 0)
+        clk = f", shader clock inside the kernel {buf[0] / max(buf[1], 1) * 100.0:.0f} MHz"
+    print(f"{name:6s}: {ms * 1e3:8.1f} us per launch, {2.0 * N * H * W * Cout * 9 * Cin / ms / 1e9:6.1f} TFLOP/s{clk}", flush=True)
