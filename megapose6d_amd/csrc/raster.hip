@@ -313,7 +313,13 @@ __device__ __forceinline__ void scatter_batch(const Piece& p, bool active, int x
 // ---- coverage form 2 (the view's "large" list and the overflow fallback only): wave-per-piece sweep with the 64-bit edge functions.
 // The piece is wave-uniform, lane l tests ITS pixel and updates its own z-buffer slots (no conflicts). ----------------------------
 template <int NS>
-__device__ __noinline__ void sweep_piece(const Piece& p, int tile_x0, int tile_y0, int px, int py, int lane, unsigned long long* zb) {
+__device__ __noinline__ void sweep_piece(int X0, int Y0, int X1, int Y1, int X2, int Y2, float iz0, float iz1, float iz2, int id, int tile_x0,
+                                         int tile_y0, int px, int py, int lane, unsigned long long* zb) {
+  // (scalar arguments travel in registers; a `const Piece&` would be built in scratch memory before every call)
+  Piece p;
+  p.X[0] = X0; p.Y[0] = Y0; p.X[1] = X1; p.Y[1] = Y1; p.X[2] = X2; p.Y[2] = Y2;
+  p.iz[0] = iz0; p.iz[1] = iz1; p.iz[2] = iz2;
+  p.id = id;
   const int Xmin = min(p.X[0], min(p.X[1], p.X[2])), Xmax = max(p.X[0], max(p.X[1], p.X[2]));
   const int Ymin = min(p.Y[0], min(p.Y[1], p.Y[2])), Ymax = max(p.Y[0], max(p.Y[1], p.Y[2]));
   const int sx0 = tile_x0 * SUBPIX, sy0 = tile_y0 * SUBPIX;
@@ -328,7 +334,8 @@ __device__ __noinline__ void sweep_piece(const Piece& p, int tile_x0, int tile_y
 }
 
 // roi_align of one output pixel; one instance for the four (C, layout) cases (code size)
-__device__ __noinline__ void crop_lane(const CropArgs& crop, int item, int h, int w, int px, int py, float (&cvals)[4]) {
+__device__ __noinline__ float4 crop_lane(CropArgs crop, int item, int h, int w, int px, int py) {
+  float cvals[4];   // (arguments and result by value = in registers: references would be built in scratch memory before the call)
   const float* bx = crop.boxes + (size_t)item * 4;
   const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
   const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
@@ -342,6 +349,7 @@ __device__ __noinline__ void crop_lane(const CropArgs& crop, int item, int h, in
     if (crop.C == 4) crop_pixel<4, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
     else crop_pixel<3, false>(img, crop.H, crop.W, x1, y1, bin_w, bin_h, px, py, cvals);
   }
+  return make_float4(cvals[0], cvals[1], cvals[2], cvals[3]);
 }
 
 struct ViewHdr {   // what a wave needs to know about one view's lists for its tile (wave-uniform)
@@ -465,13 +473,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       while (big) {
         const int j = __ffsll((long long)big) - 1;
         big &= big - 1ull;
-        Piece p;
-        p.id = rl(mine_p.id, j);
-        p.X[0] = rl(mine_p.X[0], j); p.Y[0] = rl(mine_p.Y[0], j);
-        p.X[1] = rl(mine_p.X[1], j); p.Y[1] = rl(mine_p.Y[1], j);
-        p.X[2] = rl(mine_p.X[2], j); p.Y[2] = rl(mine_p.Y[2], j);
-        p.iz[0] = rlf(mine_p.iz[0], j); p.iz[1] = rlf(mine_p.iz[1], j); p.iz[2] = rlf(mine_p.iz[2], j);
-        sweep_piece<NS>(p, tile_x0, tile_y0, px, py, lane, zb);
+        sweep_piece<NS>(rl(mine_p.X[0], j), rl(mine_p.Y[0], j), rl(mine_p.X[1], j), rl(mine_p.Y[1], j), rl(mine_p.X[2], j), rl(mine_p.Y[2], j),
+                        rlf(mine_p.iz[0], j), rlf(mine_p.iz[1], j), rlf(mine_p.iz[2], j), rl(mine_p.id, j), tile_x0, tile_y0, px, py, lane, zb);
       }
       wave_lds_fence();
       PROF(3)
@@ -553,10 +556,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     PROF(6)
   }
   if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
-    float cvals[4];
-    crop_lane(crop, item, h, w, px, py, cvals);
-    my_stage[crop.c0 - c_lo] = cvals[0]; my_stage[crop.c0 + 1 - c_lo] = cvals[1]; my_stage[crop.c0 + 2 - c_lo] = cvals[2];
-    if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cvals[3];
+    const float4 cv4 = crop_lane(crop, item, h, w, px, py);
+    my_stage[crop.c0 - c_lo] = cv4.x; my_stage[crop.c0 + 1 - c_lo] = cv4.y; my_stage[crop.c0 + 2 - c_lo] = cv4.z;
+    if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cv4.w;
   }
   wave_lds_fence();
   PROF(7)

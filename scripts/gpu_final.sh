@@ -1,0 +1,20 @@
+#!/bin/bash
+# Final measurement call of a round (run through gpurun): pipeline tests, bench lines, rocprofv3 kernel stats of the bench command and
+# the three PMC passes (ONE hardware counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_*) that feed profiles/rNN_traffic.json.
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/final
+mkdir -p $O
+R="$GRAFT_REPO_ROOT"
+timeout 240 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q > $O/pytest_pipeline.log 2>&1; echo "rc=$?" >> $O/pytest_pipeline.log
+timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "rc=$?" >> $O/bench_n1.err
+for c in 3 4 5; do timeout 200 python bench.py --config $c --steps 1 --warmup 1 > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+export TMPDIR=/tmp
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python $R/bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline > $R/$O/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 150 rocprofv3 --pmc $c --kernel-trace -d $R/$O/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $R/$O/pmc_$c.log 2>&1
+done
+timeout 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $R/$O/pmc_SQ -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $R/$O/pmc_SQ.log 2>&1
+cd $R
+find $O -name "*kernel_trace.csv" -size +8M -delete
+find $O -name "*.csv" -size +30M -delete
