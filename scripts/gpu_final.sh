@@ -8,6 +8,7 @@ R="$GRAFT_REPO_ROOT"
 timeout 240 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q > $O/pytest_pipeline.log 2>&1; echo "rc=$?" >> $O/pytest_pipeline.log
 timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "rc=$?" >> $O/bench_n1.err
 for c in 3 4 5; do timeout 200 python bench.py --config $c --steps 1 --warmup 1 > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+MP_PROF_DETAIL=1 timeout 100 python scripts/profile_layers.py > $O/layers.log 2>&1
 export TMPDIR=/tmp
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python $R/bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline > $R/$O/stats.log 2>&1
