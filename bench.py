@@ -142,37 +142,69 @@ def extras(est, obs, det, steps: int) -> dict:
         return (time.perf_counter() - t0) / steps
 
     out = {}
+
+    def guarded(name: str, fn) -> None:
+        # an optional mode that fails must not take the headline line down with it: record the error under its own key
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
+
+    def hyp_line(note: str, k_hyp: int = N_HYP) -> dict:
+        dt = timed(k_hyp)
+        return {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt, "note": note}
+
     for k in (1, 5):
-        dt = timed(k)
-        out[f"n_pose_hypotheses={k}"] = {"ms_per_call": dt * 1e3, "coarse_hypotheses_per_s": N_HYP / dt,
-                                         "note": "576 coarse rows + K x 5 refine rows + K score rows (megapose-1.0-RGB[-multi-hypothesis] defaults)"}
-    dt = timed(N_HYP)
-    out["without_event_profiler"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
-                                     "note": "the `value` workload without the per-launch HIP events the roofline figures need (two event records per "
-                                             "kernel launch inside the timed region cost the difference)"}
+        def released(k=k):
+            dt = timed(k)
+            return {"ms_per_call": dt * 1e3, "coarse_hypotheses_per_s": N_HYP / dt,
+                    "note": "576 coarse rows + K x 5 refine rows + K score rows (megapose-1.0-RGB[-multi-hypothesis] defaults)"}
+        guarded(f"n_pose_hypotheses={k}", released)
+    guarded("without_event_profiler", lambda: hyp_line(
+        "the `value` workload without the per-launch HIP events the roofline figures need (two event records per kernel launch inside "
+        "the timed region cost the difference)"))
     rend = est.coarse_model.renderer   # one renderer serves both models
-    rend.msaa = 1
-    dt = timed(N_HYP)
-    rend.msaa = 4
-    out["single_sample_renders"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
-                                    "note": "Panda3dBatchRenderer(msaa=1): one centre sample per pixel instead of the reference's 4x multisampling "
-                                            "(panda3d_scene_renderer.py:73-74); what the rasteriser's multisampling costs end to end; never `value`"}
-    est.n_streams = 3  # chunk interleave on 3 HIP streams: fills the tails of the conv grids and overlaps raster with MFMA work; not the
-    dt = timed(N_HYP)  # default because overlapping kernels distort the per-kernel event timing the roofline figures rest on
-    est.n_streams = 1
-    out["three_stream_interleave"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
-                                      "note": "same fp32 path, PoseEstimator.n_streams=3 (MP_N_STREAMS); not used for `value`"}
+
+    def single_sample():
+        rend.msaa = 1
+        try:
+            return hyp_line("Panda3dBatchRenderer(msaa=1): one centre sample per pixel instead of the reference's 4x multisampling "
+                            "(panda3d_scene_renderer.py:73-74); what the rasteriser's multisampling costs end to end; never `value`")
+        finally:
+            rend.msaa = 4
+    guarded("single_sample_renders", single_sample)
+
+    def streams3():
+        est.n_streams = 3  # chunk interleave on 3 HIP streams: fills the tails of the conv grids and overlaps raster with MFMA work; not
+        try:               # the default because overlapping kernels distort the per-kernel event timing the roofline figures rest on
+            return hyp_line("same fp32 path, PoseEstimator.n_streams=3 (MP_N_STREAMS); not used for `value`")
+        finally:
+            est.n_streams = 1
+    guarded("three_stream_interleave", streams3)
+
+    def fp16_renders():
+        est.render_dtype = torch.float16
+        try:
+            return hyp_line("optional mode (BASELINE.json configs[4] \"fp16 renders\"): the rasteriser launch stores the CNN input (renders + "
+                            "observation crop) as binary16 (MP_RASTER_F16), the stem convolution widens it on its way into LDS "
+                            "(mp_backbone_forward_f16); narrower than the reference's fp32 input -- never `value`")
+        finally:
+            est.render_dtype = torch.float32
+    guarded("fp16_renders", fp16_renders)
     for prec in (9, 6):
-        for m in (est.coarse_model, est.refiner_model):
-            m.conv_precision = prec
-            m._engine_bb = None
-        dt = timed(N_HYP)
-        out[f"conv_bf16x{prec}_split"] = {"ms_per_step": dt * 1e3, "pose_hypotheses_per_s": N_HYP / dt,
-                                          "note": "optional mode: fp32 operands split exactly into 3 bf16 pieces, bf16 MFMA, fp32 accumulate; "
-                                                  "narrower than the reference's fp32 when product terms are dropped (x6) -- never `value`"}
-    for m in (est.coarse_model, est.refiner_model):
-        m.conv_precision = 0
-        m._engine_bb = None
+        def split(prec=prec):
+            for m in (est.coarse_model, est.refiner_model):
+                m.conv_precision = prec
+                m._engine_bb = None
+            try:
+                return hyp_line("optional mode: fp32 operands split exactly into 3 bf16 pieces, bf16 MFMA, fp32 accumulate; narrower than "
+                                "the reference's fp32 when product terms are dropped (x6) -- never `value`")
+            finally:
+                for m in (est.coarse_model, est.refiner_model):
+                    m.conv_precision = 0
+                    m._engine_bb = None
+        guarded(f"conv_bf16x{prec}_split", split)
     return out
 
 
@@ -215,9 +247,10 @@ def build_workload(cfg_id: int, world: int, backbone: str, tmp: str, precision: 
         desc = f"configs[2]: megapose-1.0-RGBD structure ({backbone} coarse 9ch + RGBD refiner 32ch), {n_obj} objects x 576 hypotheses"
     elif cfg_id in (4, 5):
         n_obj = 64
-        est, obs, det, ds = make_multi_frame_scene(8, 8, 16, backbone=backbone, rgbd=(cfg_id == 5), **common)
+        # config 5 = the "...-RGB-multi-hypothesis-icp" recipe: RGB coarse + refiner, the frames' depth channel only feeds the depth refiner
+        est, obs, det, ds = make_multi_frame_scene(8, 8, 16, backbone=backbone, depth_obs=(cfg_id == 5), **common)
         desc = (f"configs[{cfg_id - 1}]: megapose-1.0-RGB-multi-hypothesis structure ({backbone}), 64 detections over 8 frames / 16 meshes x 576 "
-                "hypotheses" + (", + depth refiner (ICP) on the RGBD frames" if cfg_id == 5 else ""))
+                "hypotheses" + (", + depth refiner (ICP) on the frames' depth channel" if cfg_id == 5 else ""))
         if cfg_id == 5:
             from megapose6d_amd.icp_refiner import ICPRefiner
 
@@ -372,6 +405,22 @@ def main():
                            "all_gather_ms_per_step": gather_ms / a.steps}
         if world == 1 and a.config == 2 and not a.no_extras:
             out["extras"] = extras(est, obs, det, a.steps)
+        if world == 1 and a.config == 5 and not a.no_extras:   # the "fp16 renders" variant BASELINE.json names for this configuration
+            try:
+                est.render_dtype = torch.float16
+                step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    step()
+                torch.cuda.synchronize()
+                dt16 = (time.perf_counter() - t0) / a.steps
+                out["extras"] = {"fp16_renders": {"ms_per_step": dt16 * 1e3, "pose_hypotheses_per_s": n_obj * N_HYP / dt16,
+                                                  "note": "same workload with PoseEstimator.render_dtype = float16 (binary16 CNN input); never `value`"}}
+            except Exception as e:  # noqa: BLE001
+                out["extras"] = {"fp16_renders": {"error": f"{type(e).__name__}: {e}"[:300]}}
+            finally:
+                est.render_dtype = torch.float32
         if not a.no_cpu_baseline and world == 1 and a.config == 2 and k_hyp == N_HYP:
             cb = cpu_baseline(ds, obs.images, obs.K, det.bboxes)
             out["parity"] = parity_block(cb.pop("_values"), extra)

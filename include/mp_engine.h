@@ -103,6 +103,12 @@ float mp_mesh_db_radius(const mp_mesh_db* db, int mesh_id);
                                      standard 4-sample pattern, shading once per (pixel, piece) at the pixel centre, 8-bit
                                      per-sample colours averaged; without the flag: one sample at the pixel centre          */
 
+#define MP_RASTER_F16 32u          /* "fp16 renders" (BASELINE.json configs[4]; the reference's output path, panda3d_batch_renderer.py:
+                                     261-274, converts uint8 -> fp32): d_out points at IEEE binary16 elements instead of floats --
+                                     same ELEMENT strides and channel numbers, every written channel (renders and, with
+                                     mp_raster_render_crop, the observation crop) rounded to nearest-even.  The consumer is
+                                     mp_backbone_forward_f16 / mp_conv_desc.x_f16.                                              */
+
 typedef struct {
   float ambient[3];        /* sum of ambient light colours                                  */
   int32_t n_point;         /* number of point lights (<= 8)                                 */
@@ -161,6 +167,9 @@ int mp_crop_roi_align(const float* d_images /*[n_im,C,H,W] NCHW*/, int n_im, int
 /* ------------------------------------------------------------------------------------ */
 int mp_normalize_depth(float* d_x, int b, int h, int w, int border, int C, const int32_t* h_channels,
                        int n_ch, const float* d_tCR /*[b,3]*/, int mode, mp_stream stream);
+/* the same on a half-precision padded-NHWC tensor (MP_RASTER_F16 output): read, normalise in fp32, round back to binary16 */
+int mp_normalize_depth_f16(void* d_x_half, int b, int h, int w, int border, int C, const int32_t* h_channels,
+                           int n_ch, const float* d_tCR /*[b,3]*/, int mode, mp_stream stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Convolution stack: replaces `self.backbone(x)` (models/pose_rigid.py:323) for           */
@@ -190,6 +199,9 @@ typedef struct {
   int32_t c_real;          /* real (unpadded) input channels, for the profiler's algorithmic FLOP count; 0 = C   */
   float* d_splitk_ws;      /* optional scratch: with it, launches whose tile grid cannot fill the chip (small batches) split  */
   int64_t splitk_ws_floats;/* the K loop over several workgroups and reduce deterministically (fixed order); NULL = never    */
+  int32_t x_f16;           /* != 0: d_x holds IEEE binary16 values in the same padded-NHWC geometry (what MP_RASTER_F16 writes);    */
+                           /* the kernel widens them to fp32 on the way into LDS, arithmetic and outputs stay fp32.  Cout <= 64     */
+                           /* (the stem convolutions) and mp_conv2d_nhwc only (not the bf16 split modes)                            */
 } mp_conv_desc;
 
 int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);
@@ -254,6 +266,12 @@ int mp_backbone_workspace_reset(mp_backbone* bb, const void* d_workspace);
 int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out,
                         float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
                         mp_stream stream);
+/* the same forward on a half-precision input tensor (binary16 elements, same padded-NHWC geometry: what the rasteriser writes  */
+/* with MP_RASTER_F16).  Only the stem convolution differs (it widens the halves on their way into LDS); native fp32 backbones  */
+/* only (precision 0).                                                                                                          */
+int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, int h, int w, float* d_out,
+                            float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
+                            mp_stream stream);
 /* algorithmic conv+fc FLOPs of one forward at this batch (2*MACs, real channels only)       */
 double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w);
 

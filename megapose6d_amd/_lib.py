@@ -56,6 +56,7 @@ class ConvDesc(C.Structure):
         ("c_real", C.c_int32),
         ("d_splitk_ws", C.c_void_p),
         ("splitk_ws_floats", C.c_int64),
+        ("x_f16", C.c_int32),
     ]
 
 
@@ -88,6 +89,7 @@ SIGNATURES = {
     "mp_pack_observation_nhwc4": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mp_crop_roi_align": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _i, _vp]),
     "mp_normalize_depth": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),
+    "mp_normalize_depth_f16": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),
     "mp_conv_packed_floats": (_sz, [_i, _i, _i, _i]),
     "mp_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
@@ -106,6 +108,7 @@ SIGNATURES = {
     "mp_backbone_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "mp_backbone_workspace_reset": (_i, [_vp, _vp]),
     "mp_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_backbone_forward_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_flops": (C.c_double, [_vp, _i, _i, _i]),
     "mp_normalize_T": (_i, [_vp, _i, _vp, _vp]),
     "mp_init_extents": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

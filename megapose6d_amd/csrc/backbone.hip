@@ -134,9 +134,10 @@ int make_bnact(mp_backbone* bb, const StateMap& sm, const std::string& bnkey, in
 constexpr size_t SPLITK_WS_FLOATS = 12u << 20;  // 48 MB of split-K scratch at the end of the workspace (>= 512 tiles of 128 x 128)
 
 int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, int H, int W, int in_border, float* y, int out_border,
-             const float* res, int relu, float* y_act, const BnAct* act, hipStream_t s, float* splitk_ws = nullptr) {
+             const float* res, int relu, float* y_act, const BnAct* act, hipStream_t s, float* splitk_ws = nullptr, bool x_f16 = false) {
   mp_conv_desc d;
   memset(&d, 0, sizeof(d));
+  d.x_f16 = x_f16 ? 1 : 0;
   d.d_x = x; d.N = N; d.H = H; d.W = W; d.C = L.Cin_p; d.c_real = L.Cin; d.in_border = in_border;
   d.d_w = L.d_w; d.d_bias = L.d_b; d.Cout = L.Cout; d.KH = L.K; d.KW = L.K; d.stride = L.stride; d.pad = L.pad;
   d.d_y = y; d.out_border = out_border; d.d_residual = res; d.relu = relu;
@@ -277,9 +278,10 @@ extern "C" int mp_backbone_workspace_reset(mp_backbone* bb, const void* d_ws) {
   return MP_OK;
 }
 
-extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out, float* d_sigmoid,
-                                   float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, int batch, int h, int w, float* d_out, float* d_sigmoid,
+                                 float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
   MP_REQUIRE(bb && d_x && d_out && d_ws, "mp_backbone_forward: null pointer");
+  MP_REQUIRE(!x_f16 || bb->precision == 0, "mp_backbone_forward_f16: half-precision inputs need a native fp32 backbone (precision 0)");
   if (batch == 0) return MP_OK;
   const size_t need = mp_backbone_workspace_bytes(bb, batch, h, w);
   MP_REQUIRE(ws_bytes >= need, "mp_backbone_forward: workspace %zu < %zu bytes", ws_bytes, need);
@@ -308,7 +310,7 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
   float* SK = p;  // split-K scratch (SPLITK_WS_FLOATS)
   int rc;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
-  rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK);
+  rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
   if (rc) return rc;
   const Block& b0 = bb->blocks[0];
   rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, 64, 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
@@ -350,6 +352,16 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
   }
   return mp_pool_fc_heads(A[3], batch, g.hs[3], g.ws[3], 512, 1, bb->d_fc_w, bb->d_fc_b, 512, bb->d_head_w, bb->d_head_b, bb->n_out,
                           d_feat, d_out, d_sigmoid, s);
+}
+
+extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out, float* d_sigmoid,
+                                   float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  return backbone_forward_impl(bb, d_x, false, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+}
+
+extern "C" int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, int h, int w, float* d_out, float* d_sigmoid,
+                                       float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  return backbone_forward_impl(bb, (const float*)d_x_half, true, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
 }
 
 extern "C" double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w) {

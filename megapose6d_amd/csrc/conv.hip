@@ -144,7 +144,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
 // VARIANT: 1 = the LDS store of the next chunk sits under the LAST MFMA group, | 256 = under the 3rd of 4; | 4096 = the two-chunks-ahead
 // pipeline (barrier before the last group); | 8192 = buffer loads (scalar resource + 32-bit offsets) instead of global loads.
-template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, bool SPLITK = false>
+// AHALF: the INPUT tensor holds IEEE binary16 values (the "fp16 renders" CNN input the rasteriser writes with MP_RASTER_F16): the A
+// tile is fetched as 8-byte pieces (4 halves), stays packed in registers across the MFMA block and is widened to fp32 on its way
+// into LDS -- everything after the LDS store (fragments, MFMA, epilogue) is the fp32 path unchanged.
+template <int BM, int BN, int WM, int WN, int VARIANT = 0, bool RAGGED = false, bool SPLITK = false, bool AHALF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_f32_mfma(ConvParams p) {
   constexpr int NBUF = 2;
   constexpr int LDT = LDS_LD;
@@ -208,7 +211,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // with 64-bit lane addresses.  The A resource starts at the tile's first pixel (addresses ascend with the row index, the tile spans
   // a few image rows), the B resource at this n-block's packed weights; neither range check can trigger (num_records = 2^32 - 1).
   constexpr bool BUFLD = (VARIANT & 8192) != 0;
+  static_assert(!AHALF || BUFLD, "the half-precision input path is written for the buffer-load variants");
+  constexpr int A_ES = AHALF ? 2 : 4;   // bytes per input element
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   int a_voff[A_LD4] = {0, 0, 0, 0};
   int b_voff = 0;
   __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
@@ -219,11 +226,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ho = t % p.Ho;
     const int n = t / p.Ho;
     const size_t pix = ((size_t)n * p.Hp + (size_t)(ho * p.stride + p.in_off)) * p.Wp + (size_t)(wo * p.stride + p.in_off);
-    const float* a_base = p.x + pix * p.C;
-    a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, -1, 0x00020000);
+    const float* a_base = p.x + pix * p.C;   // (AHALF: p.x really points at halves; a_ptr / a_base only serve as element counters)
+    if constexpr (AHALF)
+      a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const _Float16*>(p.x) + pix * p.C), 0, -1, 0x00020000);
+    else
+      a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, -1, 0x00020000);
     b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)nblk * p.n_chunks * (BN * BK)), 0, -1, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < A_LD4; ++i) a_voff[i] = (int)((a_ptr[i] - a_base) * 4);
+    for (int i = 0; i < A_LD4; ++i) a_voff[i] = (int)((a_ptr[i] - a_base) * A_ES);
     b_voff = ((tid >> 3) * BK + a_col) * 4;
   }
   const int row_stride = p.Wp * p.C;  // floats between successive kh rows
@@ -247,13 +257,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define MP_CONV_LOAD(AOFF, BP)                                                                                     \
   if constexpr (BUFLD) {                                                                                           \
     /* RAGGED: the run position is per lane (vector offset); otherwise only a_col is, the rest rides in the scalar offset */ \
-    const int av_ = RAGGED ? (AOFF) * 4 : a_col * 4;                                                               \
-    const int as_ = RAGGED ? 0 : a_su * 4;   /* a_su / b_su: the wave-uniform parts of AOFF / BP, tracked separately */ \
+    const int av_ = RAGGED ? (AOFF) * A_ES : a_col * A_ES;                                                         \
+    const int as_ = RAGGED ? 0 : a_su * A_ES;   /* a_su / b_su: the wave-uniform parts of AOFF / BP, tracked separately */ \
     const int bs_ = b_su * 4;                                                                                      \
-    a0 = MP_BUF4(a_rsrc, a_voff[0] + av_, as_);                                                                    \
-    a1 = MP_BUF4(a_rsrc, a_voff[1] + av_, as_);                                                                    \
-    a2 = MP_BUF4(a_rsrc, a_voff[2] + av_, as_);                                                                    \
-    a3 = MP_BUF4(a_rsrc, a_voff[3] + av_, as_);                                                                    \
+    if constexpr (AHALF) {   /* 4 halves per lane and tile row: widened when they are written to LDS */            \
+      ah0 = __builtin_amdgcn_raw_buffer_load_b64(a_rsrc, a_voff[0] + av_, as_, 0);                                 \
+      ah1 = __builtin_amdgcn_raw_buffer_load_b64(a_rsrc, a_voff[1] + av_, as_, 0);                                 \
+      ah2 = __builtin_amdgcn_raw_buffer_load_b64(a_rsrc, a_voff[2] + av_, as_, 0);                                 \
+      ah3 = __builtin_amdgcn_raw_buffer_load_b64(a_rsrc, a_voff[3] + av_, as_, 0);                                 \
+    } else {                                                                                                       \
+      a0 = MP_BUF4(a_rsrc, a_voff[0] + av_, as_);                                                                  \
+      a1 = MP_BUF4(a_rsrc, a_voff[1] + av_, as_);                                                                  \
+      a2 = MP_BUF4(a_rsrc, a_voff[2] + av_, as_);                                                                  \
+      a3 = MP_BUF4(a_rsrc, a_voff[3] + av_, as_);                                                                  \
+    }                                                                                                              \
     b0 = MP_BUF4(b_rsrc, b_voff, bs_);                                                                             \
     b1 = MP_BUF4(b_rsrc, b_voff, bs_ + 4096);                                                                      \
     if constexpr (B_LD4 > 2) {                                                                                     \
@@ -273,10 +290,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }                                                                                                              \
   }
 #define MP_ST4(P, V) (*reinterpret_cast<float4*>(P) = (V))
+#define MP_H4(V) ([&] { const f16x4 h_ = __builtin_bit_cast(f16x4, V);                                             \
+    return make_float4((float)h_.x, (float)h_.y, (float)h_.z, (float)h_.w); }())
 #define MP_CONV_STORE(BUF)                                                        \
   {                                                                               \
     float* as_w = As + (BUF) * BM * LDT + a_r0 * LDT + a_c4 * 4;            \
     float* bs_w = Bs + (BUF) * BN * LDT + (tid >> 3) * LDT + (tid & 7) * 4; \
+    if constexpr (AHALF) {                                                        \
+      a0 = MP_H4(ah0);                                                            \
+      a1 = MP_H4(ah1);                                                            \
+      a2 = MP_H4(ah2);                                                            \
+      a3 = MP_H4(ah3);                                                            \
+    }                                                                             \
     MP_ST4(as_w, a0);                                                             \
     MP_ST4(as_w + 32 * LDT, a1);                                               \
     MP_ST4(as_w + 64 * LDT, a2);                                               \
@@ -294,6 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* a_ptr2 = a_ptr[2];
   const float* a_ptr3 = a_ptr[3];
   float4 a0, a1, a2, a3, b0, b1, b2, b3;
+  u32x2 ah0, ah1, ah2, ah3;   // AHALF: the packed halves of the prefetched A pieces
 
   // per-thread position of its float4 inside the concatenated K axis: j = offset in the current kernel row's run,
   // aoff = element offset from the pixel's first tap (run % 4 == 0, so a float4 never straddles two rows)
@@ -469,6 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef MP_CONV_LOAD
 #undef MP_BUF4
 #undef MP_CONV_STORE
+#undef MP_H4
 #undef MP_CONV_ADVANCE
 #undef MP_LD4
 #undef MP_ST4
@@ -572,7 +599,7 @@ static int launch_splitk(const ConvParams& p, hipStream_t s, double alg_k) {
   return MP_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false>
+template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false, bool AHALF = false>
 static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_main = 0) {
   ConvParams q = p;
   q.n_mblocks = ceil_div(p.M, BM);
@@ -585,7 +612,7 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   const size_t lds = (size_t)(NBUF * BM * LDT + NBUF * BN * LDT) * sizeof(float) + BM * sizeof(int) + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>,
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED, false, AHALF>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -596,6 +623,7 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   // algorithmic work of this launch: 2*MACs over the REAL (unpadded) reduction length; bytes = input + weights + output once
   static const bool detail = getenv("MP_PROF_DETAIL") != nullptr;  // tuning aid: one profiler row per layer shape
   const char* pname = BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>";
+  if (AHALF) pname = "conv_nhwc_f32_mfma<128,64,64,32>/x_f16";   // own profiler row: never mixed into the fp32 kernels' roofline figures
   if (detail) {
     static std::vector<std::string> names;  // stable storage for the profiler's name pointers
     char buf[96];
@@ -605,8 +633,8 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
     if (!found) { names.reserve(64); names.emplace_back(buf); pname = names.back().c_str(); }
   }
   ProfScope prof(pname, 2.0 * m_here * p.Cout * alg_k,
-                 4.0 * (m_here * p.stride * p.stride * p.C + (double)p.n_chunks * BK * p.Cout + m_here * p.Cout), s);
-  hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED>), grid, dim3(256), lds, s, q);
+                 (AHALF ? 2.0 : 4.0) * m_here * p.stride * p.stride * p.C + 4.0 * ((double)p.n_chunks * BK * p.Cout + m_here * p.Cout), s);
+  hipLaunchKernelGGL((conv_nhwc_f32_mfma<BM, BN, WM, WN, VARIANT, RAGGED, false, AHALF>), grid, dim3(256), lds, s, q);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
@@ -778,6 +806,10 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
   const double alg_k = (double)d->KH * d->KW * (d->c_real > 0 ? d->c_real : d->C);
   static const int variant = getenv("MP_CONV_VARIANT") ? atoi(getenv("MP_CONV_VARIANT")) : 8449;  // default: buffer loads, LDS store under the 3rd of 4 MFMA groups; others = A/B timing
   const bool small = conv_bn_tile(d->Cout) == 64;
+  if (d->x_f16) {   // half-precision input (the stems of the "fp16 renders" mode): single-pass launches of the 128x64 tile only
+    MP_REQUIRE(small, "mp_conv2d_nhwc: x_f16 is implemented for Cout <= 64 (the stem convolutions), got Cout = %d", d->Cout);
+    return p.run % BK != 0 ? launch<128, 64, 64, 32, 8449, true, true>(p, s, alg_k) : launch<128, 64, 64, 32, 8449, false, true>(p, s, alg_k);
+  }
   static const int splitk_on = getenv("MP_CONV_SPLITK") ? atoi(getenv("MP_CONV_SPLITK")) : 1;
   static const int tail_on = getenv("MP_CONV_TAIL") ? atoi(getenv("MP_CONV_TAIL")) : 1;
   static int resident = 0;
@@ -820,7 +852,8 @@ extern "C" int mp_conv2d_plan(const mp_conv_desc* d, int n_cu, int32_t* out5) {
   ConvParams p;
   int rc = make_params(d, &p);
   if (rc) return rc;
-  const ConvPlan pl = plan_conv(p, conv_bn_tile(d->Cout) == 64, d->d_splitk_ws ? d->splitk_ws_floats : 0, 2 * n_cu, true, true);
+  ConvPlan pl = plan_conv(p, conv_bn_tile(d->Cout) == 64, d->d_splitk_ws ? d->splitk_ws_floats : 0, 2 * n_cu, true, true);
+  if (d->x_f16) pl = ConvPlan{0, 1, p.n_chunks, 0, 0};   // half-precision inputs always run as one single-pass launch
   out5[0] = pl.mode; out5[1] = pl.k_split; out5[2] = pl.chunks_per_split; out5[3] = pl.n_main; out5[4] = pl.m_begin;
   return MP_OK;
 }

@@ -357,6 +357,7 @@ extern "C" int mp_conv2d_nhwc_split(const mp_conv_desc* d, int n_products, mp_st
   MP_REQUIRE(d && d->d_x && d->d_w && (d->d_y || d->d_y_act), "mp_conv2d_nhwc_split: null pointer");
   MP_REQUIRE(d->C % 4 == 0 && d->in_border >= d->pad && (n_products == 9 || n_products == 6), "mp_conv2d_nhwc_split: bad arguments");
   MP_REQUIRE(!d->d_y_act || (d->d_act_scale && d->d_act_shift), "mp_conv2d_nhwc_split: y_act needs scale/shift");
+  MP_REQUIRE(!d->x_f16, "mp_conv2d_nhwc_split: half-precision inputs (x_f16) are implemented by mp_conv2d_nhwc only");
   const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
   const long M = (long)d->N * Ho * Wo;
   MP_REQUIRE(M > 0 && M < (1L << 31) && (long)d->N * (Ho + 2 * d->out_border) * (Wo + 2 * d->out_border) * d->Cout < (1L << 31),

@@ -44,20 +44,22 @@ __global__ void pack_nhwc4_kernel(const float* __restrict__ in, int C, int HW, f
   out[(size_t)im * HW + i] = v;
 }
 
-__global__ void normalize_depth_kernel(float* __restrict__ x, int h, int w, int border, int C, int ch,
+// T = float, or _Float16 for the half-precision CNN input of the "fp16 renders" mode (value read, normalised in fp32, rounded back)
+template <typename T>
+__global__ void normalize_depth_kernel(T* __restrict__ x, int h, int w, int border, int C, int ch,
                                        const float* __restrict__ tCR, int mode) {
   const int row = blockIdx.y;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= h * w) return;
   const int py = pix / w, px = pix % w;
   const int Wp = w + 2 * border, Hp = h + 2 * border;
-  float* p = x + (((size_t)row * Hp + py + border) * Wp + px + border) * C + ch;
+  T* p = x + (((size_t)row * Hp + py + border) * Wp + px + border) * C + ch;
   const float zr = tCR[3 * row + 2];
-  float d = *p;
+  float d = (float)*p;
   if (mode == 1) d = d / zr;
   else if (mode == 2) d = fminf(fmaxf(d / zr, 0.f), 2.f) - 1.f;
   else if (mode == 3) d = fminf(fmaxf(d - zr, -2.f), 2.f);
-  *p = d;
+  *p = (T)d;
 }
 
 }  // namespace mp
@@ -84,17 +86,32 @@ extern "C" int mp_crop_roi_align(const float* d_images, int n_im, int C, int H, 
   return MP_OK;
 }
 
-extern "C" int mp_normalize_depth(float* d_x, int b, int h, int w, int border, int C, const int32_t* h_channels, int n_ch,
-                                  const float* d_tCR, int mode, mp_stream stream) {
+static int normalize_depth_impl(void* d_x, bool f16, int b, int h, int w, int border, int C, const int32_t* h_channels, int n_ch,
+                                const float* d_tCR, int mode, mp_stream stream) {
   MP_REQUIRE(d_x && d_tCR && (n_ch == 0 || h_channels), "mp_normalize_depth: null pointer");
   MP_REQUIRE(mode >= 0 && mode <= 3, "mp_normalize_depth: unknown mode %d", mode);
   if (mode == 0 || b == 0) return MP_OK;
   dim3 grid(ceil_div((long)h * w, 256), b);
-  for (int i = 0; i < n_ch; ++i)
-    hipLaunchKernelGGL(normalize_depth_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_x, h, w, border, C, h_channels[i],
-                       d_tCR, mode);
+  for (int i = 0; i < n_ch; ++i) {
+    if (f16)
+      hipLaunchKernelGGL(normalize_depth_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (_Float16*)d_x, h, w, border, C,
+                         h_channels[i], d_tCR, mode);
+    else
+      hipLaunchKernelGGL(normalize_depth_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (float*)d_x, h, w, border, C,
+                         h_channels[i], d_tCR, mode);
+  }
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
+}
+
+extern "C" int mp_normalize_depth(float* d_x, int b, int h, int w, int border, int C, const int32_t* h_channels, int n_ch,
+                                  const float* d_tCR, int mode, mp_stream stream) {
+  return normalize_depth_impl(d_x, false, b, h, w, border, C, h_channels, n_ch, d_tCR, mode, stream);
+}
+
+extern "C" int mp_normalize_depth_f16(void* d_x_half, int b, int h, int w, int border, int C, const int32_t* h_channels, int n_ch,
+                                      const float* d_tCR, int mode, mp_stream stream) {
+  return normalize_depth_impl(d_x_half, true, b, h, w, border, C, h_channels, n_ch, d_tCR, mode, stream);
 }
 
 extern "C" int mp_pack_observation_nhwc4(const float* d_images, int n_im, int C, int H, int W, float* d_out, mp_stream stream) {

@@ -366,7 +366,9 @@ __device__ __forceinline__ ViewHdr load_view_hdr(const int* __restrict__ ws, con
   return v;
 }
 
-template <int NS>
+// F16 (MP_RASTER_F16, the "fp16 renders" mode of BASELINE.json configs[4]): `out` holds IEEE binary16 elements -- same element
+// strides, every written channel (renders and the fused crop) is rounded to nearest-even on its way out; nothing else changes.
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(MP_RASTER_WAVES, MP_RASTER_WAVES))) void raster_tiles(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
@@ -563,15 +565,26 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   wave_lds_fence();
   PROF(7)
   // ---- store: each of the tile's 8 rows leaves as one contiguous run of 8 pixels x `run` channels (only written channels) -------
-  float* out_item = out + (size_t)item * stride_v + c_lo;
   const int cols = min(TILE, w - tile_x0), rows = min(TILE, h - tile_y0);
   const int per_row = cols * run;   // <= 256 floats
+  if constexpr (F16) {
+    _Float16* out_item = reinterpret_cast<_Float16*>(out) + (size_t)item * stride_v + c_lo;
+    for (int i = lane; i < per_row; i += 64) {
+      const int x = i / run, c = i - x * run;
+      if (!((run_mask >> c) & 1u)) continue;
+      _Float16* o = out_item + (size_t)tile_y0 * stride_y + (size_t)(tile_x0 + x) * stride_x + c;
+      const float* sp = stage + (size_t)x * run + c;
+      for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = (_Float16)sp[(size_t)row * 8 * run];   // v_cvt_f16_f32: round to nearest even
+    }
+  } else {
+  float* out_item = out + (size_t)item * stride_v + c_lo;
   for (int i = lane; i < per_row; i += 64) {
     const int x = i / run, c = i - x * run;   // once per lane and 64-float slice, reused for all 8 rows
     if (!((run_mask >> c) & 1u)) continue;
     float* o = out_item + (size_t)tile_y0 * stride_y + (size_t)(tile_x0 + x) * stride_x + c;
     const float* sp = stage + (size_t)x * run + c;
     for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = sp[(size_t)row * 8 * run];
+  }
   }
   PROF(8)
   PROF_FLUSH
@@ -717,7 +730,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
   MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && h <= 1024 && views_per_item >= 1, "mp_raster_render: bad size");
   MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
-  MP_REQUIRE((flags & ~(MP_RASTER_NORMALS | MP_RASTER_DEPTH | MP_RASTER_NORMALS_GL | MP_RASTER_MSAA4)) == 0, "mp_raster_render: unknown flag bits 0x%x", flags);
+  MP_REQUIRE((flags & ~(MP_RASTER_NORMALS | MP_RASTER_DEPTH | MP_RASTER_NORMALS_GL | MP_RASTER_MSAA4 | MP_RASTER_F16)) == 0,
+             "mp_raster_render: unknown flag bits 0x%x", flags);
   if (n_views == 0) return MP_OK;
   MP_REQUIRE(ws_bytes >= mp_raster_workspace_bytes(db, n_views, h, w), "mp_raster_render: workspace too small");
   MP_REQUIRE(n_views % views_per_item == 0, "mp_raster_render: n_views (%d) must be a multiple of views_per_item (%d)", n_views, views_per_item);
@@ -770,10 +784,21 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
-  const double crop_bytes = crop.images ? (double)n_items * 2.0 * crop.C * 4.0 * h * w : 0.0;
-  ProfScope prof("raster_tiles", 0.0,
-                 (double)n_views * ((double)n_ch * 4.0 * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) + crop_bytes, s);
-  if (ns == 4)
+  const bool f16 = (flags & MP_RASTER_F16) != 0;
+  const double out_es = f16 ? 2.0 : 4.0;   // bytes per output element
+  ProfScope prof(f16 ? "raster_tiles/f16" : "raster_tiles", 0.0,
+                 (double)n_views * ((double)n_ch * out_es * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) +
+                     (crop.images ? (double)n_items * crop.C * (out_es + 4.0) * h * w : 0.0), s);   // crop: C channels written + <= the same-sized fp32 source window read
+  if (f16) {
+    if (ns == 4)
+      hipLaunchKernelGGL((raster_tiles<4, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO,
+                         d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
+                         (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
+    else
+      hipLaunchKernelGGL((raster_tiles<1, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO,
+                         d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
+                         (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
+  } else if (ns == 4)
     hipLaunchKernelGGL(raster_tiles<4>, dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, d_K,
                        (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
                        (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);

@@ -19,6 +19,7 @@ RASTER_NORMALS = 1
 RASTER_DEPTH = 2
 RASTER_NORMALS_GL = 4
 RASTER_MSAA4 = 16   # 4x multisampling = the reference renderer's configuration (panda3d_scene_renderer.py:73-74)
+RASTER_F16 = 32     # "fp16 renders": the output tensor holds binary16 elements (set from `out.dtype`, never by hand)
 
 BACKBONE_KINDS = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2}
 
@@ -174,7 +175,8 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
                   lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
                   c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0, slot: int = 0,
                   crop=None) -> None:
-    """Render n views into `out` (float32 device tensor) at the given element strides.
+    """Render n views into `out` (float32 or float16 device tensor) at the given ELEMENT strides / offset; a float16 `out`
+    selects MP_RASTER_F16 (values rounded to nearest-even binary16 as they are stored -- the "fp16 renders" mode).
     crop = (images [n_im,C,H,W], im_ids [n_items], boxes [n_items,4], c0): also roi_align-crop every item's observation into channels
     c0.. of its pixels in the same launch (mp_raster_render_crop)."""
     lib = _lib.load()
@@ -182,7 +184,9 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     mesh_ids = _dev_i32(mesh_ids)
     TCO = _dev_f32(TCO)
     K = _dev_f32(K)
-    assert out.dtype == torch.float32 and out.is_cuda
+    assert out.dtype in (torch.float32, torch.float16) and out.is_cuda
+    es = out.element_size()
+    flags = (flags | RASTER_F16) if out.dtype == torch.float16 else (flags & ~RASTER_F16)
     ws = db.workspace(n, h, w, out.device, slot)
     if crop is not None:
         images, im_ids, boxes, c0 = crop
@@ -195,12 +199,12 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
         im_ids, boxes = _dev_i32(im_ids), _dev_f32(boxes)
         assert boxes.shape[0] * views_per_item == n and im_ids.shape[0] == boxes.shape[0]
         check(lib.mp_raster_render_crop(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
-                                        out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x,
+                                        out.data_ptr() + es * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x,
                                         c_rgb, c_normals, c_depth, ws.data_ptr(), ws.numel(), images.data_ptr(), nhwc4, n_im, Cc, H, W,
                                         im_ids.data_ptr(), boxes.data_ptr(), c0, _stream()))
         return
     check(lib.mp_raster_render(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
-                               out.data_ptr() + 4 * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x, c_rgb,
+                               out.data_ptr() + es * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x, c_rgb,
                                c_normals, c_depth, ws.data_ptr(), ws.numel(), _stream()))
 
 
@@ -218,19 +222,22 @@ def normalize_depth(x: torch.Tensor, b: int, h: int, w: int, border: int, Cp: in
                     mode: int) -> None:
     lib = _lib.load()
     ch = (C.c_int32 * len(channels))(*channels)
-    check(lib.mp_normalize_depth(x.data_ptr(), b, h, w, border, Cp, ch, len(channels), _dev_f32(tCR).data_ptr(), mode, _stream()))
+    fn = lib.mp_normalize_depth_f16 if x.dtype == torch.float16 else lib.mp_normalize_depth
+    check(fn(x.data_ptr(), b, h, w, border, Cp, ch, len(channels), _dev_f32(tCR).data_ptr(), mode, _stream()))
 
 
 DEPTH_NORM_MODES = {None: 0, "none": 0, "tCR_scale": 1, "tCR_scale_clamp_center": 2, "tCR_center_clamp": 3}
 
 
 # --------------------------------------------------------------------------- #
-def padded_nhwc(n: int, h: int, w: int, c: int, border: int, device, slack: Optional[int] = None) -> torch.Tensor:
+def padded_nhwc(n: int, h: int, w: int, c: int, border: int, device, slack: Optional[int] = None,
+                dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """Zero-initialised flat buffer holding a padded-NHWC tensor + read slack: the conv's last 32-float K chunk may run
-    past the kernel window into the next padded row (its weights are zero there, the memory only has to be readable)."""
+    past the kernel window into the next padded row (its weights are zero there, the memory only has to be readable).
+    dtype float16 = the half-precision CNN input of the "fp16 renders" mode (same element geometry)."""
     if slack is None:
         slack = (w + 2 * border) * c + 64
-    return torch.zeros(n * (h + 2 * border) * (w + 2 * border) * c + slack, dtype=torch.float32, device=device)
+    return torch.zeros(n * (h + 2 * border) * (w + 2 * border) * c + slack, dtype=dtype, device=device)
 
 
 def padded_view(buf: torch.Tensor, n: int, h: int, w: int, c: int, border: int) -> torch.Tensor:
@@ -255,9 +262,12 @@ def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int
                 residual: Optional[torch.Tensor] = None, relu: bool = False, y_act: Optional[torch.Tensor] = None,
                 act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None, split_products: int = 0,
                 splitk_ws: Optional[torch.Tensor] = None) -> None:
-    """`splitk_ws` (fp32 scratch): lets launches whose tile grid cannot fill the chip split the K loop (deterministic two-pass)"""
+    """`splitk_ws` (fp32 scratch): lets launches whose tile grid cannot fill the chip split the K loop (deterministic two-pass).
+    A float16 `x` (same padded-NHWC geometry) selects the half-precision input path (mp_conv_desc.x_f16; Cout <= 64 only)."""
     lib = _lib.load()
     d = ConvDesc()
+    assert x.dtype in (torch.float32, torch.float16)
+    d.x_f16 = int(x.dtype == torch.float16)
     if splitk_ws is not None:
         d.d_splitk_ws, d.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
     d.d_x, d.N, d.H, d.W, d.C, d.in_border = x.data_ptr(), N, H, W, Cp, in_border
@@ -272,10 +282,11 @@ def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int
 
 
 def conv2d_plan(N: int, H: int, W: int, Cp: int, in_border: int, Cout: int, K: int, stride: int, pad: int, n_cu: int,
-                ws_floats: int = 0) -> Dict[str, int]:
+                ws_floats: int = 0, x_f16: bool = False) -> Dict[str, int]:
     """How mp_conv2d_nhwc would lay this launch out on `n_cu` CUs (host-only, no GPU work): mode 0 single pass, 1 every tile
-    split along K, 2 full rounds + split-K tail."""
+    split along K, 2 full rounds + split-K tail (half-precision inputs always run single pass)."""
     d = ConvDesc()
+    d.x_f16 = int(x_f16)
     dummy = 0x1000  # the planner only tests pointers for NULL
     d.d_x, d.N, d.H, d.W, d.C, d.in_border = dummy, N, H, W, Cp, in_border
     d.d_w, d.Cout, d.KH, d.KW, d.stride, d.pad = dummy, Cout, K, K, stride, pad
@@ -351,8 +362,9 @@ class Backbone:
     def forward(self, x: torch.Tensor, batch: int, h: int, w: int, out: torch.Tensor, sigmoid: Optional[torch.Tensor] = None,
                 feat: Optional[torch.Tensor] = None, slot: int = 0) -> None:
         ws = self.workspace(batch, h, w, x.device, slot)
-        check(_lib.load().mp_backbone_forward(self.handle, x.data_ptr(), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat),
-                                              ws.data_ptr(), ws.numel(), _stream()))
+        assert x.dtype in (torch.float32, torch.float16)
+        fn = _lib.load().mp_backbone_forward_f16 if x.dtype == torch.float16 else _lib.load().mp_backbone_forward
+        check(fn(self.handle, x.data_ptr(), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()))
 
     def close(self):
         if getattr(self, "handle", None):

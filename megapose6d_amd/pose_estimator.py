@@ -117,6 +117,19 @@ class PoseEstimator(torch.nn.Module):
         self._SO3_grid = load_SO3_grid(grid_size).cuda()
         self._extents = None
 
+    @property
+    def render_dtype(self) -> torch.dtype:
+        """torch.float32 (reference arithmetic, default) or torch.float16 = the "fp16 renders" mode of BASELINE.json configs[4]: both
+        pose models store their CNN input (renders + observation crop) as binary16 (`PosePredictor.render_dtype`)."""
+        m = self.refiner_model if self.refiner_model is not None else self.coarse_model
+        return getattr(m, "render_dtype", torch.float32)
+
+    @render_dtype.setter
+    def render_dtype(self, dtype: torch.dtype) -> None:
+        for m in (self.coarse_model, self.refiner_model):
+            if m is not None:
+                m.render_dtype = dtype
+
     # -- helpers -------------------------------------------------------------------------------------------------
     def _chunk(self, reference_bsz: int) -> int:
         return reference_bsz if self.strict_batching else max(self.max_rows_per_launch, 1)

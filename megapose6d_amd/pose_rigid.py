@@ -151,6 +151,10 @@ class PosePredictor(nn.Module):
         self.debug_data = SimpleNamespace(output=None, images=None, origin_uv=None, ref_point_uv=None, origin_uv_crop=None,
                                           pose_predictor_outputs=None)
         self._engine_bb: Optional[eng.Backbone] = None
+        # torch.float16 = the "fp16 renders" mode (BASELINE.json configs[4]): the rasteriser launch stores the whole CNN input
+        # (renders + observation crop) as binary16 and the stem convolution widens it on its way into LDS; half the bytes of the
+        # largest tensor of a step.  Narrower than the reference (fp32 inputs, models/pose_rigid.py:567): off by default.
+        self.render_dtype: torch.dtype = torch.float32
         self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
         self._x_rows: Dict[int, int] = {}
         self._label_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -171,10 +175,14 @@ class PosePredictor(nn.Module):
     def _x_buffer(self, rows: int, device, slot: int = 0) -> torch.Tensor:
         bb = self._backbone_engine()
         h, w = self.render_size
+        if self.render_dtype not in (torch.float32, torch.float16):
+            raise ValueError(f"render_dtype must be torch.float32 or torch.float16, got {self.render_dtype}")
+        if self.render_dtype == torch.float16 and int(getattr(self, "conv_precision", 0)) != 0:
+            raise NotImplementedError("render_dtype=float16 needs the native fp32 backbone (conv_precision 0)")
         x = self._x.get(slot)
-        if x is None or self._x_rows[slot] < rows or x.device != device:
+        if x is None or self._x_rows[slot] < rows or x.device != device or x.dtype != self.render_dtype:
             self._x.pop(slot, None)
-            self._x[slot] = x = eng.padded_nhwc(rows, h, w, bb.c_in_p, bb.in_border, device)
+            self._x[slot] = x = eng.padded_nhwc(rows, h, w, bb.c_in_p, bb.in_border, device, dtype=self.render_dtype)
             self._x_rows[slot] = rows
         return x
 
@@ -203,7 +211,8 @@ class PosePredictor(nn.Module):
     def _nchw_view(self, rows: int, c0: int, c1: int, slot: int = 0) -> torch.Tensor:
         bb = self._backbone_engine()
         h, w = self.render_size
-        return eng.padded_view(self._x[slot], self._x_rows[slot], h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
+        v = eng.padded_view(self._x[slot], self._x_rows[slot], h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
+        return v if v.dtype == torch.float32 else v.float()   # (fp16 renders mode: callers always see fp32 crops / renders)
 
     def _packed(self, images: torch.Tensor) -> "eng.PackedObservation":
         """[n_im,C,H,W] frames -> NHWC4 copy for the fused crop, cached while the same (unmodified) tensor keeps coming in"""

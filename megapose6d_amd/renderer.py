@@ -114,9 +114,14 @@ class Panda3dBatchRenderer:
     # -- reference API -----------------------------------------------------------------------------------
     def render(self, labels: List[str], TCO: torch.Tensor, K: torch.Tensor, light_datas: List[List[Panda3dLightData]],
                resolution: Resolution, render_depth: bool = False, render_mask: bool = False,
-               render_normals: bool = False) -> BatchRenderOutput:
+               render_normals: bool = False, output_dtype: torch.dtype = torch.float32) -> BatchRenderOutput:
+        """`output_dtype=torch.float16` (engine extension, trailing keyword): the launch stores binary16 values (rounded to nearest
+        even) and the returned rgbs / normals / depths are float16 tensors -- the "fp16 renders" mode; the reference's output
+        path (panda3d_batch_renderer.py:261-274) only knows uint8 -> fp32."""
         if render_mask:
             raise NotImplementedError
+        if output_dtype not in (torch.float32, torch.float16):
+            raise ValueError("output_dtype must be torch.float32 or torch.float16")
         bsz = TCO.shape[0]
         assert TCO.shape == (bsz, 4, 4)
         assert K.shape == (bsz, 3, 3)
@@ -126,7 +131,7 @@ class Panda3dBatchRenderer:
         K = K.detach().to(device=device, dtype=torch.float32)
         h, w = resolution
         C = 8  # rgb 0..2, normals 3..5, depth 6
-        out = torch.empty(bsz, h, w, C, dtype=torch.float32, device=device)
+        out = torch.empty(bsz, h, w, C, dtype=output_dtype, device=device)
         mesh_ids = self.label_ids(labels, device)
         # one launch per distinct light set (the hot path always passes identical lights for the whole batch)
         groups: Dict[tuple, List[int]] = {}
@@ -139,7 +144,7 @@ class Panda3dBatchRenderer:
         else:
             for idx in groups.values():
                 sel = torch.as_tensor(idx, device=device)
-                tmp = torch.empty(len(idx), h, w, C, dtype=torch.float32, device=device)
+                tmp = torch.empty(len(idx), h, w, C, dtype=output_dtype, device=device)
                 self.render_into(mesh_ids[sel], TCO[sel], K[sel], light_datas[idx[0]], resolution, tmp, h * w * C, w * C, C, 0, c_n, c_d)
                 out[sel] = tmp
         nchw = out.permute(0, 3, 1, 2)  # views with NCHW shape; memory stays NHWC

@@ -81,9 +81,12 @@ def make_scene(n_objects: int = 1, seed: int = 0, backbone: str = "vanilla_resne
 
 
 def make_multi_frame_scene(n_frames: int = 8, n_per_frame: int = 8, n_meshes: int = 16, seed: int = 40, backbone: str = "vanilla_resnet34",
-                           rgbd: bool = False, SO3_grid_size: int = 576, tmp_dir: Optional[str] = None, **est_kwargs):
+                           rgbd: bool = False, SO3_grid_size: int = 576, tmp_dir: Optional[str] = None, depth_obs: bool = False,
+                           **est_kwargs):
     """BASELINE.json configs[3]/[4] shape: `n_frames` 640x480 frames with `n_per_frame` detections each over `n_meshes` distinct
-    meshes (every mesh appears n_frames * n_per_frame / n_meshes times).  -> (estimator, observation, detections, object dataset)"""
+    meshes (every mesh appears n_frames * n_per_frame / n_meshes times).  -> (estimator, observation, detections, object dataset).
+    rgbd: RGBD refiner + RGBD frames; depth_obs: RGBD frames for an RGB model pair (the "...-icp" recipes: the depth image only feeds
+    the depth refiner, reference utils/load_model.py NAMED_MODELS)."""
     import pandas as pd
 
     from .tcoll import PandasTensorCollection
@@ -99,7 +102,7 @@ def make_multi_frame_scene(n_frames: int = 8, n_per_frame: int = 8, n_meshes: in
     for f in range(n_frames):
         labs = [labels_all[(2 * f + j) % n_meshes] for j in range(n_per_frame)]
         poses = np.stack([syn.random_pose(rng, (0.5, 0.8), 0.3) for _ in labs])
-        im, bb = render_observation(r, labs, poses, K, seed=f, with_depth=rgbd)
+        im, bb = render_observation(r, labs, poses, K, seed=f, with_depth=rgbd or depth_obs)
         frames.append(im)
         rows += [dict(label=l, batch_im_id=f) for l in labs]
         boxes.append(bb)

@@ -34,6 +34,10 @@ class OraclePosePredictor:
         self.V = cfg.n_rendered_views
         self.ids2000 = og.sample_point_ids(self.points.shape[1], 2000)
         self.ids200 = og.sample_point_ids(self.points.shape[1], 200)
+        # "fp16 renders" mode of the engine (BASELINE.json configs[4]; NOT a reference mode -- the reference's renderer output path,
+        # panda3d_batch_renderer.py:261-274, is uint8 -> fp32): the CNN input passes through IEEE binary16 (round to nearest even)
+        # where the engine stores it as halves -- crop and renders as rendered, the depth channels once more after normalisation.
+        self.input_f16 = False
 
     def _pts(self, labels, ids):
         obj = torch.tensor([self.label_to_id[l] for l in labels], dtype=torch.long)
@@ -104,8 +108,12 @@ class OraclePosePredictor:
         else:
             KV = K_crop.unsqueeze(1)
         renders = self.render_multiview(labels, TCV_O, KV)
+        if self.input_f16:
+            crops, renders = crops.half().float(), renders.half().float()
         crops_n, renders_n = self.normalize_images(crops, renders, tCR)
         x = torch.cat((crops_n, renders_n), dim=1)
+        if self.input_f16:
+            x = x.half().float()
         net = ob.net_forward(self.sd, self.cfg.backbone_str, x)
         return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV, K_crop=K_crop, boxes_rend=boxes_rend, boxes_crop=boxes_crop, x=x, net=net)
 

@@ -11,6 +11,38 @@ import torch
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
+def test_oracle_fp16_renders_mode_rounds_the_cnn_input_through_binary16():
+    """oracle side of the engine's "fp16 renders" mode (OraclePosePredictor.input_f16): the CNN input is the fp32 one rounded to
+    nearest-even binary16 (depth channels: rounded as rendered, normalised, rounded again), everything else is unchanged"""
+    from megapose6d_amd import synthetic as syn
+    from oracle import harness
+
+    g = {k: v for k, v in np.load(GOLD / "pipeline.npz").items()}
+    images = (torch.from_numpy(g["img_u8"]).float() / 255).permute(2, 0, 1)[None]
+    K = torch.from_numpy(g["K"]).float().reshape(-1, 3, 3)
+    T = torch.from_numpy(g["gt_TCO"][:1]).float()
+    ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_h16_"), n_objects=1, seed=0)
+    coarse, refiner, db = harness.make_oracle_models(ds)
+    im = torch.zeros(1, dtype=torch.long)
+    a = coarse.step(images, im, K, [ds[0].label], T)
+    coarse.input_f16 = True
+    b = coarse.step(images, im, K, [ds[0].label], T)
+    assert torch.equal(a["x"].half().float(), b["x"]) and not torch.equal(a["x"], b["x"])
+    assert torch.equal(a["K_crop"], b["K_crop"]) and torch.equal(a["TCV_O"], b["TCV_O"])
+    la, lb = a["net"]["renderings_logits"], b["net"]["renderings_logits"]
+    assert la.shape == lb.shape and 0 < (la - lb).abs().max().item() < 1e-2 * max(1.0, la.abs().max().item())
+    # RGBD refiner: normalised depth channels are rounded twice
+    ds2 = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_h16d_"), n_objects=1, seed=0)
+    _, ref_d, _ = harness.make_oracle_models(ds2, rgbd=True)
+    depth = torch.full((1, 1, *images.shape[-2:]), 0.6)
+    rgbd = torch.cat([images, depth], 1)
+    ra = ref_d.step(rgbd, im, K, [ds2[0].label], T)
+    ref_d.input_f16 = True
+    rb = ref_d.step(rgbd, im, K, [ds2[0].label], T)
+    assert torch.equal(rb["x"], rb["x"].half().float())
+    assert (ra["x"] - rb["x"]).abs().max().item() < 2e-3   # |x| <= 2 (clamped depth): half an ulp of binary16 at 2.0 is 4.9e-4, twice
+
+
 def test_sampled_rows_parity_is_exact_on_the_oracles_own_run():
     from megapose6d_amd import synthetic as syn
     from oracle import harness

@@ -368,6 +368,16 @@ def test_conv_launch_plan_small_grids_and_half_empty_last_rounds():
     assert _plan(1, 8, 10, 512, 512, 3, 1, ws_floats=80 * 512)[0] == 0
 
 
+def test_conv_launch_plan_half_precision_input_is_single_pass():
+    """mp_conv_desc.x_f16 (the stems of the "fp16 renders" mode): one single-pass launch whatever the grid; the same stem in fp32 at
+    batch 1 (150 tiles) splits K"""
+    from megapose6d_amd import engine as eng
+
+    kw = dict(N=1, H=240, W=320, Cp=28, in_border=3, Cout=64, K=7, stride=2, pad=3, n_cu=256, ws_floats=12 << 20)
+    assert eng.conv2d_plan(**kw)["mode"] == 1
+    assert eng.conv2d_plan(**kw, x_f16=True) == dict(mode=0, k_split=1, chunks_per_split=43, n_main=0, m_begin=0)   # ceil(7 * 196 / 32)
+
+
 def test_load_cfg_reads_python_tagged_legacy_configs_without_instantiating_them(tmp_path):
     """reference inference/utils.py:71-75 reads config.yaml with yaml.UnsafeLoader; older runs are python-tagged object dumps"""
     import argparse
