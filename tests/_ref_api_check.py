@@ -77,6 +77,91 @@ for name, rf, of in [("create_model_pose", r_pmc.create_model_pose, mp.load_mode
                      ("load_pose_models", r_iu.load_pose_models, mp.load_model.load_pose_models)]:
     diff(name, rf, of)
 
+# (i-b) Detector (row f-4): signatures + BEHAVIOUR of get_detections against the reference class driven by the same fake model
+import megapose.inference.detector as r_det  # noqa: E402
+
+from megapose6d_amd import detector as o_det  # noqa: E402
+
+for m in ["__init__", "image_tensor_from_numpy", "get_detections"]:
+    diff(f"Detector.{m}", getattr(r_det.Detector, m), getattr(o_det.Detector, m))
+
+
+def _detector_behaviour():
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+
+    class FakeMaskRCNN(torch.nn.Module):
+        """deterministic stand-in with torchvision's Mask R-CNN output format"""
+
+        def __init__(self, per_image):
+            super().__init__()
+            self.config = SimpleNamespace(label_to_category_id={"ycbv-obj_000001": 1, "ycbv-obj_000002": 2, "ycbv-obj_000005": 3})
+            self.per_image = per_image
+
+        def forward(self, images):
+            outs = []
+            for n, im in enumerate(images):
+                k = self.per_image[n]
+                g = torch.Generator().manual_seed(100 + n)
+                xy = torch.rand(k, 2, generator=g) * 200
+                wh = torch.rand(k, 2, generator=g) * 100 + 5
+                outs.append(dict(boxes=torch.cat([xy, xy + wh], 1), labels=torch.randint(1, 4, (k,), generator=g),
+                                 scores=torch.rand(k, generator=g), masks=torch.rand(k, 1, *im.shape[-2:], generator=g)))
+            return outs
+
+    rng = np.random.RandomState(0)
+    images = torch.from_numpy(rng.rand(3, 3, 24, 32).astype(np.float32))
+    from megapose.inference.types import ObservationTensor as RObs
+
+    from megapose6d_amd.types import ObservationTensor as OObs
+
+    for per_image in ([4, 0, 6], [0, 0, 0], [1, 1, 1]):
+        for kw in (dict(), dict(detection_th=0.4), dict(output_masks=True, mask_th=0.5), dict(one_instance_per_class=True),
+                   dict(detection_th=0.3, output_masks=True, one_instance_per_class=True)):
+            if sum(per_image) == 0 and (kw.get("one_instance_per_class") or kw.get("detection_th") is not None):
+                continue  # the reference itself raises on an empty frame there (groupby/score on empty columns)
+            tag = f"Detector.get_detections per_image={per_image} {kw}"
+            try:
+                a = r_det.Detector(FakeMaskRCNN(per_image)).get_detections(RObs(images=images), **kw)
+                b = o_det.Detector(FakeMaskRCNN(per_image)).get_detections(OObs(images=images), **kw)
+            except Exception as e:  # noqa: BLE001
+                problems.append(f"{tag}: raised {type(e).__name__}: {e}")
+                continue
+            da, db = a.infos.reset_index(drop=True), b.infos.reset_index(drop=True)
+            if len(da) != len(db):
+                problems.append(f"{tag}: {len(db)} detections, reference {len(da)}")
+                continue
+            if len(da) == 0:   # empty result: pandas gives the reference no instance_id column at all; ours keeps the (empty) column
+                db = db.drop(columns=["instance_id"], errors="ignore")
+            if sorted(da.columns) != sorted(db.columns):
+                problems.append(f"{tag}: columns {sorted(db.columns)}, reference {sorted(da.columns)}")
+                continue
+            for c in da.columns:
+                va, vb = da[c].tolist(), db[c].tolist()
+                if c == "score":
+                    if not np.allclose(va, vb, atol=1e-7):
+                        problems.append(f"{tag}: scores differ")
+                elif va != vb:
+                    problems.append(f"{tag}: column {c}: {vb} vs reference {va}")
+            if not torch.equal(a.bboxes.float().cpu(), b.bboxes.cpu()):
+                problems.append(f"{tag}: bboxes differ")
+            if kw.get("output_masks") and sum(per_image):
+                if not torch.equal(a.masks.cpu(), b.masks.cpu()):
+                    problems.append(f"{tag}: masks differ")
+    d = o_det.Detector(FakeMaskRCNN([1]))
+    u8 = (rng.rand(5, 7, 3) * 255).astype(np.uint8)
+    if not torch.equal(d.image_tensor_from_numpy(u8), r_det.Detector(FakeMaskRCNN([1])).image_tensor_from_numpy(u8)):
+        problems.append("Detector.image_tensor_from_numpy differs")
+
+
+try:
+    _detector_behaviour()
+except Exception as e:  # noqa: BLE001
+    import traceback
+
+    problems.append("detector behaviour check crashed: " + traceback.format_exc()[-600:])
+
 # (ii) INTEGRATION.md monkey-patch block, executed verbatim
 md = (ROOT / "INTEGRATION.md").read_text()
 blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)

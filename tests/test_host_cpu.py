@@ -404,3 +404,32 @@ def test_load_cfg_reads_python_tagged_legacy_configs_without_instantiating_them(
     (tmp_path / "bad.yaml").write_text("- 1\n- 2\n")
     with pytest.raises(ValueError):
         load_cfg(tmp_path / "bad.yaml")
+
+
+def test_detector_wrapper_builds_the_detections_collection():
+    """Detector.get_detections (reference inference/detector.py:63-136) on a stand-in model with torchvision's Mask R-CNN output
+    format; the same cases are compared with the imported reference class in tests/_ref_api_check.py (build container)."""
+    from types import SimpleNamespace
+
+    from megapose6d_amd.detector import Detector
+    from megapose6d_amd.types import ObservationTensor
+
+    class Fake(torch.nn.Module):
+        config = SimpleNamespace(label_to_category_id={"a": 1, "b": 2})
+
+        def forward(self, images):
+            assert isinstance(images, list) and images[0].shape == (3, 6, 8)
+            return [dict(boxes=torch.tensor([[1.0, 2, 5, 6], [0, 0, 3, 3], [2, 2, 4, 4]]), labels=torch.tensor([2, 1, 2]),
+                         scores=torch.tensor([0.9, 0.2, 0.6]), masks=torch.full((3, 1, 6, 8), 0.85)),
+                    dict(boxes=torch.zeros(0, 4), labels=torch.zeros(0, dtype=torch.long), scores=torch.zeros(0), masks=torch.zeros(0, 1, 6, 8))]
+
+    det = Detector(Fake())
+    obs = ObservationTensor(images=torch.rand(2, 4, 6, 8))   # RGBD frames: only the first three channels reach the model
+    d = det.get_detections(obs, output_masks=True)
+    assert d.infos["label"].tolist() == ["b", "a", "b"] and d.infos["batch_im_id"].tolist() == [0, 0, 0]
+    assert d.infos["instance_id"].tolist() == [0, 0, 1] and d.bboxes.shape == (3, 4) and d.masks.shape == (3, 6, 8) and d.masks.all()
+    assert len(det(obs, detection_th=0.5)) == 2
+    one = det.get_detections(obs, one_instance_per_class=True)
+    assert sorted(zip(one.infos["label"], one.infos["score"].round(3))) == [("a", 0.2), ("b", 0.9)]
+    assert not det.get_detections(obs, output_masks=True, mask_th=0.9).masks.any()
+    assert det.image_tensor_from_numpy(np.zeros((6, 8, 3), np.uint8)).shape == (3, 6, 8)
