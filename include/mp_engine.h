@@ -327,6 +327,54 @@ int mp_icp_refine(const float* d_depth_meas, int n_images, const int32_t* d_im_i
                   int n_iterations, int n_levels, float tolerance, int n_min_points, int user_masks, float* d_TCO_out,
                   int32_t* d_retval, float* d_residual, void* d_workspace, size_t workspace_bytes, mp_stream stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* Detector network: replaces the torchvision Mask R-CNN    */
+/* behind `self.model([image_n ...])` in inference/detector.py:92                          */
+/* (models/mask_rcnn.py:23-46 = MaskRCNN(resnet_fpn_backbone("resnet50"), num_classes,     */
+/* AnchorGenerator(((32,),(64,),(128,),(256,),(512,)), ((0.5,1,2),)*5), min/max_size);     */
+/* all other hyper-parameters torchvision 0.12 defaults).  One call runs the whole         */
+/* inference graph on the device: normalise + resize + pad, ResNet-50 + FPN (the fp32 MFMA */
+/* convolution of this library, FrozenBatchNorm folded), RPN (top-k, decode, NMS), RoIAlign,*/
+/* box head (the two FC layers run as 1x1 convolutions on the same kernel), per-class NMS, */
+/* mask head and mask pasting.  No host synchronisation, deterministic (ties resolve to    */
+/* the lower index).  csrc/detector.hip.                                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct mp_detector mp_detector;
+
+typedef struct {
+  int32_t n_classes;               /* including the background class 0                                           */
+  int32_t min_size, max_size;      /* GeneralizedRCNNTransform (cfg.input_resize: (480, 640) for the released detectors) */
+  float image_mean[3], image_std[3];
+  int32_t anchor_sizes[5];         /* one per pyramid level P2..P6                                                */
+  float aspect_ratios[3];
+  int32_t rpn_pre_nms_top_n, rpn_post_nms_top_n;   /* <= 1024 each                                              */
+  float rpn_nms_thresh, rpn_score_thresh, rpn_min_size;
+  float box_score_thresh, box_nms_thresh, box_min_size;
+  int32_t box_detections_per_img;                  /* <= 1024                                                    */
+} mp_detector_config;
+
+/* torchvision's eval defaults: 1000 / 1000 / 0.7 / 0.0 / 1e-3, 0.05 / 0.5 / 1e-2 / 100, ImageNet mean / std, the reference's anchors */
+int mp_detector_default_config(mp_detector_config* cfg, int n_classes, int min_size, int max_size);
+/* The checkpoint layout the detector expects (torchvision's state_dict keys: backbone.body.*, backbone.fpn.*, rpn.head.*,
+ * roi_heads.*): entry `idx` -> name, dims.  Returns 1 past the end.  Host only. */
+int mp_detector_state_spec(int n_classes, int idx, char* name, int name_len, int64_t* shape4, int32_t* n_dims);
+int mp_detector_create(const mp_detector_config* cfg, const mp_named_tensor* h_state, int n_tensors, mp_detector** out);
+int mp_detector_destroy(mp_detector* det);
+size_t mp_detector_workspace_bytes(const mp_detector* det, int n_images, int H, int W);
+/* d_images [n,3,H,W] fp32 in [0,1] (what Detector.get_detections passes, detector.py:88-92).  Outputs, D = box_detections_per_img:
+ * d_boxes [n,D,4] (x1,y1,x2,y2 in ORIGINAL image pixels), d_scores [n,D], d_labels [n,D] (category ids >= 1), d_counts [n]; entries
+ * past the count are zero.  d_masks: NULL or [n,D,H,W] soft masks in [0,1] pasted into the original frame (roi_heads.py
+ * paste_masks_in_image); the caller thresholds them (detector.py:106).  Images of one call share H x W. */
+int mp_detector_forward(mp_detector* det, const float* d_images, int n_images, int H, int W, float* d_boxes, float* d_scores,
+                        int32_t* d_labels, int32_t* d_counts, float* d_masks, void* d_workspace, size_t workspace_bytes,
+                        mp_stream stream);
+/* Parity taps (tests): after a forward, the device address + logical shape of an intermediate inside `d_workspace`:
+ * "P2".."P6" padded-NHWC pyramid levels {n, h, w, 256} with border 1; "proposals" {n, post_nms_top_n, 4} + "proposal_counts" {n} (int32);
+ * "class_logits" {n*post, padded 5*n_classes row: n_classes logits then 4*n_classes deltas}; "mask_logits" {n*D*14*14*4, padded n_classes}.
+ * Returns MP_ERR_INVALID for an unknown name or before the first forward. */
+int mp_detector_debug_tensor(const mp_detector* det, const char* what, const void** d_ptr, int64_t* shape4, int32_t* border,
+                             int64_t* row_stride, int64_t* n_elements /* 4-byte elements of the whole buffer (borders / row padding included) */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,20 @@ class ConvDesc(C.Structure):
     ]
 
 
+class DetectorConfig(C.Structure):
+    _fields_ = [
+        ("n_classes", C.c_int32),
+        ("min_size", C.c_int32), ("max_size", C.c_int32),
+        ("image_mean", C.c_float * 3), ("image_std", C.c_float * 3),
+        ("anchor_sizes", C.c_int32 * 5),
+        ("aspect_ratios", C.c_float * 3),
+        ("rpn_pre_nms_top_n", C.c_int32), ("rpn_post_nms_top_n", C.c_int32),
+        ("rpn_nms_thresh", C.c_float), ("rpn_score_thresh", C.c_float), ("rpn_min_size", C.c_float),
+        ("box_score_thresh", C.c_float), ("box_nms_thresh", C.c_float), ("box_min_size", C.c_float),
+        ("box_detections_per_img", C.c_int32),
+    ]
+
+
 class NamedTensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("h_data", C.c_void_p), ("numel", C.c_int64)]
 
@@ -118,6 +132,13 @@ SIGNATURES = {
     "mp_icp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mp_icp_refine": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_pose_update": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "mp_detector_default_config": (_i, [C.POINTER(DetectorConfig), _i, _i, _i]),
+    "mp_detector_state_spec": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_int32)]),
+    "mp_detector_create": (_i, [C.POINTER(DetectorConfig), C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
+    "mp_detector_destroy": (_i, [_vp]),
+    "mp_detector_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mp_detector_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_detector_debug_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(_i64), C.POINTER(_i64)]),
 }
 
 _lib = None
