@@ -452,3 +452,104 @@ def icp_refine(depth_meas: torch.Tensor, im_ids: torch.Tensor, depth_rend: torch
                             K_rows.data_ptr(), TCO.data_ptr(), N, H, W, n_iterations, n_levels, tolerance, n_min_points, int(user_masks), out.data_ptr(),
                             retval.data_ptr(), residual.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out, retval, residual
+
+
+# --------------------------------------------------------------------------- #
+class DetectorNet:
+    """mp_detector: the Mask R-CNN (ResNet-50 + FPN) detection graph resident on the device, one call per image batch
+    (csrc/detector.hip).  `state_dict` uses torchvision's keys (= a checkpoint of the reference's DetectorMaskRCNN)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], n_classes: int, min_size: int, max_size: int, **overrides):
+        lib = _lib.load()
+        self.cfg = _lib.DetectorConfig()
+        check(lib.mp_detector_default_config(C.byref(self.cfg), n_classes, min_size, max_size))
+        for k, v in overrides.items():
+            if not hasattr(self.cfg, k):
+                raise EngineError(f"unknown detector option '{k}'")
+            cur = getattr(self.cfg, k)
+            if hasattr(cur, "__len__"):
+                cur[:] = list(v)
+            else:
+                setattr(self.cfg, k, v)
+        keep, items = [], []
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            a = np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32)
+            keep.append(a)
+            items.append((k.encode(), a))
+        arr = (NamedTensor * len(items))()
+        for i, (k, a) in enumerate(items):
+            arr[i] = NamedTensor(k, a.ctypes.data, a.size)
+        h = C.c_void_p()
+        check(lib.mp_detector_create(C.byref(self.cfg), arr, len(items), C.byref(h)))
+        self.handle = h
+        self.n_classes = n_classes
+        self._ws: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def state_spec(n_classes: int) -> List[Tuple[str, Tuple[int, ...]]]:
+        """[(state_dict key, shape)] the detector expects (host only: mp_detector_state_spec)"""
+        lib = _lib.load()
+        out, i = [], 0
+        while True:
+            name = C.create_string_buffer(160)
+            shp, nd = (C.c_int64 * 4)(), C.c_int32(0)
+            rc = lib.mp_detector_state_spec(n_classes, i, name, 160, shp, C.byref(nd))
+            if rc == 1:
+                return out
+            check(rc)
+            out.append((name.value.decode(), tuple(int(s) for s in shp[: nd.value])))
+            i += 1
+
+    def forward(self, images: torch.Tensor, with_masks: bool = True):
+        """images [n,3,H,W] fp32 in [0,1] on the GPU -> (boxes [n,D,4], scores [n,D], labels [n,D] int32, counts [n] int32,
+        masks [n,D,H,W] or None); nothing synchronises, entries past counts[i] are zero."""
+        lib = _lib.load()
+        images = _dev_f32(images)
+        n, c, H, W = images.shape
+        if c != 3:
+            raise EngineError("the detector takes RGB images [n,3,H,W]")
+        dev = images.device
+        D = int(self.cfg.box_detections_per_img)
+        need = lib.mp_detector_workspace_bytes(self.handle, n, H, W)
+        if need == 0:
+            raise EngineError(f"mp_detector_workspace_bytes failed for {n} x {H} x {W}: {lib.mp_last_error().decode()}")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        boxes = torch.empty(n, D, 4, dtype=torch.float32, device=dev)
+        scores = torch.empty(n, D, dtype=torch.float32, device=dev)
+        labels = torch.empty(n, D, dtype=torch.int32, device=dev)
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        masks = torch.empty(n, D, H, W, dtype=torch.float32, device=dev) if with_masks else None
+        check(lib.mp_detector_forward(self.handle, images.data_ptr(), n, H, W, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                                      counts.data_ptr(), _ptr(masks), self._ws.data_ptr(), self._ws.numel(), _stream()))
+        return boxes, scores, labels, counts, masks
+
+    def debug_tensor(self, what: str) -> torch.Tensor:
+        """a COPY of an intermediate of the last forward (parity tests): padded maps come back as their [n,h,w,c] interior"""
+        lib = _lib.load()
+        ptr, shp, border, rs, n_el = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        check(lib.mp_detector_debug_tensor(self.handle, what.encode(), C.byref(ptr), shp, C.byref(border), C.byref(rs), C.byref(n_el)))
+        off = ptr.value - self._ws.data_ptr()
+        is_int = what in ("proposal_counts", "f_cnt")
+        flat = self._ws[off : off + 4 * n_el.value].view(torch.int32 if is_int else torch.float32).clone()
+        s, b = [int(v) for v in shp], border.value
+        if b:
+            return flat.view(s[0], s[1] + 2 * b, s[2] + 2 * b, s[3])[:, b : b + s[1], b : b + s[2]].contiguous()
+        if s[2] == 4:
+            return flat.view(s[0], s[1], 4)
+        if rs.value > 1:
+            return flat.view(s[0], rs.value)[:, : s[1]].contiguous()
+        return flat.view(s[0], s[1])
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().mp_detector_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -226,6 +226,38 @@ def load_named_model(model_name: str, object_dataset, n_workers: int = 4, bsz_im
                          bsz_objects=8, bsz_images=bsz_images)
 
 
+def check_update_config_detector(cfg) -> Config:
+    """reference training/detector_models_cfg.py:24-28: labels are prefixed with the dataset name (`ycbv-obj_000001`)"""
+    cfg = Config.from_any(cfg)
+    obj_prefix = cfg.train_ds_names[0][0].split(".")[0]
+    cfg.label_to_category_id = {f"{obj_prefix}-{k}": v for k, v in dict(cfg.label_to_category_id).items()}
+    return cfg
+
+
+def create_model_detector(cfg, n_classes: int):
+    """reference training/detector_models_cfg.py:31-38"""
+    from .mask_rcnn import DetectorMaskRCNN
+
+    return DetectorMaskRCNN(input_resize=tuple(cfg.input_resize), n_classes=n_classes, backbone_str=cfg.backbone_str,
+                            anchor_sizes=tuple(tuple(s) for s in cfg.anchor_sizes))
+
+
+def load_detector(run_id: str, models_root: Path = LOCAL_DATA_DIR / "experiments"):
+    """reference inference/utils.py:57-70: run directory (config.yaml + checkpoint.pth.tar) -> Detector over the HIP Mask R-CNN"""
+    from .detector import Detector
+
+    run_dir = Path(models_root) / run_id
+    cfg = check_update_config_detector(load_cfg(run_dir / "config.yaml"))
+    label_to_category_id = cfg.label_to_category_id
+    model = create_model_detector(cfg, len(label_to_category_id))
+    ckpt = torch.load(run_dir / "checkpoint.pth.tar", map_location="cpu")["state_dict"]
+    model.load_state_dict(ckpt)
+    model = model.cuda().eval()
+    model.cfg = cfg
+    model.config = cfg
+    return Detector(model)
+
+
 def save_run(run_dir, cfg, state_dict: Dict[str, torch.Tensor]) -> None:
     """Write config.yaml + checkpoint.pth.tar in the layout load_pose_models reads (used for the seeded synthetic runs)."""
     run_dir = Path(run_dir)

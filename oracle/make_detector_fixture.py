@@ -94,3 +94,20 @@ if __name__ == "__main__":
     d = Path(sys.argv[1]) if len(sys.argv) > 1 else Path(__file__).resolve().parent.parent / "tests" / "_build"
     for c in CASES:
         make_case(c, d)
+
+
+def make_golden(fixture: Path, out: Path) -> None:
+    """compact, committed digest of a fixture (tests/golden/detector_<case>.npz, ~100 KB): outputs in full, intermediates
+    sub-sampled -- what the GPU test compares the engine with when the full fixture has not been generated"""
+    r = read_records(fixture)
+    g = {"config": r["config"], "boxes": r["boxes"], "scores": r["scores"], "labels": r["labels"], "counts": r["counts"],
+         "proposals_first64": r["proposals"][:, :64], "proposal_scores_first64": r["proposal_scores"][:, :64],
+         "proposal_counts": r["proposal_counts"], "class_logits_first64": r["class_logits"][:64],
+         "box_regression_first64": r["box_regression"][:64], "masks28_first4": r["masks28"][:, :4]}
+    for l in range(2, 7):
+        f = r[f"P{l}"]
+        g[f"P{l}_sub"] = f[:, ::4, ::4, ::16].copy()          # every 4th pixel, every 16th channel
+        g[f"P{l}_absmean"] = np.array([np.abs(f).mean()], np.float32)
+    out.parent.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(out, **g)
+    print(f"[golden] {out} ({out.stat().st_size / 1e3:.0f} KB)", file=sys.stderr)

@@ -1,0 +1,95 @@
+"""-m gpu: the detector network on the HIP engine (csrc/detector.hip through DetectorMaskRCNN / Detector) against the CPU oracle
+(oracle/mask_rcnn.py, a restatement of torchvision 0.12's Mask R-CNN inference -- third party, parity unpinned).
+Weights and images are hash-generated on both sides (oracle.mask_rcnn.synthetic_*); the oracle's results come from the committed
+compact goldens (tests/golden/detector_*.npz) and, for one small case, from a fresh oracle run on the host CPU.
+Tolerances: feature maps 1e-3 relative to their scale (fp32 MFMA vs MKL-DNN summation order over ~60 layers; measured ~1e-6),
+boxes 5e-2 px, scores 2e-4, labels exact; a couple of detections may swap or drop where two scores tie within round-off.
+(The same comparison runs torch-free in scripts/microbench/native_detector_check.cpp; its MI355X log is profiles/r02_detector_native_check.txt.)"""
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _model(C, mn, mx):
+    from megapose6d_amd.mask_rcnn import DetectorMaskRCNN
+    from oracle import mask_rcnn as om
+
+    m = DetectorMaskRCNN(input_resize=(mn, mx), n_classes=C)
+    m.load_state_dict(om.synthetic_state_dict(C))
+    return m.cuda().eval()
+
+
+def _match(boxes, scores, labels, gb, gs, gl):
+    """-> number of golden detections that have a twin (same label, score within 2e-4, box within 5e-2 px) among ours"""
+    found = 0
+    for b, s, l in zip(gb, gs, gl):
+        ok = (labels == l) & (np.abs(scores - s) < 2e-4) & (np.abs(boxes - b).max(axis=1) < 5e-2)
+        found += bool(ok.any())
+    return found
+
+
+@pytest.mark.parametrize("case", ["native", "resized", "batch2"])
+def test_detector_matches_the_oracle_goldens(case):
+    from oracle import mask_rcnn as om
+
+    g = np.load(GOLD / f"detector_{case}.npz")
+    n, H, W, mn, mx, C = (int(v) for v in g["config"])
+    m = _model(C, mn, mx)
+    images = om.synthetic_images(n, H, W).cuda()
+    out = m(list(images))
+    net = m._net()
+    for l in range(2, 7):   # pyramid
+        f = net.debug_tensor(f"P{l}").cpu().numpy()
+        ref = g[f"P{l}_sub"]
+        assert np.abs(f[:, ::4, ::4, ::16] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), l
+        assert abs(np.abs(f).mean() - float(g[f"P{l}_absmean"][0])) < 1e-4
+    props, pcnt = net.debug_tensor("proposals").cpu().numpy(), net.debug_tensor("proposal_counts").cpu().numpy().ravel()
+    assert (np.abs(pcnt - g["proposal_counts"]) <= 2).all()
+    assert np.abs(props[:, :16] - g["proposals_first64"][:, :16]).max() < 5e-2   # the best proposals, in place
+    for i in range(n):
+        k = int(g["counts"][i])
+        o = out[i]
+        assert abs(len(o["boxes"]) - k) <= 3
+        assert o["masks"].shape == (len(o["boxes"]), 1, H, W) and o["labels"].dtype == torch.int64
+        found = _match(o["boxes"].cpu().numpy(), o["scores"].cpu().numpy(), o["labels"].cpu().numpy(), g["boxes"][i, :k], g["scores"][i, :k], g["labels"][i, :k])
+        assert found >= k - 3 - k // 20, (found, k)
+        s = o["scores"].cpu().numpy()
+        assert (s[:-1] >= s[1:]).all() and 0 <= float(o["masks"].min()) and float(o["masks"].max()) <= 1
+    # deterministic
+    again = m(list(images))
+    assert all(torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["masks"], b["masks"]) for a, b in zip(out, again))
+
+
+def test_detector_vs_a_fresh_oracle_run_and_through_the_detector_wrapper():
+    """small frame (128 x 160, 3 classes), full oracle on the host: detections, pasted masks, and the reference-shaped wrapper"""
+    from megapose6d_amd.detector import Detector
+    from megapose6d_amd.types import ObservationTensor
+    from oracle import mask_rcnn as om
+
+    C, H, W = 3, 128, 160
+    torch.set_num_threads(16)
+    images = om.synthetic_images(2, H, W)
+    ref = om.mask_rcnn_forward(om.synthetic_state_dict(C), list(images), H, W)
+    m = _model(C, H, W)
+    out = m(list(images.cuda()))
+    for o, r in zip(out, ref):
+        k = len(r["boxes"])
+        ob, os_, ol = o["boxes"].cpu().numpy(), o["scores"].cpu().numpy(), o["labels"].cpu().numpy()
+        assert _match(ob, os_, ol, r["boxes"].numpy(), r["scores"].numpy(), r["labels"].numpy()) >= k - 3 - k // 20
+        for j in range(min(k, 10)):   # pasted masks of detections that sit at the same place in both lists
+            if j < len(ob) and ol[j] == int(r["labels"][j]) and np.abs(ob[j] - r["boxes"][j].numpy()).max() < 1e-3:
+                assert (o["masks"][j, 0].cpu() - r["masks"][j, 0]).abs().max().item() < 5e-2
+    m.config = SimpleNamespace(label_to_category_id={"ds-obj_000001": 1, "ds-obj_000002": 2})
+    det = Detector(m)
+    d = det.get_detections(ObservationTensor(images=images.cuda()), output_masks=True, detection_th=0.3)
+    assert set(d.infos.columns) >= {"batch_im_id", "label", "score", "instance_id"} and (d.infos["score"] > 0.3).all()
+    assert d.bboxes.shape == (len(d), 4) and d.masks.shape == (len(d), H, W) and d.masks.dtype == torch.bool
+    assert set(d.infos["label"]) <= {"ds-obj_000001", "ds-obj_000002"}
+    one = det.get_detections(ObservationTensor(images=images.cuda()), one_instance_per_class=True)
+    assert one.infos.groupby(["batch_im_id", "label"]).size().max() == 1
