@@ -192,6 +192,39 @@ def extras(est, obs, det, steps: int) -> dict:
         finally:
             est.render_dtype = torch.float32
     guarded("fp16_renders", fp16_renders)
+    def detector_line():
+        # the 2D detector front-end: Mask R-CNN ResNet-50-FPN, one 640x480 frame, 22 classes (YCB-V sized head),
+        # random weights of that architecture; NOT part of `value` (detections are supplied to the pose pipeline, as BASELINE.json defines)
+        from megapose6d_amd import engine as eng_
+        from megapose6d_amd.mask_rcnn import DetectorMaskRCNN
+
+        g = torch.Generator().manual_seed(0)
+        sd = {}
+        for name, shape in eng_.DetectorNet.state_spec(22):
+            t = torch.rand(shape, generator=g) * 2 - 1
+            if name.endswith("running_var") or ((".bn" in name or "downsample.1." in name) and name.endswith(".weight")):
+                t = t * 0.5 + 1.0
+            elif name.endswith(".weight"):
+                t = t * (3.0 / (t.numel() // shape[0])) ** 0.5
+            else:
+                t = t * 0.1
+            sd[name] = t
+        m = DetectorMaskRCNN(input_resize=(480, 640), n_classes=22)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        frame = [obs.images[0, :3]]
+        m(frame)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out_ = m(frame)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        m._engine.close()
+        return {"ms_per_frame": dt * 1e3, "detections": int(len(out_[0]["boxes"])),
+                "note": "Detector front-end: DetectorMaskRCNN (ResNet-50 + FPN Mask R-CNN, 22 classes, masks included) on one 640x480 frame, "
+                        "one native call per frame (mp_detector_forward) + the host read of the detection count; informational"}
+    guarded("detector_front_end", detector_line)
     for prec in (9, 6):
         def split(prec=prec):
             for m in (est.coarse_model, est.refiner_model):

@@ -98,3 +98,35 @@ def test_oracle_is_pinned_to_its_golden_outputs():
         f = dbg["feats"][l - 2].permute(0, 2, 3, 1).numpy()
         assert np.abs(f[:, ::4, ::4, ::16] - g[f"P{l}_sub"]).max() < 1e-4
     assert np.abs(out[0]["masks28"][:4, 0].numpy() - g["masks28_first4"][0]).max() < 1e-5
+
+
+def test_native_checker_generates_the_oracles_synthetic_network(tmp_path):
+    """scripts/microbench/native_detector_check.cpp (the torch-free parity runner used on the GPU box) regenerates weights and images
+    from the same hash as oracle.mask_rcnn.synthetic_*: its --checksums mode (host only) must agree tensor by tensor, bit for bit"""
+    import shutil
+    import subprocess
+
+    root = Path(__file__).resolve().parent.parent
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).is_file() or not (root / "megapose6d_amd" / "libmp_engine.so").is_file():
+        pytest.skip("needs hipcc and the built engine library")
+    from oracle import mask_rcnn as om
+
+    exe = tmp_path / "native_detector_check"
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", f"-I{root / 'include'}", str(root / "scripts/microbench/native_detector_check.cpp"),
+                    "-o", str(exe), f"-L{root / 'megapose6d_amd'}", "-lmp_engine", f"-Wl,-rpath,{root / 'megapose6d_amd'}"], check=True, timeout=300)
+    lines = subprocess.run([str(exe), "--checksums", "4"], check=True, capture_output=True, text=True, timeout=300).stdout.split("\n")
+    rows = [l.split() for l in lines if l.strip()]
+
+    def ck(a):
+        b = np.ascontiguousarray(a, np.float32).reshape(-1).view(np.uint32).astype(np.uint64)
+        k = (np.arange(b.size, dtype=np.uint64) % np.uint64(251)) + np.uint64(1)
+        with np.errstate(over="ignore"):
+            return int((b * k).sum(dtype=np.uint64))
+
+    spec = om.state_spec(4)
+    assert len(rows) == len(spec) + 1
+    for (name, shape), row in zip(spec, rows):
+        v = om.synthetic_tensor(name, shape)
+        assert row[0] == name and int(row[1]) == v.size and int(row[2]) == ck(v), name
+    assert int(rows[-1][2]) == ck(om.synthetic_images(1, 24, 32).numpy())
