@@ -143,7 +143,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
 // VARIANT: 1 = the LDS store of the next chunk sits under the LAST MFMA group, | 256 = under the 3rd of 4; | 4096 = the two-chunks-ahead
-// pipeline (barrier before the last group); | 8192 = buffer loads (scalar resource + 32-bit offsets) instead of global loads.
+// pipeline (barrier before the last group); | 8192 = buffer loads (scalar resource + 32-bit offsets) instead of global loads;
+// | 16384 = persistent workgroups: the launch has one workgroup per resident slot (2 per CU) and each walks the tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... (p.k_split carries the tile count of the launch) -- no workgroup dispatch between tiles.
 // AHALF: the INPUT tensor holds IEEE binary16 values (the "fp16 renders" CNN input the rasteriser writes with MP_RASTER_F16): the A
 // tile is fetched as 8-byte pieces (4 halves), stays packed in registers across the MFMA block and is widened to fp32 on its way
 // into LDS -- everything after the LDS store (fragments, MFMA, epilogue) is the fp32 path unchanged.
@@ -170,7 +172,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wm = wave / (BN / WN);
   const int wn = wave % (BN / WN);
 
-  const int lb = xcd_remap(blockIdx.x, gridDim.x) + p.tile_begin;
+  constexpr bool PERSIST = (VARIANT & 16384) != 0;
+  static_assert(!PERSIST || !SPLITK, "persistent workgroups are a single-pass launch mode");
+  for (int tile = blockIdx.x; PERSIST ? tile < p.k_split : true; tile += gridDim.x) {   // (not PERSIST: exactly one trip, the loop folds away)
+  if constexpr (PERSIST) {
+    if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+  }
+  const int lb = (PERSIST ? xcd_remap(tile, p.k_split) : xcd_remap(blockIdx.x, gridDim.x)) + p.tile_begin;
   const int nblk = lb % p.n_nblocks;
   const int mblk = lb / p.n_nblocks;
   const int m0 = mblk * BM;
@@ -534,6 +542,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     case 6: conv_epilogue<TM, TN, false, true, true>(p, acc, row_off, erow0, en0); break;
     default: conv_epilogue<TM, TN, true, true, true>(p, acc, row_off, erow0, en0); break;
   }
+  if constexpr (!PERSIST) break;
+  __syncthreads();   // the next tile rewrites row_off (and the LDS stages) that slower waves may still be reading in their epilogue
+  }
 }
 
 // sum of the k_split partial tiles in ascending split order + the fused epilogue (bias, residual, ReLU, pre-activation output)
@@ -572,6 +583,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(ConvParams p) {
     *reinterpret_cast<float4*>(p.y_act + off) = a;
   }
 }
+
+// resident workgroup slots of the device (2 per CU: LDS-limited); set by mp_conv2d_nhwc before the first launch
+static int g_resident_workgroups = 0;
 
 template <int BM, int BN, int WM, int WN, int VARIANT, bool RAGGED = false>
 static int launch_splitk(const ConvParams& p, hipStream_t s, double alg_k) {
@@ -620,6 +634,10 @@ static int launch(const ConvParams& p, hipStream_t s, double alg_k, int n_tiles_
   const int n_tiles = n_tiles_main > 0 ? n_tiles_main : q.n_mblocks * q.n_nblocks;
   const double m_here = n_tiles_main > 0 ? (double)(n_tiles_main / q.n_nblocks) * BM : (double)p.M;
   dim3 grid(n_tiles);
+  if constexpr ((VARIANT & 16384) != 0) {   // persistent: one workgroup per resident slot, each walks its share of the tiles
+    q.k_split = n_tiles;
+    grid = dim3(std::min(n_tiles, g_resident_workgroups > 0 ? g_resident_workgroups : 512));
+  }
   // algorithmic work of this launch: 2*MACs over the REAL (unpadded) reduction length; bytes = input + weights + output once
   static const bool detail = getenv("MP_PROF_DETAIL") != nullptr;  // tuning aid: one profiler row per layer shape
   const char* pname = BN == 64 ? "conv_nhwc_f32_mfma<128,64,64,32>" : "conv_nhwc_f32_mfma<128,128,64,64>";
@@ -818,6 +836,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     resident = 2 * n_cu;
+    g_resident_workgroups = resident;
   }
   const ConvPlan plan = plan_conv(p, small, d->d_splitk_ws ? d->splitk_ws_floats : 0, resident, splitk_on != 0, tail_on != 0);
   if (plan.mode == 1) {  // small grid: every tile split along K
@@ -843,6 +862,7 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     case 257: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);  // the default schedule with global_load (64-bit lane addresses)
     case 12289: return small ? launch<128, 64, 64, 32, 12289>(p, s, alg_k) : launch<128, 128, 64, 64, 12289>(p, s, alg_k);  // 4097 with buffer loads
     case 4097: return small ? launch<128, 64, 64, 32, 4097>(p, s, alg_k) : launch<128, 128, 64, 64, 4097>(p, s, alg_k);  // two-chunks-ahead pipeline, barrier before the last group
+    case 24833: return small ? launch<128, 64, 64, 32, 24833>(p, s, alg_k) : launch<128, 128, 64, 64, 24833>(p, s, alg_k);  // 8449 with persistent workgroups
     default: return small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k) : launch<128, 128, 64, 64, 8449>(p, s, alg_k);
   }
 }
