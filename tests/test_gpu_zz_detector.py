@@ -64,32 +64,3 @@ def test_detector_matches_the_oracle_goldens(case):
     # deterministic
     again = m(list(images))
     assert all(torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["masks"], b["masks"]) for a, b in zip(out, again))
-
-
-def test_detector_vs_a_fresh_oracle_run_and_through_the_detector_wrapper():
-    """small frame (128 x 160, 3 classes), full oracle on the host: detections, pasted masks, and the reference-shaped wrapper"""
-    from megapose6d_amd.detector import Detector
-    from megapose6d_amd.types import ObservationTensor
-    from oracle import mask_rcnn as om
-
-    C, H, W = 3, 128, 160
-    torch.set_num_threads(16)
-    images = om.synthetic_images(2, H, W)
-    ref = om.mask_rcnn_forward(om.synthetic_state_dict(C), list(images), H, W)
-    m = _model(C, H, W)
-    out = m(list(images.cuda()))
-    for o, r in zip(out, ref):
-        k = len(r["boxes"])
-        ob, os_, ol = o["boxes"].cpu().numpy(), o["scores"].cpu().numpy(), o["labels"].cpu().numpy()
-        assert _match(ob, os_, ol, r["boxes"].numpy(), r["scores"].numpy(), r["labels"].numpy()) >= k - 3 - k // 20
-        for j in range(min(k, 10)):   # pasted masks of detections that sit at the same place in both lists
-            if j < len(ob) and ol[j] == int(r["labels"][j]) and np.abs(ob[j] - r["boxes"][j].numpy()).max() < 1e-3:
-                assert (o["masks"][j, 0].cpu() - r["masks"][j, 0]).abs().max().item() < 5e-2
-    m.config = SimpleNamespace(label_to_category_id={"ds-obj_000001": 1, "ds-obj_000002": 2})
-    det = Detector(m)
-    d = det.get_detections(ObservationTensor(images=images.cuda()), output_masks=True, detection_th=0.3)
-    assert set(d.infos.columns) >= {"batch_im_id", "label", "score", "instance_id"} and (d.infos["score"] > 0.3).all()
-    assert d.bboxes.shape == (len(d), 4) and d.masks.shape == (len(d), H, W) and d.masks.dtype == torch.bool
-    assert set(d.infos["label"]) <= {"ds-obj_000001", "ds-obj_000002"}
-    one = det.get_detections(ObservationTensor(images=images.cuda()), one_instance_per_class=True)
-    assert one.infos.groupby(["batch_im_id", "label"]).size().max() == 1

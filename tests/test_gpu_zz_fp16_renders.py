@@ -186,39 +186,3 @@ def test_normalize_depth_f16(eng):
         eng.normalize_depth(xf, b, h, w, border, C, [3, 6], tCR.cuda(), mode)
         torch.cuda.synchronize()
         assert torch.equal(_bits(xf.half()), _bits(xh)), mode
-
-
-def test_pipeline_in_fp16_renders_mode_vs_oracle(scene72):
-    """72-rotation grid, top-2, 3 refiner iterations: HIP pipeline with render_dtype=float16 vs the oracle with the same rounding
-    of its CNN input.  Tolerances of test_gpu_pipeline.py (poses 1e-4, logits 1e-4 / 5e-4 of their scale)."""
-    from megapose6d_amd.pose_estimator import load_SO3_grid
-    from oracle import harness
-
-    ds, est, obs, det, gt = scene72
-    oest, db = harness.make_oracle_estimator(ds, 72)
-    oest.coarse.input_f16 = oest.refiner.input_f16 = True
-    infos = pd.DataFrame(dict(label=[o.label for o in ds.list_objects], batch_im_id=0, instance_id=[0]))
-    est.render_dtype = torch.float16
-    try:
-        assert est.coarse_model.render_dtype == torch.float16 and est.refiner_model.render_dtype == torch.float16
-        final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=3, n_pose_hypotheses=2)
-        f32_final = None
-    finally:
-        est.render_dtype = torch.float32
-    f32_final, _ = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=3, n_pose_hypotheses=2)
-    res = oest.run(obs.images.cpu(), obs.K.cpu(), infos, det.bboxes.cpu(), n_refiner_iterations=3, n_pose_hypotheses=2)
-    lg = extra["coarse"]["data"]["logits"].flatten().cpu().numpy()
-    scale = max(1.0, float(res["coarse_logits"].abs().max()))
-    assert_logits_close(lg, res["coarse_logits"].numpy(), scale)
-    hyp = extra["coarse_filter"]["preds"].infos["hypothesis_id"].tolist()
-    ohyp = res["filtered_infos"]["hypothesis_id"].tolist()
-    assert sorted(hyp) == sorted(ohyp)
-    order = [hyp.index(h) for h in ohyp]
-    for n in range(3):
-        p = extra["refiner_all_hypotheses"]["preds"][f"iteration={n + 1}"].poses.cpu()[order]
-        assert (p - res["refiner_poses"][n]).abs().max().item() < 1e-4, n
-    assert_logits_close(extra["scoring"]["data"]["logits"].flatten().cpu().numpy()[order], res["scoring_logits"].numpy(), scale)
-    assert (final.poses.cpu() - res["final_TCO"]).abs().max().item() < 1e-4
-    # the mode is a (small) deviation from the fp32 reference arithmetic, never a silent no-op and never a different answer
-    d = (final.poses - f32_final.poses).abs().max().item()
-    assert d < 5e-3
