@@ -232,3 +232,16 @@ def make_detections_from_object_data(object_data: List[ObjectData]):
     infos = pd.DataFrame(dict(label=[d.label for d in object_data], batch_im_id=0, instance_id=np.arange(len(object_data))))
     bboxes = torch.as_tensor(np.stack([d.bbox_modal for d in object_data]))
     return PandasTensorCollection(infos=infos, bboxes=bboxes)
+
+
+def make_cameras(camera_data: List[CameraData]):
+    """inference/utils.py:197-211: list of CameraData -> PandasTensorCollection(infos: batch_im_id, resolution; K [B,3,3])"""
+    import pandas as pd
+
+    from .tcoll import PandasTensorCollection
+
+    infos, K = [], []
+    for n, cam in enumerate(camera_data):
+        K.append(torch.tensor(cam.K))
+        infos.append(dict(batch_im_id=n, resolution=cam.resolution))
+    return PandasTensorCollection(infos=pd.DataFrame(infos), K=torch.stack(K))

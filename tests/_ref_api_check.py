@@ -165,6 +165,7 @@ except Exception as e:  # noqa: BLE001
 # (i-c) scene annotation types of the inference script: JSON produced / parsed like the reference's (datasets/scene_dataset.py)
 def _scene_data_behaviour():
     import numpy as np
+    import torch
     import megapose.datasets.scene_dataset as r_sd
     import megapose.lib3d.transform as r_tr
 
@@ -216,6 +217,10 @@ def _scene_data_behaviour():
     da, db = r_iu.make_detections_from_object_data(ro), o_sd.make_detections_from_object_data(oo)
     if not da.infos.equals(db.infos) or not (da.bboxes.numpy() == db.bboxes.numpy()).all():
         problems.append("make_detections_from_object_data differs from the reference")
+    cams_r = r_iu.make_cameras([r_sd.CameraData.from_json(cs), r_sd.CameraData.from_json(cs)])
+    cams_o = o_sd.make_cameras([o_sd.CameraData.from_json(cs), o_sd.CameraData.from_json(cs)])
+    if not cams_r.infos.equals(cams_o.infos) or not torch.equal(cams_r.K, cams_o.K):
+        problems.append("make_cameras differs from the reference")
     # the example script: same public functions, same signatures
     import megapose6d_amd.scripts.run_inference_on_example as o_ex
 
