@@ -906,6 +906,8 @@ extern "C" int mp_detector_forward(mp_detector* d, const float* d_images, int n,
   int rc = det_make_plan(d, n, H, W, &p);
   if (rc) return rc;
   MP_REQUIRE(ws_bytes >= p.total * sizeof(float), "mp_detector_forward: workspace %zu < %zu bytes", ws_bytes, p.total * sizeof(float));
+  MP_REQUIRE((long)n * p.a_total < (1L << 31) && (long)n * (d->C - 1) * d->cfg.rpn_post_nms_top_n < (1L << 31),
+             "mp_detector_forward: %d images of %d anchors exceed the 32-bit index range of the selection kernels; split the batch", n, p.a_total);
   const mp_detector_config& cfg = d->cfg;
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)d_ws;
