@@ -6,7 +6,6 @@ Tolerances: feature maps 1e-3 relative to their scale (fp32 MFMA vs MKL-DNN summ
 boxes 5e-2 px, scores 2e-4, labels exact; a couple of detections may swap or drop where two scores tie within round-off.
 (The same comparison runs torch-free in scripts/microbench/native_detector_check.cpp; its MI355X log is profiles/r02_detector_native_check.txt.)"""
 from pathlib import Path
-from types import SimpleNamespace
 
 import numpy as np
 import pytest

@@ -7,17 +7,12 @@ piece has an EXACT statement in terms of the fp32 path, checked bit for bit thro
   * backbone:     forward_f16(x) == forward(float(x)) at a batch that runs the stem single-pass;
   * normalize_depth_f16 == round(normalize_depth(float(x))).
 End to end the HIP pipeline in this mode is compared with the oracle run with `input_f16` (the same rounding applied to its
-CNN input, oracle/pipeline.py), tolerances as in test_gpu_pipeline.py.
-(File name sorts last on purpose: this mode was written in a session without GPU access; `pytest -x` must reach every other
-file first.)"""
+CNN input, oracle/pipeline.py) in tests/test_gpu_zzzz_oracle_heavy.py."""
 import tempfile
 
 import numpy as np
-import pandas as pd
 import pytest
 import torch
-
-from conftest import assert_logits_close  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

@@ -60,7 +60,6 @@ def test_detector_vs_a_fresh_oracle_run_and_through_the_detector_wrapper():
 def test_pipeline_in_fp16_renders_mode_vs_oracle(scene72):
     """72-rotation grid, top-2, 3 refiner iterations: HIP pipeline with render_dtype=float16 vs the oracle with the same rounding
     of its CNN input.  Tolerances of test_gpu_pipeline.py (poses 1e-4, logits 1e-4 / 5e-4 of their scale)."""
-    from megapose6d_amd.pose_estimator import load_SO3_grid
     from oracle import harness
 
     ds, est, obs, det, gt = scene72
