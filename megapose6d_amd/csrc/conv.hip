@@ -482,6 +482,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);
         CPROF(2)
       }
+      // (experiment, MP_CONV_EXPERIMENTS builds only: | 32768 = raise the wave's issue priority for the duration of an MFMA group, so
+      //  that the co-resident workgroup's loads / LDS traffic never delay the next MFMA of the wave that owns the matrix pipe)
+      if constexpr ((VARIANT & 32768) != 0) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
+      if constexpr ((VARIANT & 32768) != 0) __builtin_amdgcn_s_setprio(0);
     }
     CPROF(3)
     __syncthreads();
@@ -863,6 +867,10 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     case 12289: return small ? launch<128, 64, 64, 32, 12289>(p, s, alg_k) : launch<128, 128, 64, 64, 12289>(p, s, alg_k);  // 4097 with buffer loads
     case 4097: return small ? launch<128, 64, 64, 32, 4097>(p, s, alg_k) : launch<128, 128, 64, 64, 4097>(p, s, alg_k);  // two-chunks-ahead pipeline, barrier before the last group
     case 24833: return small ? launch<128, 64, 64, 32, 24833>(p, s, alg_k) : launch<128, 128, 64, 64, 24833>(p, s, alg_k);  // 8449 with persistent workgroups
+#ifdef MP_CONV_EXPERIMENTS   // `make variant NAME=exp DEFS=-DMP_CONV_EXPERIMENTS`: never in the product library
+    case 41217: return small ? launch<128, 64, 64, 32, 41217>(p, s, alg_k) : launch<128, 128, 64, 64, 41217>(p, s, alg_k);  // 8449 + s_setprio around the MFMA groups
+    case 57601: return small ? launch<128, 64, 64, 32, 57601>(p, s, alg_k) : launch<128, 128, 64, 64, 57601>(p, s, alg_k);  // persistent + s_setprio
+#endif
     default: return small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k) : launch<128, 128, 64, 64, 8449>(p, s, alg_k);
   }
 }
