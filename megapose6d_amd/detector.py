@@ -58,10 +58,13 @@ class Detector(torch.nn.Module):
             scores_n = torch.as_tensor(out_n["scores"]).cpu().tolist()
             infos += [dict(batch_im_id=n, label=l, score=float(s)) for l, s in zip(labels_n, scores_n)]
             bboxes.append(torch.as_tensor(out_n["boxes"]).to(device))
-            masks.append(torch.as_tensor(out_n["masks"])[:, 0].to(device) > mask_th)
+            if "masks" in out_n:
+                masks.append(torch.as_tensor(out_n["masks"])[:, 0].to(device) > mask_th)
+            elif output_masks:   # (engine model with compute_masks = False)
+                raise ValueError("output_masks=True, but the detection model returned no masks (DetectorMaskRCNN.compute_masks is off)")
         if len(bboxes) > 0:
             bboxes_t = torch.cat(bboxes).float()
-            masks_t = torch.cat(masks)
+            masks_t = torch.cat(masks) if masks else None
             infos_df = pd.DataFrame(infos)
         else:  # (the reference builds an empty frame from a dict of empty lists, detector.py:117-120)
             infos_df = pd.DataFrame(dict(score=[], label=[], batch_im_id=[]))

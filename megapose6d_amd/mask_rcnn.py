@@ -28,6 +28,9 @@ class DetectorMaskRCNN(nn.Module):
         self.min_size, self.max_size = int(min(input_resize)), int(max(input_resize))
         self.anchor_sizes = tuple(int(s[0]) for s in anchor_sizes)
         self.engine_overrides: Dict[str, object] = {}   # mp_detector_config fields, e.g. {"box_score_thresh": 0.0}
+        # False: skip the mask head and the [n, D, H, W] pasted masks (mp_detector_forward with d_masks = NULL); the returned dicts then
+        # carry no "masks" entry.  Default True = torchvision's contract (Detector.get_detections reads the masks of every detection).
+        self.compute_masks: bool = True
         self._engine: Optional[eng.DetectorNet] = None
         # parameter tree with torchvision's state_dict keys: conv / linear weights and biases are Parameters, the FrozenBatchNorm2d
         # statistics and affine terms are buffers (ops/misc.py), exactly as in a reference checkpoint
@@ -73,9 +76,11 @@ class DetectorMaskRCNN(nn.Module):
         net = self._net()
         for (H, W), idx in groups.items():
             batch = torch.stack([images[i] for i in idx]).to(device="cuda", dtype=torch.float32)
-            boxes, scores, labels, counts, masks = net.forward(batch, with_masks=True)
+            boxes, scores, labels, counts, masks = net.forward(batch, with_masks=self.compute_masks)
             counts_h = counts.cpu().tolist()   # the only host touch: the per-image detection counts size the returned views
             for j, i in enumerate(idx):
                 k = counts_h[j]
-                out[i] = dict(boxes=boxes[j, :k], labels=labels[j, :k].long(), scores=scores[j, :k], masks=masks[j, :k, None])
+                out[i] = dict(boxes=boxes[j, :k], labels=labels[j, :k].long(), scores=scores[j, :k])
+                if masks is not None:
+                    out[i]["masks"] = masks[j, :k, None]
         return out  # type: ignore[return-value]

@@ -433,3 +433,24 @@ def test_detector_wrapper_builds_the_detections_collection():
     assert sorted(zip(one.infos["label"], one.infos["score"].round(3))) == [("a", 0.2), ("b", 0.9)]
     assert not det.get_detections(obs, output_masks=True, mask_th=0.9).masks.any()
     assert det.image_tensor_from_numpy(np.zeros((6, 8, 3), np.uint8)).shape == (3, 6, 8)
+
+
+def test_detector_wrapper_accepts_models_that_skip_the_mask_head():
+    """DetectorMaskRCNN(compute_masks=False) returns no "masks": fine unless the caller asks for them"""
+    from types import SimpleNamespace
+
+    from megapose6d_amd.detector import Detector
+    from megapose6d_amd.types import ObservationTensor
+
+    class NoMasks(torch.nn.Module):
+        config = SimpleNamespace(label_to_category_id={"a": 1})
+
+        def forward(self, images):
+            return [dict(boxes=torch.tensor([[1.0, 2, 5, 6]]), labels=torch.tensor([1]), scores=torch.tensor([0.9]))]
+
+    det = Detector(NoMasks())
+    obs = ObservationTensor(images=torch.rand(1, 3, 6, 8))
+    d = det.get_detections(obs)
+    assert len(d) == 1 and "masks" not in d.tensors and d.infos["label"].tolist() == ["a"]
+    with pytest.raises(ValueError):
+        det.get_detections(obs, output_masks=True)
