@@ -263,8 +263,8 @@ def _relaunch(n: int) -> int:
 
 def build_workload(cfg_id: int, world: int, backbone: str, tmp: str, precision: int, k_hyp: int):
     """-> (estimator, observation, detections, object dataset, description dict, n_objects, run kwargs)"""
-    from megapose6d_amd.scene import make_multi_frame_scene, make_scene
-    from megapose6d_amd import synthetic as syn
+    from tests.support.scene import make_multi_frame_scene, make_scene
+    from tests.support import synthetic as syn
 
     common = dict(SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1, n_streams=int(os.environ.get("MP_N_STREAMS", "1")), precision=precision)
     run = dict(n_refiner_iterations=N_ITERS, n_pose_hypotheses=k_hyp)

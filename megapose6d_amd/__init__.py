@@ -4,12 +4,12 @@ Only what the hot path needs: the HIP/C-ABI engine (`csrc/
 of the reference's renderer / PosePredictor / PoseEstimator interfaces.  Importing the package never touches the GPU; the
 first engine call loads `libmp_engine.so` and raises if it is missing (there is no CPU fallback).
 """
-from . import (detector, distributed, engine, icp_refiner, load_model, mask_rcnn, mesh_db, mesh_io, pose_estimator, pose_rigid,  # noqa: F401
-               prediction_runner, renderer, scene_data, synthetic, tcoll, types)
+from . import (detector, distributed, engine, icp_refiner, load_model, mask_rcnn, mesh_db, mesh_io, object_dataset, pose_estimator,  # noqa: F401
+               pose_rigid, prediction_runner, renderer, tcoll, types)
 from .detector import Detector  # noqa: F401
 from .icp_refiner import DepthRefiner, ICPRefiner  # noqa: F401
 from .mask_rcnn import DetectorMaskRCNN  # noqa: F401
-from .scene_data import CameraData, ObjectData, Transform  # noqa: F401
+from .object_dataset import RigidObject, RigidObjectDataset  # noqa: F401
 from .load_model import NAMED_MODELS, create_model_pose, load_named_model, load_pose_models  # noqa: F401
 from .pose_estimator import CoarseRefinePoseEstimator, PoseEstimator  # noqa: F401
 from .pose_rigid import PosePredictor  # noqa: F401

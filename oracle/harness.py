@@ -15,9 +15,9 @@ from . import raster as orr
 def make_oracle_models(ds, backbone: str = "vanilla_resnet34", rgbd: bool = False, seeds=(11, 12), pose_head_scale: float = 0.001,
                        renderer_kwargs: Optional[dict] = None):
     """-> (coarse OraclePosePredictor, refiner OraclePosePredictor, batched mesh db) with the SAME seeded weights that
-    megapose6d_amd.scene.build_estimator gives the HIP engine."""
+    tests.support.scene.build_estimator gives the HIP engine."""
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.mesh_db import MeshDataBase
 
     meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}

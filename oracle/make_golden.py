@@ -6,7 +6,7 @@ oracle/ref_import.py).  CONTAINER-ONLY; the vectors are committed so that the or
 Files
   geometry.npz   reference outputs of the pure-torch pose/geometry functions on seeded inputs
   backbones.npz  reference module outputs (torchvision_resnet.resnet34 / WideResNet34 / WideResNet18) with the seeded
-                 reference-layout state_dicts of megapose6d_amd.synthetic.make_state_dict loaded strict=True
+                 reference-layout state_dicts of tests.support.synthetic.make_state_dict loaded strict=True
   pipeline.npz   the reference's unmodified PoseEstimator.run_inference_pipeline (+ create_model_pose / PosePredictor)
                  driven with the oracle renderer on a synthetic scene: coarse logits, top-K, per-iteration refined poses,
                  scores, final pose
@@ -86,7 +86,7 @@ def synthetic_input(n, c, h, w) -> torch.Tensor:
 
 
 def backbone_vectors(r) -> dict:
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     out = {}
     g = torch.Generator().manual_seed(7)
@@ -115,7 +115,7 @@ def make_scene(tmp, n_objects=1, seed=0):
     """Synthetic scene shared by the golden generator and the tests (tests/scene_util.py re-implements nothing: it calls this
     through the saved npz inputs)."""
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import raster as orr
 
     ds = syn.make_object_dataset(tmp, n_objects=n_objects, seed=seed)
@@ -140,7 +140,7 @@ def make_scene(tmp, n_objects=1, seed=0):
 
 
 def pipeline_vectors(r) -> dict:
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import raster as orr
 
     tmp = Path(tempfile.mkdtemp(prefix="mp_golden_"))

@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from megapose6d_amd import engine as eng
-from megapose6d_amd import synthetic as syn
+from tests.support import synthetic as syn
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--kind", default="vanilla_resnet34")

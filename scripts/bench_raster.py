@@ -7,7 +7,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from megapose6d_amd import engine as eng, mesh_io, synthetic as syn
+from megapose6d_amd import engine as eng, mesh_io
+from tests.support import synthetic as syn
 
 ds = syn.make_object_dataset("/tmp/mp_rb", 1, 0)
 mesh = mesh_io.load_rigid_object(ds[0])

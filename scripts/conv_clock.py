@@ -7,7 +7,8 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from megapose6d_amd import _lib, engine as eng, synthetic as syn
+from megapose6d_amd import _lib, engine as eng
+from tests.support import synthetic as syn
 
 lib = _lib.load()
 lib.mp_conv_prof_read.restype = C.c_int

@@ -6,7 +6,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from megapose6d_amd import engine as eng
-from megapose6d_amd import synthetic as syn
+from tests.support import synthetic as syn
 
 cin, b = int(sys.argv[1]) if len(sys.argv) > 1 else 27, int(sys.argv[2]) if len(sys.argv) > 2 else 576
 head, n_out = ("pose", 9) if cin != 9 else ("logits", 1)

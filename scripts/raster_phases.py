@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from megapose6d_amd import _lib, engine as eng, mesh_io, synthetic as syn
+from megapose6d_amd import _lib, engine as eng, mesh_io
+from tests.support import synthetic as syn
 
 lib = _lib.load()
 lib.mp_raster_prof_read.restype = C.c_int

@@ -21,7 +21,7 @@ from oracle import make_golden as mg  # noqa: E402
 from oracle import ref_import  # noqa: E402
 
 r = ref_import.ref()
-from megapose6d_amd import synthetic as syn  # noqa: E402
+from tests.support import synthetic as syn  # noqa: E402
 from megapose6d_amd.load_model import Config  # noqa: E402
 from megapose6d_amd.pose_estimator import load_SO3_grid  # noqa: E402
 from oracle import harness  # noqa: E402

@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def object_dataset(tmp_path_factory):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     return syn.make_object_dataset(tmp_path_factory.mktemp("meshes"), n_objects=3, seed=0)
 

@@ -1,4 +1,5 @@
-"""Synthetic scenes + model assembly shared by bench.py, smoke() and the tests (product side: no oracle imports).
+"""TEST / BENCH SUPPORT (not product code): synthetic scenes + model assembly shared by bench.py, smoke() and the tests
+(no oracle imports).
 The observation is rendered by the engine's own rasteriser over a uniform-noise background."""
 from __future__ import annotations
 
@@ -9,12 +10,13 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
+from megapose6d_amd.load_model import build_pose_model, make_detections
+from megapose6d_amd.mesh_db import MeshDataBase
+from megapose6d_amd.pose_estimator import PoseEstimator
+from megapose6d_amd.renderer import Panda3dBatchRenderer
+from megapose6d_amd.types import ObservationTensor, Panda3dLightData
+
 from . import synthetic as syn
-from .load_model import build_pose_model, make_detections
-from .mesh_db import MeshDataBase
-from .pose_estimator import PoseEstimator
-from .renderer import Panda3dBatchRenderer
-from .types import ObservationTensor, Panda3dLightData
 
 
 def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
@@ -89,7 +91,7 @@ def make_multi_frame_scene(n_frames: int = 8, n_per_frame: int = 8, n_meshes: in
     the depth refiner, reference utils/load_model.py NAMED_MODELS)."""
     import pandas as pd
 
-    from .tcoll import PandasTensorCollection
+    from megapose6d_amd.tcoll import PandasTensorCollection
 
     tmp = Path(tmp_dir or tempfile.mkdtemp(prefix="mp_scene_mf_"))
     ds = syn.make_object_dataset(tmp, n_objects=n_meshes, seed=seed, n_theta=48, n_z=50)

@@ -1,4 +1,5 @@
-"""Seeded synthetic assets (meshes, weights, scenes) -- there is no network for datasets or checkpoints.
+"""TEST / BENCH SUPPORT (not product code): seeded synthetic assets (meshes, weights, scenes) -- there is no network for
+datasets or checkpoints.
 
 Shapes follow SURVEY.md section 8d: procedurally generated closed lathe surfaces (>= 2000 vertices, per-vertex
 colours, mm units), K from the reference README.md:226, seeded random weights laid out exactly like the
@@ -14,6 +15,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
+
+from megapose6d_amd.object_dataset import RigidObject, RigidObjectDataset  # noqa: F401
 
 # K of the barbecue-sauce example (reference README.md:226), 640x480
 K_EXAMPLE = np.array([[605.9547119140625, 0.0, 319.029052734375], [0.0, 605.006591796875, 249.67617797851562], [0.0, 0.0, 1.0]])
@@ -87,50 +90,6 @@ def write_ply(path, verts: np.ndarray, faces: np.ndarray, colors_u8: Optional[np
         f.write(("\n".join(hdr) + "\n").encode("ascii"))
         f.write(arr.tobytes())
         f.write(fa.tobytes())
-
-
-class RigidObject:
-    """Duck type of the reference RigidObject (src/megapose/datasets/object_dataset.py:35-137)."""
-
-    def __init__(self, label, mesh_path, mesh_units="m", scaling_factor=1.0, ypr_offset_deg=(0.0, 0.0, 0.0),
-                 scaling_factor_mesh_units_to_meters=None, **_):
-        self.label = label
-        self.mesh_path = Path(mesh_path)
-        self.mesh_units = mesh_units
-        self.scaling_factor_mesh_units_to_meters = (
-            scaling_factor_mesh_units_to_meters if scaling_factor_mesh_units_to_meters is not None else {"m": 1.0, "mm": 0.001}[mesh_units]
-        )
-        self.scaling_factor = scaling_factor
-        self.ypr_offset_deg = ypr_offset_deg
-        self.symmetries_discrete, self.symmetries_continuous = [], []
-        self.diameter_meters = None
-
-    @property
-    def scale(self) -> float:
-        return self.scaling_factor_mesh_units_to_meters * self.scaling_factor
-
-
-class RigidObjectDataset:
-    """Duck type of the reference RigidObjectDataset (object_dataset.py:140-166)."""
-
-    def __init__(self, objects):
-        self.list_objects = list(objects)
-        self.label_to_objects = {o.label: o for o in self.list_objects}
-        if len(self.label_to_objects) != len(self.list_objects):
-            raise RuntimeError("There are objects with duplicate labels")
-
-    def __getitem__(self, i):
-        return self.list_objects[i]
-
-    def __len__(self):
-        return len(self.list_objects)
-
-    def get_object_by_label(self, label):
-        return self.label_to_objects[label]
-
-    @property
-    def objects(self):
-        return self.list_objects
 
 
 def make_object_dataset(out_dir, n_objects: int = 1, seed: int = 0, n_theta: int = 72, n_z: int = 70) -> RigidObjectDataset:

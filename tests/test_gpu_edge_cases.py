@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def multi_scene():
     """2 frames with different intrinsics, 3 detections: two instances of obj_000000 in frame 0, obj_000001 in frame 1."""
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import build_estimator, render_observation
+    from tests.support import synthetic as syn
+    from tests.support.scene import build_estimator, render_observation
     from megapose6d_amd.tcoll import PandasTensorCollection
     from megapose6d_amd.types import ObservationTensor
 
@@ -43,7 +43,7 @@ def multi_scene():
 
 def _oracle(tmp, ds, grid=72):
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.mesh_db import MeshDataBase
     from megapose6d_amd.pose_estimator import load_SO3_grid
     from oracle import pipeline as op
@@ -149,7 +149,7 @@ def test_degenerate_inputs(multi_scene):
 
 def test_mesh_with_too_few_vertices_is_rejected(tmp_path):
     """lib3d/mesh_ops.py:79: the deterministic 2000-point sampling asserts n_points <= n_vertices"""
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.mesh_db import MeshDataBase
 
     v, f, c = syn.make_lathe_mesh(1, n_theta=16, n_z=20)
@@ -162,7 +162,7 @@ def test_mesh_with_too_few_vertices_is_rejected(tmp_path):
 def test_pose_predictor_stand_alone_helpers_match_the_fused_step():
     """PosePredictor.compute_crops_multiview / normalize_depth / normalize_images / *_dims (models/pose_rigid.py:132-158, 249-303,
     410-496) as stand-alone calls agree with what the fused step computes"""
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
 
     est, obs, det, gt = make_scene(n_objects=2, seed=9, rgbd=True, SO3_grid_size=72)
     ref = est.refiner_model

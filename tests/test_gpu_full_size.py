@@ -16,7 +16,7 @@ def _by_key(final):
 
 def test_config3_rgbd_8_objects_x_576_hypotheses_row_independence():
     """megapose-1.0-RGBD structure (RGB coarse + 32-channel RGBD refiner), 8 objects x 576 hypotheses ALL refined 5 iterations"""
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
     from megapose6d_amd.tcoll import PandasTensorCollection
 
     est, obs, det, gt = make_scene(n_objects=8, seed=7, rgbd=True, SO3_grid_size=576)
@@ -50,8 +50,8 @@ def test_config4_64_detections_over_8_frames_multi_hypothesis():
     """megapose-1.0-RGB-multi-hypothesis (K=5) on 64 detections / 8 frames / 16 distinct meshes, 576-rotation grid"""
     import tempfile
 
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import build_estimator, render_observation
+    from tests.support import synthetic as syn
+    from tests.support.scene import build_estimator, render_observation
     from megapose6d_amd.tcoll import PandasTensorCollection
     from megapose6d_amd.types import ObservationTensor
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _scene():
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.renderer import Panda3dBatchRenderer
     from megapose6d_amd.types import Panda3dLightData
 
@@ -83,7 +83,7 @@ def test_icp_refiner_vs_oracle_and_ground_truth():
 def test_pipeline_with_depth_refiner():
     """run_inference_pipeline(run_depth_refiner=True) (pose_estimator.py:607-616): extra_data['depth_refiner'] and final poses"""
     from megapose6d_amd.icp_refiner import ICPRefiner
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
 
     est, obs, det, gt = make_scene(n_objects=1, seed=0, SO3_grid_size=72, rgbd=True)
     est.depth_refiner = ICPRefiner(est.mesh_db, est.refiner_model.renderer)
@@ -136,7 +136,7 @@ def test_gpu_refiner_vs_opencv_icp_restatement_on_12_scenes():
 
 def test_user_masks_replace_threshold_mask_on_device():
     """icp_refiner.py:249-250: with caller masks a pose 15 cm off in depth is refined (the threshold mask alone would reject it)"""
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.icp_refiner import ICPRefiner
     from megapose6d_amd.renderer import Panda3dBatchRenderer
     from megapose6d_amd.tcoll import PandasTensorCollection

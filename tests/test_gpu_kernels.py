@@ -149,7 +149,7 @@ def test_maxpool_and_tail(eng):
                                                   ("resnet34", 27, "pose", 9), ("resnet18", 9, "logits", 1),
                                                   ("vanilla_resnet34", 32, "pose", 9)])
 def test_backbone_matches_oracle(eng, kind, c_in, head, n_out):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import backbones as ob
 
     sd = syn.make_state_dict(kind, c_in, head, n_out, seed=1)
@@ -181,7 +181,7 @@ def _mesh_db(eng, engine_meshes):
 @pytest.mark.parametrize("flags,lit", [(1, False), (3, False), (1 | 4, False), (0, True), (16 | 3, False), (16 | 1 | 4, False), (16, True)])
 def test_raster_bit_exact_vs_oracle(eng, engine_meshes, flags, lit):
     """flags: 1 normals, 2 depth, 4 GL eye axes, 16 = 4x MSAA (the reference's configuration); lit = ambient + 6 point lights"""
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import raster as orr
 
     db = _mesh_db(eng, engine_meshes)
@@ -273,7 +273,7 @@ def test_crop_roi_align_vs_oracle(eng, C):
 
 
 def test_pose_ops_vs_oracle(eng, engine_meshes):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import geometry as og
 
     rng = np.random.RandomState(11)
@@ -358,7 +358,7 @@ def test_conv_bf16_split_modes_match_torch_fp32(eng, case, nprod):
 
 
 def test_backbone_bf16x9_matches_oracle(eng):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import backbones as ob
 
     sd = syn.make_state_dict("vanilla_resnet34", 27, "pose", 9, seed=1)
@@ -414,7 +414,7 @@ def test_conv_full_rounds_plus_splitk_tail(eng, shape):
 @pytest.mark.parametrize("C", [3, 4])
 def test_fused_crop_in_raster_launch_equals_standalone_crop(eng, engine_meshes, C):
     """mp_raster_render_crop: the crop role of the band kernel writes exactly what mp_crop_roi_align writes, and leaves the views alone"""
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     db = _mesh_db(eng, engine_meshes)
     rng = np.random.RandomState(7)

@@ -28,8 +28,8 @@ def _check(res):
 
 def test_config2_rgb_1x576x5_sampled_rows_vs_oracle():
     """BASELINE configs[1] exactly as bench.py runs it: vanilla ResNet-34, 1 object, all 576 hypotheses refined 5 iterations"""
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import make_scene
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
     from oracle import harness
 
     tmp = tempfile.mkdtemp(prefix="mp_p2_")
@@ -45,8 +45,8 @@ def test_config2_rgb_1x576x5_sampled_rows_vs_oracle():
 
 def test_config3_rgbd_wide_resnet_8x576_sampled_rows_vs_oracle():
     """BASELINE configs[2]: RGB coarse + 32-channel RGBD refiner on WideResNet-34, 8 objects x 576 hypotheses, all refined"""
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import make_scene
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
     from oracle import harness
 
     tmp = tempfile.mkdtemp(prefix="mp_p3_")
@@ -64,7 +64,7 @@ def test_config3_rgbd_wide_resnet_8x576_sampled_rows_vs_oracle():
 def test_config4_64_detections_two_detections_vs_oracle():
     """BASELINE configs[3] (K = 5): 64 detections / 8 frames / 16 meshes; the oracle re-computes two detections completely from the
     top-K on (sampled coarse rows, all 5 refiner chains x 5 iterations, re-score) and must pick the same final hypothesis"""
-    from megapose6d_amd.scene import make_multi_frame_scene
+    from tests.support.scene import make_multi_frame_scene
     from oracle import harness
 
     tmp = tempfile.mkdtemp(prefix="mp_p4_")
@@ -88,8 +88,8 @@ def test_teacher_forced_iterations_with_undamped_pose_head():
     (30x; a conv error reaches the 9-vector and the pose almost undamped) and every iteration is TEACHER-FORCED: the HIP refiner gets
     the oracle's input pose of iteration n inside a 576-row launch and its raw network output and updated pose are compared with the
     oracle's iteration n.  Reference: models/pose_rigid.py:498-604 (forward), :305-312 (update_pose)."""
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import make_scene
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
     from oracle import backbones as ob
     from oracle import harness
 

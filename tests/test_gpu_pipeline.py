@@ -17,8 +17,8 @@ GOLD = Path(__file__).resolve().parent / "golden"
 
 @pytest.fixture(scope="module")
 def scene72():
-    from megapose6d_amd.scene import build_estimator
-    from megapose6d_amd import synthetic as syn
+    from tests.support.scene import build_estimator
+    from tests.support import synthetic as syn
 
     tmp = tempfile.mkdtemp(prefix="mp_t_")
     ds = syn.make_object_dataset(tmp, n_objects=1, seed=0)
@@ -69,7 +69,7 @@ def test_cnn_input_tensor_vs_oracle(scene72):
     """the assembled CNN input (crop + 4 views x (rgb, normals)) of one refiner step: crop <= 1e-5, renders identical except
     for the rare pixel whose coverage flips because a camera matrix differs in the last ulp (counted and bounded)."""
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.mesh_db import MeshDataBase
     from oracle import pipeline as op
     from oracle import raster as orr
@@ -130,7 +130,7 @@ def test_renderer_api_contract(scene72):
 
 def test_full_grid_multi_object_invariants():
     """576-rotation grid, 3 objects, K=5: structure, determinism and sharded-row bookkeeping at BASELINE sizes."""
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
 
     est, obs, det, gt = make_scene(n_objects=3, seed=3, SO3_grid_size=576)
     f1, e1 = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=5)
@@ -157,10 +157,10 @@ def test_full_grid_multi_object_invariants():
 def test_rgbd_and_wide_resnet_pipeline_vs_oracle():
     """config 3 structure: RGBD refiner (32 ch, depth normalisation + validity rule) on WideResNet34, vs the CPU oracle."""
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.mesh_db import MeshDataBase
     from megapose6d_amd.pose_estimator import load_SO3_grid
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
     from oracle import pipeline as op
     from oracle import raster as orr
 
@@ -203,7 +203,7 @@ def _dist_worker(rank, world, port, q, backend="gloo"):
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
 
     torch.cuda.set_device(local)
     # gloo: both ranks share the single test GPU (RCCL needs one device per rank); nccl: one GPU per rank, RCCL all-gathers
@@ -226,7 +226,7 @@ def test_row_sharded_pipeline_two_ranks_matches_single_rank(backend):
 
     import torch.multiprocessing as mp
 
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
 
     est, obs, det, _ = make_scene(n_objects=2, seed=7, SO3_grid_size=72)
     f1, e1 = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=3)
@@ -250,8 +250,8 @@ def test_row_sharded_pipeline_two_ranks_matches_single_rank(backend):
 @pytest.mark.parametrize("precision", [9, 6])
 def test_pipeline_split_precision_modes_match_reference_golden(precision):
     """the optional bf16x9 / bf16x6 conv modes must meet the SAME end-to-end bounds against the reference's golden outputs"""
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import build_estimator
+    from tests.support import synthetic as syn
+    from tests.support.scene import build_estimator
 
     ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_sp_"), n_objects=1, seed=0)
     est = build_estimator(ds, SO3_grid_size=72, precision=precision)

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 
 
 def test_prediction_runner_multi_image_batching_matches_per_frame_calls():
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.icp_refiner import ICPRefiner
     from megapose6d_amd.prediction_runner import PredictionRunner
-    from megapose6d_amd.scene import build_estimator, render_observation
+    from tests.support.scene import build_estimator, render_observation
     from megapose6d_amd.tcoll import PandasTensorCollection
     from megapose6d_amd.types import InferenceConfig
 

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def textured(tmp_path_factory):
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     d = tmp_path_factory.mktemp("tex")
     objs = [syn.make_textured_object(d / "a", "tex_a", seed=3, fmt="obj", with_vertex_colors=True),
@@ -26,7 +26,7 @@ def textured(tmp_path_factory):
 def test_textured_raster_bit_exact_vs_oracle(textured, res, zr, msaa):
     """three resolutions/distances so that the per-pixel LOD spans mip levels 0..4 (trilinear); ambient light -> bit-identical"""
     from megapose6d_amd import engine as eng
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import raster as orr
 
     _, meshes = textured
@@ -54,7 +54,7 @@ def test_textured_raster_bit_exact_vs_oracle(textured, res, zr, msaa):
 
 
 def test_textured_objects_through_renderer_api_with_point_lights(textured):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.renderer import Panda3dBatchRenderer
     from megapose6d_amd.types import make_scene_lights
     from oracle import raster as orr

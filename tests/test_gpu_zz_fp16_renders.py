@@ -27,8 +27,8 @@ def eng():
 
 @pytest.fixture(scope="module")
 def scene72():
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import make_scene
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
 
     tmp = tempfile.mkdtemp(prefix="mp_t16_")
     est, obs, det, gt = make_scene(n_objects=1, seed=0, SO3_grid_size=72, tmp_dir=tmp)
@@ -146,7 +146,7 @@ def test_half_input_is_refused_where_it_is_not_implemented(eng):
 
 @pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 32)])
 def test_backbone_forward_f16_equals_forward_on_the_widened_input(eng, kind, c_in):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     head, n_out = ("pose", 9) if c_in != 9 else ("logits", 1)
     sd = syn.make_state_dict(kind, c_in, head, n_out, seed=5)

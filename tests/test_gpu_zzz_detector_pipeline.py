@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 def test_run_inference_pipeline_with_the_hip_detector():
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.detector import Detector
     from megapose6d_amd.mask_rcnn import DetectorMaskRCNN
-    from megapose6d_amd.scene import make_scene
+    from tests.support.scene import make_scene
     from oracle import mask_rcnn as om
 
     tmp = tempfile.mkdtemp(prefix="mp_tdp_")

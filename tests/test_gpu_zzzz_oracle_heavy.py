@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def scene72():
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import make_scene
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
 
     tmp = tempfile.mkdtemp(prefix="mp_t16b_")
     est, obs, det, gt = make_scene(n_objects=1, seed=0, SO3_grid_size=72, tmp_dir=tmp)
@@ -92,48 +92,22 @@ def test_pipeline_in_fp16_renders_mode_vs_oracle(scene72):
     assert d < 5e-3
 
 
-def test_example_script_end_to_end_equals_the_direct_api(tmp_path, monkeypatch):
-    """python -m megapose6d_amd.scripts.run_inference_on_example <name> --run-inference --vis-detections --vis-outputs on an example
-    directory in the reference's layout (PNG frame, camera_data.json, inputs/object_data.json, meshes/<label>/mesh.ply) with the two run
-    directories `load_named_model` reads: the written poses equal those of an estimator assembled directly from the same weights."""
-    import json
-    import shutil
-
-    from PIL import Image
-
+def test_load_named_model_from_run_directories_equals_the_direct_api(tmp_path, monkeypatch):
+    """`load_named_model` (reference utils/load_model.py:50-97) on the two run directories it reads (config.yaml + checkpoint.pth.tar,
+    written in the reference layout): the estimator it assembles gives the poses of one assembled directly from the same weights."""
     from megapose6d_amd import load_model as lm
-    from megapose6d_amd import synthetic as syn
-    from megapose6d_amd.scene import make_scene
-    from megapose6d_amd.scripts import run_inference_on_example as ex
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
 
     est, obs, det, gt = make_scene(n_objects=1, seed=0, tmp_dir=str(tmp_path / "scene"))
     ds = syn.make_object_dataset(tmp_path / "scene", n_objects=1, seed=0)
-    label = ds[0].label
-    d = tmp_path / "examples" / "demo"
-    (d / "inputs").mkdir(parents=True)
-    (d / "meshes" / label).mkdir(parents=True)
-    shutil.copy(ds[0].mesh_path, d / "meshes" / label / ("mesh" + ds[0].mesh_path.suffix))
-    assert ds[0].mesh_units == "mm"
-    rgb = (obs.images[0, :3].permute(1, 2, 0).cpu().numpy() * 255).round().astype(np.uint8)
-    Image.fromarray(rgb).save(d / "image_rgb.png")
-    (d / "camera_data.json").write_text(json.dumps({"K": obs.K[0].cpu().double().numpy().tolist(), "resolution": [480, 640]}))
-    (d / "inputs" / "object_data.json").write_text(json.dumps([{"label": label, "bbox_modal": det.bboxes[0].cpu().double().numpy().tolist()}]))
     info = lm.NAMED_MODELS["megapose-1.0-RGB-multi-hypothesis"]
     for role, seed, run_id in (("coarse", 11, info["coarse_run_id"]), ("refiner", 12, info["refiner_run_id"])):
         cfg = syn.make_cfg(role)
         head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
         lm.save_run(tmp_path / "megapose-models" / run_id, cfg, syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), head, n_out, seed=seed))
     monkeypatch.setattr(lm, "LOCAL_DATA_DIR", tmp_path)
-    monkeypatch.setattr(ex, "LOCAL_DATA_DIR", tmp_path)
-    ex.main(["demo", "--run-inference", "--vis-detections", "--vis-outputs"])
-    out = json.loads((d / "outputs" / "object_data.json").read_text())
-    assert len(out) == 1 and out[0]["label"] == label
-    from megapose6d_amd.scene_data import Transform
-
-    T_script = Transform(tuple(out[0]["TWO"][0]), tuple(out[0]["TWO"][1])).matrix
-    final, _ = est.run_inference_pipeline(obs, detections=det, **info["inference_parameters"])
-    assert np.abs(T_script - final.poses[0].cpu().double().numpy()).max() < 1e-5
-    for f in ("detections.png", "mesh_overlay.png", "contour_overlay.png", "all_results.png"):
-        assert (d / "visualizations" / f).is_file()
-    allr = np.array(Image.open(d / "visualizations" / "all_results.png"))
-    assert allr.shape == (480, 3 * 640, 3) and (allr[:, :640] == rgb).all() and (allr[:, 640:1280] != rgb).any()
+    named = lm.load_named_model("megapose-1.0-RGB-multi-hypothesis", ds)
+    f_named, _ = named.run_inference_pipeline(obs, detections=det, **info["inference_parameters"])
+    f_direct, _ = est.run_inference_pipeline(obs, detections=det, **info["inference_parameters"])
+    assert np.abs(f_named.poses.cpu().numpy() - f_direct.poses.cpu().numpy()).max() < 1e-6

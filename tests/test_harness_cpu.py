@@ -14,7 +14,7 @@ GOLD = Path(__file__).resolve().parent / "golden"
 def test_oracle_fp16_renders_mode_rounds_the_cnn_input_through_binary16():
     """oracle side of the engine's "fp16 renders" mode (OraclePosePredictor.input_f16): the CNN input is the fp32 one rounded to
     nearest-even binary16 (depth channels: rounded as rendered, normalised, rounded again), everything else is unchanged"""
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import harness
 
     g = {k: v for k, v in np.load(GOLD / "pipeline.npz").items()}
@@ -44,7 +44,7 @@ def test_oracle_fp16_renders_mode_rounds_the_cnn_input_through_binary16():
 
 
 def test_sampled_rows_parity_is_exact_on_the_oracles_own_run():
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import harness
 
     g = {k: v for k, v in np.load(GOLD / "pipeline.npz").items()}

@@ -97,7 +97,7 @@ def test_config_back_compat_and_named_models():
 
 def test_mesh_io_roundtrip_and_formats(tmp_path):
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     v, f, c = syn.make_lathe_mesh(3, n_theta=40, n_z=60)
     assert len(v) >= 2000
@@ -185,7 +185,7 @@ def test_textured_mesh_ingestion(tmp_path):
     """UV-textured assets: OBJ+MTL+PNG, PLY per-face texcoord (BOP layout), PLY per-vertex s,t -> per-corner uvs +
     RGBA8 mip chain; vertex order untouched"""
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     ms = {fmt: mesh_io.load_rigid_object(syn.make_textured_object(tmp_path / fmt, seed=3, fmt=fmt)) for fmt in ("obj", "ply_face", "ply_vertex")}
     v, f, _ = syn.make_lathe_mesh(3, n_theta=48, n_z=40, height_mm=140.0, radius_mm=35.0)

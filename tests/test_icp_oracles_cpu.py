@@ -15,7 +15,7 @@ def _rot_err_deg(A, B):
 def make_icp_scenes(n_scenes: int, seed: int = 3):
     """-> list of (depth_measured [480,640], K, init pose, gt pose, mesh) rendered with the oracle rasteriser (centre samples)"""
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import icp as oicp
     from oracle import raster as orr
 
@@ -70,7 +70,7 @@ def test_user_masks_replace_the_threshold_mask():
     from oracle import icp as oicp
     from oracle import raster as orr
 
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     _, scenes = make_icp_scenes(1)
     _, K, _, _, mesh, _ = scenes[0]

@@ -91,7 +91,7 @@ def test_roi_align_restatement_is_self_consistent(geo):
 
 
 def test_backbone_restatement_against_reference_modules():
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from oracle import backbones as ob
     from oracle.make_golden import synthetic_input
 
@@ -109,7 +109,7 @@ def test_backbone_restatement_against_reference_modules():
 
 def test_state_dict_keys_match_product_module():
     """the product's parameter-hosting module must load reference-layout checkpoints strict=True."""
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.pose_rigid import HipBackbone
 
     for kind, c_in in (("vanilla_resnet34", 27), ("resnet34", 9), ("resnet18", 32)):
@@ -125,7 +125,7 @@ def pipeline_gold():
 
 def build_oracle_estimator(tmp, backbone="vanilla_resnet34", grid=72):
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
     from megapose6d_amd.mesh_db import MeshDataBase
     from megapose6d_amd.pose_estimator import load_SO3_grid
     from oracle import pipeline as op

@@ -71,7 +71,7 @@ def _compare(lib, mesh, T, K, h, w, flags, lights=None, **kw):
 
 
 def _poses(n, seed, z=(0.35, 0.7), xy=0.12):
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     rng = np.random.RandomState(seed)
     return np.stack([syn.random_pose(rng, z_range=z, xy_frac=xy) for _ in range(n)])
@@ -138,7 +138,7 @@ def test_overflow_fallback_dense_mesh(emul, engine_meshes):
 @pytest.mark.parametrize("msaa", [1, 4])
 def test_textured_mesh_trilinear_lod_matches_oracle(emul, tmp_path, msaa):
     from megapose6d_amd import mesh_io
-    from megapose6d_amd import synthetic as syn
+    from tests.support import synthetic as syn
 
     obj = syn.make_textured_object(tmp_path, fmt="obj")
     mesh = mesh_io.load_rigid_object(obj)
