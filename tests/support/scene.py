@@ -20,7 +20,7 @@ from . import synthetic as syn
 
 
 def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
-                    seeds=(11, 12), precision: int = 0, pose_head_scale: float = 0.001, **est_kwargs) -> PoseEstimator:
+                    seeds=(11, 12), precision: int = 0, pose_head_scale: float = syn.POSE_HEAD_SCALE, **est_kwargs) -> PoseEstimator:
     """Seeded random-weight coarse + refiner models in the released recipes' structure, on the HIP engine."""
     renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
     mesh_db = MeshDataBase.from_object_ds(object_dataset).batched().cuda()
