@@ -140,6 +140,81 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
   }
 }
 
+// LDS-transposed epilogue with 16-byte stores (Cout % 4 == 0).  The MFMA C layout gives a lane ONE column of 16 scattered rows, so the
+// direct epilogue above needs TM*TN*16 dword stores (and as many dword residual loads) per wave -- store-ISSUE-bound: 9 % of an
+// 18-chunk layer-1 tile.  Here each wave parks its WM x WN accumulator tile in its own slice of the (now idle) A/B staging LDS
+// (row stride = WN floats: conflict-free for both the ds_write_b32 column writes and the ds_read_b128 row reads) and walks it back in
+// rows: a lane owns 4 consecutive channels of one output pixel -> one buffer_load_b128 of the residual, one buffer_store_b128 of the
+// result (4x fewer VMEM instructions, whole 128/256-byte row segments per 8/16 lanes).  Same arithmetic per element, same masking
+// through the buffer range check.  The wave only touches its own slice: no workgroup barrier.
+template <int TM, int TN, bool RES, bool RELU, bool ACT>
+__device__ __forceinline__ void conv_epilogue_vec(const ConvParams& p, const f32x16 (&acc)[TM][TN], const int* row_off, float* stage,
+                                                  int wave_row0, int n_wave0) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int LDW = TN * 32;              // floats per staged row
+  constexpr int LPR = TN * 8;               // lanes per row (one float4 each)
+  constexpr int RPI = 64 / LPR;             // rows per iteration
+  constexpr int NIT = TM * 32 / RPI;        // iterations
+  const int lane = threadIdx.x & 63;
+  {
+    float* st = stage + ((lane >> 5) * 4) * LDW + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[(i * 32 + (r & 3) + 8 * (r >> 2)) * LDW + j * 32] = acc[i][j][r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int base = __builtin_amdgcn_readfirstlane(row_off[0]);
+  const int lr = lane / LPR, lc = (lane % LPR) * 4;
+  const int n = n_wave0 + lc;
+  const bool n_ok = n < p.Cout;
+  unsigned voff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int o = row_off[wave_row0 + it * RPI + lr];
+    voff[it] = (o >= 0 && n_ok) ? (unsigned)(o - base + n) * 4u : EPI_WINDOW;
+  }
+  u32x4 res[NIT];
+  if (RES) {
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual + base), 0, (int)EPI_WINDOW, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) res[it] = __builtin_amdgcn_raw_buffer_load_b128(r_res, voff[it], 0, 0);
+  }
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && n_ok) bias = *reinterpret_cast<const float4*>(p.bias + n);
+  if (ACT && n_ok) {
+    sc = *reinterpret_cast<const float4*>(p.act_scale + n);
+    sh = *reinterpret_cast<const float4*>(p.act_shift + n);
+  }
+  const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y ? p.y + base : nullptr), 0, p.y ? (int)EPI_WINDOW : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_act =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? p.y_act + base : nullptr), 0, ACT ? (int)EPI_WINDOW : 0, 0x00020000);
+  const float* rd = stage + lr * LDW + lc;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    float4 v = *reinterpret_cast<const float4*>(rd + it * RPI * LDW);
+    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+    if (RES) {
+      v.x += __uint_as_float(res[it].x); v.y += __uint_as_float(res[it].y);
+      v.z += __uint_as_float(res[it].z); v.w += __uint_as_float(res[it].w);
+    }
+    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    u32x4 o;
+    o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(o, r_y, voff[it], 0, 0);
+    if (ACT) {
+      u32x4 a;
+      a.x = __float_as_uint(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f)); a.y = __float_as_uint(fmaxf(fmaf(v.y, sc.y, sh.y), 0.f));
+      a.z = __float_as_uint(fmaxf(fmaf(v.z, sc.z, sh.z), 0.f)); a.w = __float_as_uint(fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+      __builtin_amdgcn_raw_buffer_store_b128(a, r_act, voff[it], 0, 0);
+    }
+  }
+}
+
 // waves_per_eu(2,2): LDS already limits residency to 2 workgroups per CU (= 2 waves per SIMD); telling the compiler so lets it
 // keep the prefetch registers live across the MFMA block instead of spilling them to scratch to chase a higher occupancy.
 // VARIANT: 1 = the LDS store of the next chunk sits under the LAST MFMA group, | 256 = under the 3rd of 4; | 4096 = the two-chunks-ahead
@@ -173,6 +248,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wn = wave % (BN / WN);
 
   constexpr bool PERSIST = (VARIANT & 16384) != 0;
+  constexpr bool VEC_EPI = (VARIANT & 65536) != 0;   // LDS-transposed epilogue with 16-byte stores (conv_epilogue_vec)
+  static_assert(4 * WM * WN <= NBUF * (BM + BN) * LDT, "the epilogue stages the accumulators in the A/B buffers");
   static_assert(!PERSIST || !SPLITK, "persistent workgroups are a single-pass launch mode");
   for (int tile = blockIdx.x; PERSIST ? tile < p.k_split : true; tile += gridDim.x) {   // (not PERSIST: exactly one trip, the loop folds away)
   if constexpr (PERSIST) {
@@ -536,6 +613,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     return;
   }
   const int emode = (p.residual ? 1 : 0) | (p.relu ? 2 : 0) | (p.y_act ? 4 : 0);
+  if (VEC_EPI && (p.Cout & 3) == 0) {   // 16-byte path (every backbone layer); Cout % 4 != 0 (detector predictor heads) takes the dword path
+    float* stage = smem + wave * (WM * WN);   // the wave's slice of the idle A/B staging buffers (the K loop ended with a barrier)
+    const int vr0 = wm * WM, vn0 = n0 + wn * WN;
+    switch (emode) {
+      case 0: conv_epilogue_vec<TM, TN, false, false, false>(p, acc, row_off, stage, vr0, vn0); break;
+      case 1: conv_epilogue_vec<TM, TN, true, false, false>(p, acc, row_off, stage, vr0, vn0); break;
+      case 2: conv_epilogue_vec<TM, TN, false, true, false>(p, acc, row_off, stage, vr0, vn0); break;
+      case 3: conv_epilogue_vec<TM, TN, true, true, false>(p, acc, row_off, stage, vr0, vn0); break;
+      case 4: conv_epilogue_vec<TM, TN, false, false, true>(p, acc, row_off, stage, vr0, vn0); break;
+      case 5: conv_epilogue_vec<TM, TN, true, false, true>(p, acc, row_off, stage, vr0, vn0); break;
+      case 6: conv_epilogue_vec<TM, TN, false, true, true>(p, acc, row_off, stage, vr0, vn0); break;
+      default: conv_epilogue_vec<TM, TN, true, true, true>(p, acc, row_off, stage, vr0, vn0); break;
+    }
+  } else
   switch (emode) {
     case 0: conv_epilogue<TM, TN, false, false, false>(p, acc, row_off, erow0, en0); break;
     case 1: conv_epilogue<TM, TN, true, false, false>(p, acc, row_off, erow0, en0); break;
@@ -850,8 +941,11 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 8193, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193, true>(p, s, alg_k);
     return small ? launch_splitk<128, 64, 64, 32, 8193>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193>(p, s, alg_k);
   }
+  const bool vec = (variant & 65536) != 0;   // LDS-transposed 16-byte epilogue (A/B against the dword epilogue)
   if (plan.mode == 2) {  // whole rounds single-pass, the tiles of the half-empty last round split along K
-    int rc2 = small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 8449>(p, s, alg_k, plan.n_main);
+    int rc2;
+    if (vec) rc2 = small ? launch<128, 64, 64, 32, 73985>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 73985>(p, s, alg_k, plan.n_main);
+    else rc2 = small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 8449>(p, s, alg_k, plan.n_main);
     if (rc2) return rc2;
     p.chunks_per_split = plan.chunks_per_split;
     p.k_split = plan.k_split;
@@ -860,17 +954,15 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     p.m_part_begin = plan.m_begin;
     return small ? launch_splitk<128, 64, 64, 32, 8193>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193>(p, s, alg_k);
   }
-  if (p.run % BK != 0)  // ragged K (stems): per-lane K bookkeeping
+  if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
+    if (vec) return small ? launch<128, 64, 64, 32, 73985, true>(p, s, alg_k) : launch<128, 128, 64, 64, 73985, true>(p, s, alg_k);
     return small ? launch<128, 64, 64, 32, 8449, true>(p, s, alg_k) : launch<128, 128, 64, 64, 8449, true>(p, s, alg_k);
-  switch (variant) {  // every variant computes the same result; 8449 is the measured best, the others are kept for A/B timing
+  }
+  switch (variant) {  // every variant computes the same result; the others are kept for A/B timing
     case 257: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);  // the default schedule with global_load (64-bit lane addresses)
-    case 12289: return small ? launch<128, 64, 64, 32, 12289>(p, s, alg_k) : launch<128, 128, 64, 64, 12289>(p, s, alg_k);  // 4097 with buffer loads
-    case 4097: return small ? launch<128, 64, 64, 32, 4097>(p, s, alg_k) : launch<128, 128, 64, 64, 4097>(p, s, alg_k);  // two-chunks-ahead pipeline, barrier before the last group
     case 24833: return small ? launch<128, 64, 64, 32, 24833>(p, s, alg_k) : launch<128, 128, 64, 64, 24833>(p, s, alg_k);  // 8449 with persistent workgroups
-#ifdef MP_CONV_EXPERIMENTS   // `make variant NAME=exp DEFS=-DMP_CONV_EXPERIMENTS`: never in the product library
-    case 41217: return small ? launch<128, 64, 64, 32, 41217>(p, s, alg_k) : launch<128, 128, 64, 64, 41217>(p, s, alg_k);  // 8449 + s_setprio around the MFMA groups
-    case 57601: return small ? launch<128, 64, 64, 32, 57601>(p, s, alg_k) : launch<128, 128, 64, 64, 57601>(p, s, alg_k);  // persistent + s_setprio
-#endif
+    case 73985: return small ? launch<128, 64, 64, 32, 73985>(p, s, alg_k) : launch<128, 128, 64, 64, 73985>(p, s, alg_k);  // 8449 + 16-byte epilogue
+    case 90369: return small ? launch<128, 64, 64, 32, 90369>(p, s, alg_k) : launch<128, 128, 64, 64, 90369>(p, s, alg_k);  // persistent + 16-byte epilogue
     default: return small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k) : launch<128, 128, 64, 64, 8449>(p, s, alg_k);
   }
 }
