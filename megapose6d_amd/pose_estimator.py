@@ -333,14 +333,20 @@ class PoseEstimator(torch.nn.Module):
                 render_time += o.timing_dict["render"]
                 event_sets.append(o.timing_dict.get("events"))
         self._join(streams, produced)
+        # ONE all-gather for the whole stage: the 58 floats of every iteration side by side, [rows, n_iterations * 58]
+        W = 58
+        blocks = []
+        for n in range(1, n_iterations + 1):
+            a = acc[n]
+            if rows_h.size:
+                blocks += [torch.cat(a["poses"]).flatten(1), torch.cat(a["poses_input"]).flatten(1), torch.cat(a["K_crop"]).flatten(1),
+                           torch.cat(a["boxes_rend"]), torch.cat(a["boxes_crop"]), torch.cat(a["pose_out"])]
+        packed_all = torch.cat(blocks, dim=1) if rows_h.size else torch.zeros(0, W * n_iterations, device=device)
+        packed_all = self._gather(packed_all, R)
         preds = dict()
         pose_outputs = dict()
         for n in range(1, n_iterations + 1):
-            a = acc[n]
-            packed = torch.cat([torch.cat(a["poses"]).flatten(1), torch.cat(a["poses_input"]).flatten(1), torch.cat(a["K_crop"]).flatten(1),
-                                torch.cat(a["boxes_rend"]), torch.cat(a["boxes_crop"]), torch.cat(a["pose_out"])],
-                               dim=1) if rows_h.size else torch.zeros(0, 58, device=device)
-            packed = self._gather(packed, R)
+            packed = packed_all[:, (n - 1) * W:n * W]
             preds[f"iteration={n}"] = PandasTensorCollection(
                 df, poses=packed[:, 0:16].reshape(R, 4, 4).contiguous(), poses_input=packed[:, 16:32].reshape(R, 4, 4).contiguous(),
                 K_crop=packed[:, 32:41].reshape(R, 3, 3).contiguous(), K=K_all, boxes_rend=packed[:, 41:45].contiguous(),

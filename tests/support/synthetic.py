@@ -211,7 +211,8 @@ def _linear(sd, g, prefix, out_f, in_f, scale=1.0):
 # tolerance (1e-4) is asserted ABSOLUTELY everywhere.
 VANILLA_BN2_GAIN = 0.4     # gain on the last BN of every vanilla BasicBlock
 WIDE_CONV2_GAIN = 0.35     # gain on the second conv of every pre-activation block
-LOGIT_HEAD_SCALE = 4.0     # spreads the coarse / score logits of neighbouring hypotheses (~1e-3 apart on a 576 grid) while |logit| stays O(1)
+LOGIT_HEAD_SCALE = 2.0     # spreads the coarse / score logits of neighbouring hypotheses while |logit| stays O(1); a flipped silhouette sample
+                           # (crop cameras agree to 1 ulp only) then moves a logit by <~5e-5
 POSE_HEAD_SCALE = 0.05     # default pose-head weight scale: one refiner iteration moves a pose by ~1e-2 (rotation, rad; depth, rel.)
 
 

@@ -208,9 +208,13 @@ def _dist_worker(rank, world, port, q, backend="gloo"):
     torch.cuda.set_device(local)
     # gloo: both ranks share the single test GPU (RCCL needs one device per rank); nccl: one GPU per rank, RCCL all-gathers
     dist.init_process_group(backend, rank=rank, world_size=world)
+    from megapose6d_amd import distributed as mpd
+
     est, obs, det, _ = make_scene(n_objects=2, seed=7, SO3_grid_size=72, distributed=True)
+    mpd.stats.reset()
     final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=3)
-    q.put((rank, final.poses.cpu().numpy(), extra["coarse"]["data"]["logits"].cpu().numpy(), final.infos["hypothesis_id"].tolist()))
+    q.put((rank, final.poses.cpu().numpy(), extra["coarse"]["data"]["logits"].cpu().numpy(), final.infos["hypothesis_id"].tolist(),
+           mpd.stats.calls))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -240,7 +244,8 @@ def test_row_sharded_pipeline_two_ranks_matches_single_rank(backend):
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
-    for rank, pose, logits, hyp in res:
+    for rank, pose, logits, hyp, n_gathers in res:
+        assert n_gathers == 3, n_gathers  # coarse, refiner (all iterations packed), scoring -- one all-gather each
         assert np.abs(logits - ref_logits).max() < 5e-5 * max(1.0, np.abs(ref_logits).max())
         assert hyp == f1.infos["hypothesis_id"].tolist()
         assert np.abs(pose - ref_pose).max() < 5e-5
