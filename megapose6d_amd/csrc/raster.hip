@@ -360,7 +360,7 @@ __device__ __forceinline__ ViewHdr load_view_hdr(const int* __restrict__ ws, con
 
 // F16 (MP_RASTER_F16, the "fp16 renders" mode of BASELINE.json configs[4]): `out` holds IEEE binary16 elements -- same element
 // strides, every written channel (renders and the fused crop) is rounded to nearest-even on its way out; nothing else changes.
-template <int NS, bool F16 = false>
+template <int NS, bool F16 = false, bool FULL = true>
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(MP_RASTER_WAVES, MP_RASTER_WAVES))) void raster_tiles(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     wave_lds_fence();
     PROF(4)
-    const TexDev* tex = m.uvs ? &texs[mesh_id] : nullptr;
+    const TexDev* tex = (FULL && m.uvs) ? &texs[mesh_id] : nullptr;
     for (int k0 = 0; k0 < n_tasks; k0 += 64) {
       const int k = k0 + lane;
       if (k < n_tasks) {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         }
         if (pf.flags & 2) rc::piece_from_index<true>(m, T, Kv, id, pf);   // clipped pieces (their bary rows are not in the record), large-list pieces
         float c255[3], n255[3];
-        rc::shade(m, tex, lights, T, gl_eye, do_norm, pf, tile_x0 + (tl & 7), tile_y0 + (tl >> 3), c255, n255);
+        rc::shade<FULL>(m, tex, lights, T, gl_eye, do_norm, pf, tile_x0 + (tl & 7), tile_y0 + (tl >> 3), c255, n255);
         uint2 q;
         q.x = (unsigned)rc::q255(c255[0]) | ((unsigned)rc::q255(c255[1]) << 8) | ((unsigned)rc::q255(c255[2]) << 16);
         q.y = (unsigned)rc::q255(n255[0]) | ((unsigned)rc::q255(n255[1]) << 8) | ((unsigned)rc::q255(n255[2]) << 16);
@@ -610,6 +610,7 @@ using namespace mp;
 struct mp_mesh_db {
   int n;
   int max_verts, max_faces;
+  bool any_texture;   // some mesh has uvs + a texture: raster_tiles needs its FULL instance
   MeshDev* d_meshes;
   TexDev* d_texs;
   std::vector<MeshDev> h_meshes;
@@ -622,6 +623,7 @@ extern "C" int mp_mesh_db_create(const mp_mesh_desc* hm, int n, mp_mesh_db** out
   mp_mesh_db* db = new mp_mesh_db();
   db->n = n;
   db->max_verts = db->max_faces = 0;
+  db->any_texture = false;
   db->d_meshes = nullptr;
   db->d_texs = nullptr;
   for (int i = 0; i < n; ++i) {
@@ -698,6 +700,7 @@ extern "C" int mp_mesh_db_set_texture(mp_mesh_db* db, int mesh_id, const float* 
   MP_CHECK_HIP(hipMemcpy(dtex, h_texels, total * sizeof(uint32_t), hipMemcpyHostToDevice));
   db->allocs.push_back(duv); db->allocs.push_back(dtex);
   m.uvs = duv;
+  db->any_texture = true;
   tx.texels = dtex; tx.tex_w = tex_w; tx.tex_h = tex_h; tx.tex_levels = n_levels;
   MP_CHECK_HIP(hipMemcpy(db->d_texs + mesh_id, &tx, sizeof(TexDev), hipMemcpyHostToDevice));
   MP_CHECK_HIP(hipMemcpy(db->d_meshes + mesh_id, &m, sizeof(MeshDev), hipMemcpyHostToDevice));
@@ -802,23 +805,24 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   ProfScope prof(f16 ? "raster_tiles/f16" : "raster_tiles", 0.0,
                  (double)n_views * ((double)n_ch * out_es * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) +
                      (crop.images ? (double)n_items * crop.C * (out_es + 4.0) * h * w : 0.0), s);   // crop: C channels written + <= the same-sized fp32 source window read
-  if (f16) {
-    if (ns == 4)
-      hipLaunchKernelGGL((raster_tiles<4, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO,
-                         d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
-                         (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
-    else
-      hipLaunchKernelGGL((raster_tiles<1, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO,
-                         d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
-                         (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
-  } else if (ns == 4)
-    hipLaunchKernelGGL(raster_tiles<4>, dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, d_K,
-                       (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
-                       (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
-  else
-    hipLaunchKernelGGL(raster_tiles<1>, dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs, d_mesh_ids, d_TCO, d_K,
-                       (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items, (long long)stride_view,
-                       (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop);
+  // FULL = texture + point-light code compiled in; the pose networks' renders (vertex colours, ambient light) take the lean instance
+  const bool full = db->any_texture || L.n_point > 0;
+#define MP_LAUNCH_TILES(NSV, F16V, FULLV)                                                                                              \
+  hipLaunchKernelGGL((raster_tiles<NSV, F16V, FULLV>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,    \
+                     d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,  \
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop)
+  const int sel = (ns == 4 ? 4 : 0) | (f16 ? 2 : 0) | (full ? 1 : 0);
+  switch (sel) {
+    case 0: MP_LAUNCH_TILES(1, false, false); break;
+    case 1: MP_LAUNCH_TILES(1, false, true); break;
+    case 2: MP_LAUNCH_TILES(1, true, false); break;
+    case 3: MP_LAUNCH_TILES(1, true, true); break;
+    case 4: MP_LAUNCH_TILES(4, false, false); break;
+    case 5: MP_LAUNCH_TILES(4, false, true); break;
+    case 6: MP_LAUNCH_TILES(4, true, false); break;
+    default: MP_LAUNCH_TILES(4, true, true); break;
+  }
+#undef MP_LAUNCH_TILES
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

@@ -530,7 +530,8 @@ MP_HD bool blk_touched(const BlkRec& r, int rxmin, int rxmax, int rymin, int rym
 template <class Emit>
 MP_HD void cover_sample_rel(const BlkRec& r, uint32_t rel, Emit&& emit) {
   const int E0 = dot2_i16(r.dxy[0], rel, r.e0[0]), E1 = dot2_i16(r.dxy[1], rel, r.e0[1]), E2 = dot2_i16(r.dxy[2], rel, r.e0[2]);
-  const bool inside = E0 >= (int)(r.thr_bits & 1u) && E1 >= (int)((r.thr_bits >> 1) & 1u) && E2 >= (int)((r.thr_bits >> 2) & 1u);
+  // (bitwise &: all three compares are issued back to back; && would make the GPU branch after every edge)
+  const bool inside = (E0 >= (int)(r.thr_bits & 1u)) & (E1 >= (int)((r.thr_bits >> 1) & 1u)) & (E2 >= (int)((r.thr_bits >> 2) & 1u));
   if (inside) {
     const float b0 = (float)E0 * r.inv_area, b1 = (float)E1 * r.inv_area, b2 = (float)E2 * r.inv_area;
     const float wsum = fmaf(b2, r.iz[2], fmaf(b1, r.iz[1], b0 * r.iz[0]));
@@ -612,6 +613,9 @@ MP_HD float pv_attr(const Piece& p, int k, const float* attr, int i0, int i1, in
 
 // Shade piece p at the centre of pixel (px, py): col255 = RGB on the 0..255 scale before clamping/rounding, nrm255 = eye-normal
 // LUT values on the 0..255 scale.  (Barycentrics are extrapolated when the centre lies outside the piece.)
+// FULL = false: the instance for vertex-coloured meshes under ambient light only (what the pose networks render): the texture and
+// point-light code is not compiled in (registers, code size); the caller guarantees tex == NULL / no uvs and L.n_point == 0.
+template <bool FULL = true>
 MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const float* T, bool gl_eye, bool want_normals, const Piece& p,
                  int px, int py, float col255[3], float nrm255[3]) {
   // barycentrics at the pixel centre and the edge slopes (for the texture derivatives): the 32-bit form for a piece that is small
@@ -646,7 +650,7 @@ MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const flo
     col[k] = fmaf(w2, pv_attr(p, 2, m.colors, i0, i1, i2, k), fmaf(w1, pv_attr(p, 1, m.colors, i0, i1, i2, k), w0 * pv_attr(p, 0, m.colors, i0, i1, i2, k))) * z;
     on[k] = fmaf(w2, pv_attr(p, 2, m.normals, i0, i1, i2, k), fmaf(w1, pv_attr(p, 1, m.normals, i0, i1, i2, k), w0 * pv_attr(p, 0, m.normals, i0, i1, i2, k))) * z;
   }
-  if (m.uvs && tex && tex->texels) {
+  if (FULL && m.uvs && tex && tex->texels) {
     const float* uv = m.uvs + 6 * (size_t)p.tri;
     float pu[3], pv[3];
 #pragma unroll
@@ -684,7 +688,7 @@ MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const flo
     for (int k = 0; k < 3; ++k) col[k] *= tc[k] / 255.0f;
   }
   float lr = L.ambient[0], lg = L.ambient[1], lb = L.ambient[2];
-  if (L.n_point > 0) {
+  if (FULL && L.n_point > 0) {
     float op[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)

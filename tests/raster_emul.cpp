@@ -149,17 +149,24 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
           x0 = imax(x0, tile_x0); y0 = imax(y0, tile_y0); x1 = imin(x1, tile_x0 + TILE - 1); y1 = imin(y1, tile_y0 + TILE - 1);
           if (x0 > x1 || y0 > y1) continue;
           const bool small = piece_is_small(p, tile_x0, tile_y0);
-          if (binned) {   // scatter form (every binned record)
+          if (binned) {   // block-visit form (every binned record): the arithmetic and the lane layout of the kernel
             Edges32 e;
             piece_edges32(p, e);
-            for (int py = y0; py <= y1; ++py)
-              for (int px = x0; px <= x1; ++px) {
-                const int local = ((py - tile_y0) << 3) | (px - tile_x0);
-                cover_pixel32<NS>(p, e, px, py, [&](int s, float wsum) {
-                  const unsigned long long key = depth_key(wsum, p.id, pslot);
-                  if (key > zb[local * NS + s]) zb[local * NS + s] = key;
+            const BlkRec br = make_blk_rec(p, e, tile_x0, tile_y0, pslot);
+            const int ox = tile_x0 * SUBPIX, oy = tile_y0 * SUBPIX;
+            const int rxmin = imin(p.X[0], imin(p.X[1], p.X[2])) - ox, rxmax = imax(p.X[0], imax(p.X[1], p.X[2])) - ox;
+            const int rymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])) - oy, rymax = imax(p.Y[0], imax(p.Y[1], p.Y[2])) - oy;
+            for (int k = 0; k < blk_count(NS); ++k) {
+              if (!blk_touched(br, rxmin, rxmax, rymin, rymax, NS, k)) continue;
+              for (int l = 0; l < 64; ++l) {
+                const int pix = blk_lane_pixel(NS, k, l), s = blk_lane_sample(NS, l);
+                if (tile_x0 + (pix & 7) >= w || tile_y0 + (pix >> 3) >= h) continue;
+                cover_sample_rel(br, blk_lane_rel(NS, k, l), [&](float wsum) {
+                  const unsigned long long key = depth_key_lo(wsum, br.key_lo);
+                  if (key > zb[pix * NS + s]) zb[pix * NS + s] = key;
                 });
               }
+            }
           } else {                                                             // sweep form
             const int Xmin = imin(p.X[0], imin(p.X[1], p.X[2])), Xmax = imax(p.X[0], imax(p.X[1], p.X[2]));
             const int Ymin = imin(p.Y[0], imin(p.Y[1], p.Y[2])), Ymax = imax(p.Y[0], imax(p.Y[1], p.Y[2]));
