@@ -221,6 +221,19 @@ int mp_conv2d_nhwc_split(const mp_conv_desc* desc, int n_products, mp_stream str
 /* the name of the kernel instantiation mp_conv2d_nhwc would launch (for profiling)        */
 const char* mp_conv2d_kernel_name(const mp_conv_desc* desc);
 
+/* Fused Winograd F(2x2, 3x3) form of the 3x3 / stride-1 / pad-1 convolutions of the residual stages (same call sites as
+ * mp_conv2d_nhwc: models/torchvision_resnet.py:74-120 BasicBlock conv1 / conv2, models/wide_resnet.py:29-56) -- 16 instead of 36
+ * multiplications per (2x2 output tile, cin, cout); fp32 MFMA, fp32 transforms; same fused epilogue (bias, residual, ReLU, second
+ * pre-activated output).  d_u = the blob of mp_conv_wino_pack_weights uploaded to the device; `desc->d_w` and the split-K fields
+ * are ignored.  Needs C % 16 == 0, Cout % 64 == 0, in_border >= 1.  When H or W is odd the kernel reads (and discards) up to one
+ * padded row + one pixel past the end of the input tensor: the caller provides that much readable slack (the backbone workspace
+ * does).  mp_conv_wino_eligible: 1 if a layer qualifies AND its grid gives each of n_cu compute units a workgroup (small grids stay
+ * on mp_conv2d_nhwc's split-K path).  See csrc/conv_wino.hip. */
+size_t mp_conv_wino_packed_floats(int Cin_p, int Cout);
+int mp_conv_wino_pack_weights(const float* h_w_oi33, int Cout, int Cin, int Cin_p, const float* h_scale /*[Cout] or NULL*/, float* h_packed);
+int mp_conv_wino_eligible(const mp_conv_desc* desc, int n_cu);
+int mp_conv3x3_wino_nhwc(const mp_conv_desc* desc, const float* d_u, mp_stream stream);
+
 /* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
 int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,
                     int out_border, float* d_y_act, const float* d_act_scale, const float* d_act_shift,

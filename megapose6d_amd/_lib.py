@@ -112,6 +112,10 @@ SIGNATURES = {
     "mp_conv_pack_weights_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv2d_nhwc_split": (_i, [C.POINTER(ConvDesc), _i, _vp]),
     "mp_conv2d_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
+    "mp_conv_wino_packed_floats": (_sz, [_i, _i]),
+    "mp_conv_wino_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mp_conv_wino_eligible": (_i, [C.POINTER(ConvDesc), _i]),
+    "mp_conv3x3_wino_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _vp]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),

@@ -224,7 +224,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ unsigned long long g_raster_prof[16];
 #define PROF_T0                                              \
   unsigned long long prof_t = __builtin_readcyclecounter(); \
-  unsigned long long prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   /* 9.. = counters: visits, records, tile-views, batches */
 #define PROF(slot)                                                  \
   {                                                                 \
     const unsigned long long prof_n = __builtin_readcyclecounter(); \
@@ -233,12 +233,14 @@ __device__ unsigned long long g_raster_prof[16];
   }
 #define PROF_FLUSH                                                                  \
   if (lane == 0 && (blockIdx.x & 31) == 0) {                                        \
-    for (int k = 0; k < 9; ++k) atomicAdd(&g_raster_prof[k], prof_acc[k]);          \
+    for (int k = 0; k < 13; ++k) atomicAdd(&g_raster_prof[k], prof_acc[k]);         \
   }
+#define PROF_COUNT(slot, n) prof_acc[slot] += (unsigned long long)(n);
 #else
 #define PROF_T0
 #define PROF(slot)
 #define PROF_FLUSH
+#define PROF_COUNT(slot, n)
 #endif
 
 // ---- coverage form 1 (every binned record): block visits (arithmetic and lane layout: raster_core.h "block-visit coverage form").
@@ -250,7 +252,7 @@ __device__ unsigned long long g_raster_prof[16];
 template <int NS>
 __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, int tile_x0, int tile_y0, int lane, int slot,
                                                    const uint32_t (&rel)[NS == 1 ? 1 : 4], unsigned ok_mask, uint4* blk,
-                                                   unsigned long long (&best)[NS == 1 ? 1 : 4]) {
+                                                   unsigned long long (&best)[NS == 1 ? 1 : 4], unsigned long long* n_visits = nullptr) {
   constexpr int NB = NS == 1 ? 1 : 4;
   rc::BlkRec mine;
   memset(&mine, 0, sizeof(mine));
@@ -271,6 +273,9 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     unsigned long long m = __ballot(active && rc::blk_touched(mine, rxmin, rxmax, rymin, rymax, NS, k));
+#ifdef MP_RASTER_PROF
+    if (n_visits) *n_visits += __popcll(m);
+#endif
     const bool ok = (ok_mask >> k) & 1u;
     const uint32_t rel_k = rel[k];
     unsigned long long bk = best[k];
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       continue;
     }
     PROF(0)
+    PROF_COUNT(11, 1)
     // ---- coverage + depth, binned records: block visits, the depth keys of the lane's samples in registers ---------------------
     unsigned long long best[NB];
 #pragma unroll
@@ -464,7 +470,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
           x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
         }
         const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
+#ifdef MP_RASTER_PROF
+        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best, &prof_acc[9]);
+        PROF_COUNT(10, __popcll(__ballot(hit)))
+        PROF_COUNT(12, 1)
+#else
         if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best);
+#endif
         PROF(2)
       }
     }

@@ -17,7 +17,7 @@ lib.mp_raster_prof_read.restype = C.c_int
 ds = syn.make_object_dataset("/tmp/mp_rp", 1, 0)
 db = eng.MeshDB([mesh_io.load_rigid_object(ds[0])])
 n = 2304
-names = ["list fetch", "piece set-up", "scatter", "sweep", "z read + tasks", "shading", "resolve+stage", "crop", "store"]
+names = ["init/empty", "list fetch", "block visits", "sweep (large)", "z read + tasks", "shading", "resolve+stage", "crop", "store"]
 for label, f, zr in (("zoomed (object fills the view)", 1500.0, (0.4, 0.6)), ("pipeline-like (crop lambda 1.4)", 1000.0, (0.45, 0.7))):
     rng = np.random.RandomState(0)
     T = torch.from_numpy(np.stack([syn.random_pose(rng, z_range=zr, xy_frac=0.02) for _ in range(n)])).cuda()
@@ -36,6 +36,9 @@ for label, f, zr in (("zoomed (object fills the view)", 1500.0, (0.4, 0.6)), ("p
             torch.cuda.synchronize()
         lib.mp_raster_prof_read(buf, 0)
         tot = sum(buf[i] for i in range(9))
+        if buf[11]:
+            print(f"    per tile-view with geometry: {buf[10] / buf[11]:.1f} records, {buf[9] / buf[11]:.1f} visits, {buf[12] / buf[11]:.2f} batches "
+                  f"(sampled waves: {buf[11]} tile-views)")
         print(f"{label}, flags={flags}: {e0.elapsed_time(e1):.2f} ms; wave-cycles by phase: " +
               ", ".join(f"{names[i]} {100.0 * buf[i] / tot:.1f}%" for i in range(9)) + f"  (total {tot / 1e9:.2f} G wave-cycles)", flush=True)
     cov = (out[..., 3:6].sum(-1) > 0).float().mean().item()
