@@ -365,6 +365,7 @@ def main():
     fence()
     mpd.stats.reset()
     eng.conv_clock(reset=True)
+    eng.conv_wino_stats(reset=True)
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -372,7 +373,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
-    conv_mhz = eng.conv_clock(reset=True)   # shader clock INSIDE the conv kernels of the timed steps
+    wino_direct, wino_exec = eng.conv_wino_stats(reset=True)   # algorithmic vs executed FLOPs of the Winograd launches of the timed steps
+    conv_mhz = eng.conv_clock(reset=True)   # shader clock INSIDE the (direct) conv kernels of the timed steps
     gather_ms = mpd.stats.ms() if world > 1 else 0.0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -386,10 +388,20 @@ def main():
 
     rc = 0
     if rank == 0:
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_nhwc_f32")}
+        conv = {k: v for k, v in prof.items() if k.startswith("conv_nhwc_f32") or k.startswith("conv3x3_wino")}
         dom_name = max(conv, key=lambda k: conv[k]["ms"])
         dom = conv[dom_name]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        # The Winograd kernel EXECUTES 16/36 of the algorithmic (direct-convolution) FLOPs its profiler row carries (SURVEY.md 8d counts
+        # 2 * MACs of the convolution), so its algorithmic rate may exceed the matrix peak; its MFMA utilisation is the executed rate.
+        wino = None
+        if wino_direct > 0:
+            wk = next(v for k, v in conv.items() if k.startswith("conv3x3_wino"))
+            wino = {"kernel": next(k for k in conv if k.startswith("conv3x3_wino")), "algorithm": "Winograd F(2x2,3x3), fp32 MFMA",
+                    "ms_per_step": wk["ms"] / a.steps, "algorithmic_tflops": wk["flops"] / (wk["ms"] * 1e-3) / 1e12,
+                    "executed_tflops": wk["flops"] * (wino_exec / wino_direct) / (wk["ms"] * 1e-3) / 1e12,
+                    "executed_over_algorithmic_flops": wino_exec / wino_direct}
+            wino["mfma_utilisation"] = wino["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS
         all_conv_tf = sum(v["flops"] for v in conv.values()) / (sum(v["ms"] for v in conv.values()) * 1e-3) / 1e12
         conv_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in conv.items() if v["ms"] > 0}
         kernel_ms = {k: round(v["ms"] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
@@ -421,7 +433,10 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": dom["bytes"] / dom["launches"], "launches": dom["launches"],
                          "avg_launch_ms": dom["ms"] / dom["launches"], "avg_launch_gflop": dom["flops"] / dom["launches"] / 1e9,
-                         "all_conv_kernels_tflops": all_conv_tf, "per_kernel_tflops": conv_tf,
+                         "all_conv_kernels_tflops": all_conv_tf, "per_kernel_tflops": conv_tf, "winograd": wino,
+                         "note": ("`achieved` = algorithmic FLOPs (2 x MACs of the direct convolution, SURVEY.md 8d) / HIP-event time of the dominant "
+                                  "kernel, as the contract defines it.  Where that kernel is the Winograd one, `frac` can exceed 1: the kernel executes "
+                                  "16/36 of those FLOPs -- `winograd.mfma_utilisation` is its executed rate / peak (<= 1)") if wino else None,
                          "shader_clock_mhz": conv_mhz,
                          "frac_at_measured_clock": achieved / (PEAK_FP32_MFMA_TFLOPS * conv_mhz / 2400.0) if conv_mhz > 0 else None,
                          "probe_clock_mhz": clk["shader_mhz"], "mfma_probe_tflops": clk["mfma_tflops"],

@@ -233,6 +233,8 @@ size_t mp_conv_wino_packed_floats(int Cin_p, int Cout);
 int mp_conv_wino_pack_weights(const float* h_w_oi33, int Cout, int Cin, int Cin_p, const float* h_scale /*[Cout] or NULL*/, float* h_packed);
 int mp_conv_wino_eligible(const mp_conv_desc* desc, int n_cu);
 int mp_conv3x3_wino_nhwc(const mp_conv_desc* desc, const float* d_u, mp_stream stream);
+/* totals over the Winograd launches since the last reset: algorithmic (direct-convolution) FLOPs and the FLOPs actually executed */
+int mp_conv_wino_stats(double* direct_flops, double* executed_flops, int reset);
 
 /* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
 int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mp_conv_wino_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mp_conv_wino_eligible": (_i, [C.POINTER(ConvDesc), _i]),
     "mp_conv3x3_wino_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _vp]),
+    "mp_conv_wino_stats": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),

@@ -7,6 +7,7 @@
 // into the preceding conv at load time (w' = w * g/sqrt(var+eps), b' = beta - mean * g/sqrt(var+eps)); the WideResNet
 // block-input BN (bn1) cannot fold and is emitted by the PRODUCER's epilogue as a second "activated" output.
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -18,6 +19,7 @@ namespace mp {
 struct ConvLayer {
   int Cin, Cin_p, Cout, K, stride, pad;
   float* d_w = nullptr;   // packed fp32 weights, or the bf16 split blob when the backbone runs in split mode
+  float* d_u = nullptr;   // Winograd-transformed weights (conv_wino.hip) of an eligible 3x3 / stride-1 layer, native fp32 mode only
   float* d_b = nullptr;  // folded BN shift (may be null)
 };
 
@@ -108,6 +110,13 @@ int make_conv(mp_backbone* bb, const StateMap& sm, const std::string& wkey, cons
     rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
     if (rc) return rc;
     rc = upload(bb, packed, &L->d_w);
+    // 3x3 / stride-1 layers of the residual stages also get their Winograd F(2x2, 3x3) form (MP_CONV_WINO=0 keeps the direct kernel)
+    static const bool wino_on = !(getenv("MP_CONV_WINO") && atoi(getenv("MP_CONV_WINO")) == 0);
+    if (!rc && wino_on && K == 3 && stride == 1 && pad == 1 && Cin_p % 16 == 0 && Cout % 64 == 0) {
+      std::vector<float> u(mp_conv_wino_packed_floats(Cin_p, Cout));
+      rc = mp_conv_wino_pack_weights(w, Cout, Cin, Cin_p, bnkey.empty() ? nullptr : scale.data(), u.data());
+      if (!rc) rc = upload(bb, u, &L->d_u);
+    }
   } else {
     std::vector<float> packed((mp_conv_packed_split_bytes(Cin_p, Cout, K, K) + 3) / 4);
     rc = mp_conv_pack_weights_split(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
@@ -145,11 +154,21 @@ int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, i
   if (y_act) { d.d_act_scale = act->d_scale; d.d_act_shift = act->d_shift; }
   d.d_splitk_ws = splitk_ws;
   d.splitk_ws_floats = splitk_ws ? (int64_t)SPLITK_WS_FLOATS : 0;
+  if (bb->precision == 0 && L.d_u && !x_f16) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    if (mp_conv_wino_eligible(&d, n_cu)) return mp_conv3x3_wino_nhwc(&d, L.d_u, s);   // the workspace buffers carry the read slack it needs
+  }
   return bb->precision == 0 ? mp_conv2d_nhwc(&d, s) : mp_conv2d_nhwc_split(&d, bb->precision, s);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline size_t buf_floats(int N, int H, int W, int C) { return (size_t)N * (H + 2) * (W + 2) * C + 64; }
+// (+ one padded row + one pixel of slack: the Winograd kernel reads -- and discards -- that much past an odd-sized tensor)
+inline size_t buf_floats(int N, int H, int W, int C) { return (size_t)N * (H + 2) * (W + 2) * C + (size_t)(W + 3) * C + 64; }
 
 struct Geometry {
   int h1, w1;       // stem output

@@ -56,6 +56,7 @@ struct WinoParams {
   int n_steps;          // C / 16
   int relu;
   int n_cblocks;        // Cout / 64
+  int out_bytes;        // size of the output tensor (range check of the epilogue's buffer accesses)
 };
 
 __device__ __forceinline__ float4 buf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -174,38 +175,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int fsw = ((lane & 31) >> 2) & 3;
   const float* vr = Vs + ((4 * wave) * WT + (lane & 31)) * WCK;
   const int fo0 = (((lane >> 5)) ^ fsw) * 4, fo1 = ((2 + (lane >> 5)) ^ fsw) * 4;   // float offsets of the two 8-channel halves
-#define WINO_MFMA_HALF(UU, FO)                                                                         \
-  _Pragma("unroll") for (int fi = 0; fi < 4; ++fi) {                                                   \
-    const float4 a0 = *reinterpret_cast<const float4*>(vb + fi * (WT * WCK) + (FO));                   \
-    const float4 a1 = *reinterpret_cast<const float4*>(vb + fi * (WT * WCK) + 32 * WCK + (FO));        \
-    const float4 b0 = UU[fi][0], b1 = UU[fi][1];                                                       \
-    WINO_STEP(x) WINO_STEP(y) WINO_STEP(z) WINO_STEP(w)                                                \
+#define WINO_STEP(AF, UU, Q)                                                                            \
+  acc[fi][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[0].Q, UU[fi][0].Q, acc[fi][0][0], 0, 0, 0);   \
+  acc[fi][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[0].Q, UU[fi][1].Q, acc[fi][0][1], 0, 0, 0);   \
+  acc[fi][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[1].Q, UU[fi][0].Q, acc[fi][1][0], 0, 0, 0);   \
+  acc[fi][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[1].Q, UU[fi][1].Q, acc[fi][1][1], 0, 0, 0);
+#define WINO_READ_FRAGS(AF, FI, FO)                                                                     \
+  AF[0] = *reinterpret_cast<const float4*>(vb + (FI) * (WT * WCK) + (FO));                              \
+  AF[1] = *reinterpret_cast<const float4*>(vb + (FI) * (WT * WCK) + 32 * WCK + (FO));
+#define WINO_SB __builtin_amdgcn_sched_barrier(0);
+// transform slice (a, col): one of the 16 frequency planes of the thread's patch -> one ds_write_b128.  Slice (a, 0) also forms the
+// row combination t[a][0..3] of the patch (B^T d); the column combination (. B) is 4 VALU per plane.
+#define WINO_SLICE(A, COL)                                                                              \
+  {                                                                                                     \
+    if ((COL) == 0) {                                                                                   \
+      _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                     \
+        trow[b] = (A) == 0 ? f4sub(patch[0][b], patch[2][b]) : (A) == 1 ? f4add(patch[1][b], patch[2][b])  \
+                : (A) == 2 ? f4sub(patch[2][b], patch[1][b]) : f4sub(patch[1][b], patch[3][b]);         \
+    }                                                                                                   \
+    const float4 v_ = (COL) == 0 ? f4sub(trow[0], trow[2]) : (COL) == 1 ? f4add(trow[1], trow[2])       \
+                    : (COL) == 2 ? f4sub(trow[2], trow[1]) : f4sub(trow[1], trow[3]);                   \
+    *reinterpret_cast<float4*>(vwn + ((A) * 4 + (COL)) * (WT * WCK)) = v_;                              \
   }
-#define WINO_STEP(Q)                                                                                   \
-  acc[fi][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.Q, b0.Q, acc[fi][0][0], 0, 0, 0);            \
-  acc[fi][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.Q, b1.Q, acc[fi][0][1], 0, 0, 0);            \
-  acc[fi][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.Q, b0.Q, acc[fi][1][0], 0, 0, 0);            \
-  acc[fi][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.Q, b1.Q, acc[fi][1][1], 0, 0, 0);
+  float4 A0[2], A1[2], trow[4];
   for (int st = 0; st < ns; ++st) {
     const int buf = st & 1;
     const float* vb = vr + buf * WV_STAGE;
-    // Straight-line step (no branches: the scheduler may spread the transform and the loads under the 128 MFMAs).  The last step
-    // harmlessly transforms its own patch again into the idle stage and re-loads its own weights / patch.
+    float* vwn = vw + (buf ^ 1) * WV_STAGE;
+    const int cs_patch = (st + 2 < ns ? st + 2 : ns - 1) * (WCK * 4);
+    const int us_next = (st + 1 < ns ? 2 * st + 2 : 2 * st) * U_CHUNK_BYTES;
+    // Hand-placed step (sched_barrier pins the order; in-order issue lets ~14 issue slots ride under every 64-cycle MFMA):
+    //   half 0 (channels 0-7, weights U0): after every 4 MFMAs one transform slice of the NEXT step's patch (8-20 VALU + 1 ds_write_b128)
+    //   half 1 (channels 8-15, weights U1): after every 4 MFMAs one patch request of the step after next (+ the next U0 fragments)
+    // Fragments are read one group ahead.  The last step harmlessly transforms / re-loads its own data into idle buffers.
     WINO_LOAD_U(U1, 2 * st + 1)
-    WINO_TRANSFORM(buf ^ 1)
-    WINO_LOAD_PATCH(st + 2 < ns ? st + 2 : ns - 1)
-    WINO_MFMA_HALF(U0, fo0)
-    WINO_LOAD_U(U0, st + 1 < ns ? 2 * st + 2 : 2 * st)
-    WINO_MFMA_HALF(U1, fo1)
+    WINO_READ_FRAGS(A0, 0, fo0)
+    WINO_SB
+#define WINO_GROUP_H0(FI, ACUR, ANEXT, NFI, NFO)                                                        \
+  {                                                                                                     \
+    constexpr int fi = FI;                                                                              \
+    WINO_READ_FRAGS(ANEXT, NFI, NFO)                                                                    \
+    WINO_STEP(ACUR, U0, x) WINO_SB WINO_SLICE(FI, 0) WINO_SB                                            \
+    WINO_STEP(ACUR, U0, y) WINO_SB WINO_SLICE(FI, 1) WINO_SB                                            \
+    WINO_STEP(ACUR, U0, z) WINO_SB WINO_SLICE(FI, 2) WINO_SB                                            \
+    WINO_STEP(ACUR, U0, w) WINO_SB WINO_SLICE(FI, 3) WINO_SB                                            \
+  }
+    WINO_GROUP_H0(0, A0, A1, 1, fo0)
+    WINO_GROUP_H0(1, A1, A0, 2, fo0)
+    WINO_GROUP_H0(2, A0, A1, 3, fo0)
+    WINO_GROUP_H0(3, A1, A0, 0, fo1)
+#define WINO_PLOAD(A, B) patch[A][B] = buf4(x_rsrc, x_voff, cs_patch + (A) * row_bytes + (B) * pix_bytes);
+#define WINO_ULOAD(FI, J) U0[FI][J] = buf4(u_rsrc, u_voff, us_next + ((FI) * 2 + (J)) * 1024);
+#define WINO_GROUP_H1(FI, ACUR, ANEXT, NFI, LAST)                                                       \
+  {                                                                                                     \
+    constexpr int fi = FI;                                                                              \
+    if (!(LAST)) { WINO_READ_FRAGS(ANEXT, NFI, fo1) }                                                   \
+    WINO_STEP(ACUR, U1, x) WINO_SB WINO_PLOAD(FI, 0) WINO_ULOAD(FI, 0) WINO_SB                          \
+    WINO_STEP(ACUR, U1, y) WINO_SB WINO_PLOAD(FI, 1) WINO_ULOAD(FI, 1) WINO_SB                          \
+    WINO_STEP(ACUR, U1, z) WINO_SB WINO_PLOAD(FI, 2) WINO_SB                                            \
+    WINO_STEP(ACUR, U1, w) WINO_SB WINO_PLOAD(FI, 3) WINO_SB                                            \
+  }
+    WINO_GROUP_H1(0, A0, A1, 1, false)
+    WINO_GROUP_H1(1, A1, A0, 2, false)
+    WINO_GROUP_H1(2, A0, A1, 3, false)
+    WINO_GROUP_H1(3, A1, A0, 0, true)
     __syncthreads();
   }
+#undef WINO_GROUP_H0
+#undef WINO_GROUP_H1
+#undef WINO_PLOAD
+#undef WINO_ULOAD
+#undef WINO_SLICE
+#undef WINO_READ_FRAGS
+#undef WINO_SB
 #undef WINO_STEP
-#undef WINO_MFMA_HALF
 #undef WINO_LOAD_PATCH
 #undef WINO_LOAD_U
 #undef WINO_TRANSFORM
 
   // ---- epilogue -----------------------------------------------------------------------------------------------------------------
+  // item = (tile, 4 channels): thread t owns channels (t & 15) * 4 of the tiles (t >> 4) + 16 * it, it = 0..3.  Straight-line code
+  // through buffer instructions: a missing tile / row / column gets a byte offset beyond num_records (load 0, store dropped).
+  // (0) the residual values (16 x 16 bytes per thread) are requested BEFORE the exchange, so their HBM latency hides behind it
+  const int n = cb * WCOUT + (tid & 15) * 4;
+  constexpr unsigned WOOB = 0xFFFFFFF0u;
+  unsigned voff[4][4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tl = it * 16 + (tid >> 4);
+    const int off = tile_tab[2 * tl], bits = tile_tab[2 * tl + 1];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const bool ok = off >= 0 && (!ii || (bits & 1)) && (!jj || (bits & 2));
+        voff[it][ii * 2 + jj] = ok ? (unsigned)(off + (ii * p.Wop + jj) * p.Cout + n) * 4u : WOOB;
+      }
+  }
+  const int out_bytes = p.out_bytes;
+  u32x4 res[4][4];
+  if (p.residual) {
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, out_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) res[it][k] = __builtin_amdgcn_raw_buffer_load_b128(r_res, voff[it][k], 0, 0);
+  }
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+  if (p.y_act) {
+    sc = *reinterpret_cast<const float4*>(p.act_scale + n);
+    sh = *reinterpret_cast<const float4*>(p.act_shift + n);
+  }
   // (1) row half of the output transform on the wave's own accumulators: with m[w][c] = acc[c] (c = fi),
   //     s[w][0] = m0 + m1 + m2,  s[w][1] = m1 - m2 - m3   -> S[w][jj][tile][cout] in LDS (the K loop ended with a barrier)
   float* S = smem;
@@ -224,53 +305,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
   }
   __syncthreads();
-  // (2) column half + fused epilogue: item = (tile, 4 channels); Y[0][jj] = s[0][jj] + s[1][jj] + s[2][jj], Y[1][jj] = s[1][jj] - s[2][jj] - s[3][jj]
-  const int n0 = cb * WCOUT;
-#pragma unroll 1
-  for (int it = 0; it < (WT * (WCOUT / 4)) / 256; ++it) {
-    const int item = it * 256 + tid;
-    const int tl = item >> 4, c4 = (item & 15) * 4;
-    const int off = tile_tab[2 * tl], bits = tile_tab[2 * tl + 1];
-    if (off < 0) continue;
-    const int n = n0 + c4;
-    float4 s[4][2];
+  // (2) column half + fused epilogue: Y[0][jj] = s[0][jj] + s[1][jj] + s[2][jj], Y[1][jj] = s[1][jj] - s[2][jj] - s[3][jj]
+  const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
+  const bool has_res = p.residual != nullptr, relu = p.relu != 0, has_act = p.y_act != nullptr;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tl = it * 16 + (tid >> 4);
+    float4 s4[4][2];
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) s[w][jj] = *reinterpret_cast<const float4*>(S + ((size_t)(w * 2 + jj) * WT + tl) * WCOUT + c4);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.y_act) {
-      sc = *reinterpret_cast<const float4*>(p.act_scale + n);
-      sh = *reinterpret_cast<const float4*>(p.act_shift + n);
-    }
+      for (int jj = 0; jj < 2; ++jj) s4[w][jj] = *reinterpret_cast<const float4*>(S + ((size_t)(w * 2 + jj) * WT + tl) * WCOUT + (tid & 15) * 4);
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        if ((ii && !(bits & 1)) || (jj && !(bits & 2))) continue;
         float4 v;
         if (ii == 0) {
-          v.x = (s[0][jj].x + s[1][jj].x) + s[2][jj].x; v.y = (s[0][jj].y + s[1][jj].y) + s[2][jj].y;
-          v.z = (s[0][jj].z + s[1][jj].z) + s[2][jj].z; v.w = (s[0][jj].w + s[1][jj].w) + s[2][jj].w;
+          v.x = (s4[0][jj].x + s4[1][jj].x) + s4[2][jj].x; v.y = (s4[0][jj].y + s4[1][jj].y) + s4[2][jj].y;
+          v.z = (s4[0][jj].z + s4[1][jj].z) + s4[2][jj].z; v.w = (s4[0][jj].w + s4[1][jj].w) + s4[2][jj].w;
         } else {
-          v.x = (s[1][jj].x - s[2][jj].x) - s[3][jj].x; v.y = (s[1][jj].y - s[2][jj].y) - s[3][jj].y;
-          v.z = (s[1][jj].z - s[2][jj].z) - s[3][jj].z; v.w = (s[1][jj].w - s[2][jj].w) - s[3][jj].w;
+          v.x = (s4[1][jj].x - s4[2][jj].x) - s4[3][jj].x; v.y = (s4[1][jj].y - s4[2][jj].y) - s4[3][jj].y;
+          v.z = (s4[1][jj].z - s4[2][jj].z) - s4[3][jj].z; v.w = (s4[1][jj].w - s4[2][jj].w) - s4[3][jj].w;
         }
-        const size_t o = (size_t)off + (size_t)(ii * p.Wop + jj) * p.Cout + n;
         v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        if (p.residual) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.residual + o);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        if (has_res) {
+          const u32x4 rr = res[it][ii * 2 + jj];
+          v.x += __uint_as_float(rr.x); v.y += __uint_as_float(rr.y); v.z += __uint_as_float(rr.z); v.w += __uint_as_float(rr.w);
         }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.y) *reinterpret_cast<float4*>(p.y + o) = v;
-        if (p.y_act) {
-          float4 a;
-          a.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-          a.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-          *reinterpret_cast<float4*>(p.y_act + o) = a;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        u32x4 o;
+        o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_y, voff[it][ii * 2 + jj], 0, 0);
+        if (has_act) {
+          u32x4 a;
+          a.x = __float_as_uint(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f)); a.y = __float_as_uint(fmaxf(fmaf(v.y, sc.y, sh.y), 0.f));
+          a.z = __float_as_uint(fmaxf(fmaf(v.z, sc.z, sh.z), 0.f)); a.w = __float_as_uint(fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+          __builtin_amdgcn_raw_buffer_store_b128(a, r_act, voff[it][ii * 2 + jj], 0, 0);
         }
       }
   }
@@ -288,6 +360,14 @@ extern "C" int mp_conv_wino_eligible(const mp_conv_desc* d, int n_cu) {
   const long tiles = (long)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
   const long wgs = ((tiles + WT - 1) / WT) * (d->Cout / WCOUT);
   return wgs >= (long)n_cu ? 1 : 0;
+}
+
+static double g_wino_direct = 0.0, g_wino_executed = 0.0;   // host-side totals over the launches since the last reset
+extern "C" int mp_conv_wino_stats(double* direct_flops, double* executed_flops, int reset) {
+  if (direct_flops) *direct_flops = g_wino_direct;
+  if (executed_flops) *executed_flops = g_wino_executed;
+  if (reset) g_wino_direct = g_wino_executed = 0.0;
+  return MP_OK;
 }
 
 extern "C" size_t mp_conv_wino_packed_floats(int Cin_p, int Cout) { return (size_t)16 * Cin_p * Cout; }
@@ -335,7 +415,8 @@ extern "C" int mp_conv3x3_wino_nhwc(const mp_conv_desc* d, const float* d_u, mp_
   p.tiles_x = (d->W + 1) / 2; p.tiles_y = (d->H + 1) / 2;
   const long n_tiles = (long)d->N * p.tiles_x * p.tiles_y;
   const long in_bytes = ((long)d->N * p.Hp + 2) * p.Wp * p.C * 4, out_elems = (long)d->N * p.Hop * p.Wop * d->Cout;
-  MP_REQUIRE(n_tiles < (1L << 30) && in_bytes < (1L << 31) && out_elems < (1L << 31), "mp_conv3x3_wino_nhwc: tensor too large for 32-bit offsets");
+  MP_REQUIRE(n_tiles < (1L << 30) && in_bytes < (1L << 31) && out_elems < (1L << 29), "mp_conv3x3_wino_nhwc: tensor too large for 32-bit offsets");
+  p.out_bytes = (int)(out_elems * 4);
   p.n_tiles = (int)n_tiles;
   p.n_chunks = d->C / 8;
   p.n_steps = d->C / WCK;
@@ -348,11 +429,15 @@ extern "C" int mp_conv3x3_wino_nhwc(const mp_conv_desc* d, const float* d_u, mp_
   }
   const long n_wg = ((n_tiles + WT - 1) / WT) * p.n_cblocks;
   hipStream_t s = (hipStream_t)stream;
-  // profiler row: EXECUTED flops (16 multiplications per 2x2 tile and (cin, cout) pair); the direct-equivalent figure is 2.25x that
-  // for fully used tiles.  bytes = input + weights + output once.
+  // profiler row: the ALGORITHMIC work of the layer as SURVEY.md 8d defines it (2 * MACs of the direct convolution over the real
+  // channels; bytes = input + weights + output once).  What the kernel EXECUTES is 16 multiplications per 2x2 tile and (cin, cout)
+  // pair -- 16/36 of that for even sizes; both totals are accumulated for mp_conv_wino_stats (bench.py reports the executed rate as
+  // the kernel's MFMA utilisation, which is <= 1 by construction, next to the algorithmic rate, which may exceed the matrix peak).
   const double c_real = d->c_real > 0 ? d->c_real : d->C;
-  ProfScope prof("conv3x3_wino_f32<64x64,F(2x2,3x3)>", 2.0 * 16.0 * (double)n_tiles * c_real * d->Cout,
-                 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout) + 16.0 * d->C * d->Cout), s);
+  const double direct = 2.0 * 9.0 * (double)d->N * d->H * d->W * c_real * d->Cout, executed = 2.0 * 16.0 * (double)n_tiles * c_real * d->Cout;
+  g_wino_direct += direct;
+  g_wino_executed += executed;
+  ProfScope prof("conv3x3_wino_f32<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout) + 16.0 * d->C * d->Cout), s);
   hipLaunchKernelGGL(conv3x3_wino_f32, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;

@@ -62,6 +62,13 @@ def conv_clock(reset: bool = True) -> float:
     return mhz.value
 
 
+def conv_wino_stats(reset: bool = True) -> Tuple[float, float]:
+    """(algorithmic = direct-convolution FLOPs, FLOPs actually executed) of the Winograd launches since the last reset"""
+    a, b = C.c_double(0), C.c_double(0)
+    check(_lib.load().mp_conv_wino_stats(C.byref(a), C.byref(b), 1 if reset else 0))
+    return a.value, b.value
+
+
 def profile_begin() -> None:
     check(_lib.load().mp_profile_begin())
 
@@ -279,6 +286,33 @@ def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int
         check(lib.mp_conv2d_nhwc_split(C.byref(d), split_products, _stream()))
     else:
         check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
+
+
+def conv_wino_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
+    """Winograd-transformed weights U = G g G^T of a 3x3 layer in MFMA fragment order (mp_conv_wino_pack_weights)"""
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin, KH, KW = w.shape
+    assert KH == 3 and KW == 3
+    out = np.empty(lib.mp_conv_wino_packed_floats(cin_p, Cout), dtype=np.float32)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    check(lib.mp_conv_wino_pack_weights(w.ctypes.data, Cout, Cin, cin_p, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    return out
+
+
+def conv3x3_wino_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int, u_packed: torch.Tensor,
+                      bias: Optional[torch.Tensor], Cout: int, y: Optional[torch.Tensor], out_border: int,
+                      residual: Optional[torch.Tensor] = None, relu: bool = False, y_act: Optional[torch.Tensor] = None,
+                      act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None) -> None:
+    """Fused Winograd F(2x2, 3x3) form of a 3x3 / stride-1 / pad-1 convolution (mp_conv3x3_wino_nhwc).  `x` must carry
+    (W + 2 * in_border + 1) * Cp floats of readable slack behind the tensor when H or W is odd."""
+    d = ConvDesc()
+    d.d_x, d.N, d.H, d.W, d.C, d.in_border = x.data_ptr(), N, H, W, Cp, in_border
+    d.d_bias = _ptr(bias)
+    d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, 3, 3, 1, 1
+    d.d_y, d.out_border, d.d_residual, d.relu = _ptr(y), out_border, _ptr(residual), int(relu)
+    d.d_y_act, d.d_act_scale, d.d_act_shift = _ptr(y_act), _ptr(act_scale), _ptr(act_shift)
+    check(_lib.load().mp_conv3x3_wino_nhwc(C.byref(d), u_packed.data_ptr(), _stream()))
 
 
 def conv2d_plan(N: int, H: int, W: int, Cp: int, in_border: int, Cout: int, K: int, stride: int, pad: int, n_cu: int,

@@ -94,6 +94,88 @@ def test_conv_matches_torch_fp32(eng, case, epi, splitk):
         assert (got_a - ref_a).abs().max().item() < tol * 2
 
 
+WINO_CASES = [
+    # N, Cin, H, W, Cout, in_border
+    (3, 64, 12, 16, 64, 1),
+    (5, 64, 15, 20, 128, 1),    # odd height: the last tile row is half empty
+    (2, 128, 13, 11, 64, 1),    # odd height and width
+    (4, 256, 8, 10, 256, 1),
+    (70, 16, 6, 6, 64, 2),      # 630 tiles: ten workgroups, the last one partial; border larger than the pad
+    (2, 512, 8, 10, 512, 1),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "res_relu", "dual"])
+def test_winograd_conv_matches_torch_fp32(eng, case, epi):
+    """mp_conv3x3_wino_nhwc (fused Winograd F(2x2, 3x3), csrc/conv_wino.hip) against torch's fp32 convolution, every fused epilogue;
+    the slack the kernel may read behind an odd-sized input is poisoned with NaN (nothing read there may reach an output).
+    Reference layers: models/torchvision_resnet.py:74-120, models/wide_resnet.py:29-56."""
+    N, Cin, H, W, Cout, ib = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, W, generator=g)
+    xb0 = _to_padded(eng, x, Cin, ib)
+    n_x = N * (H + 2 * ib) * (W + 2 * ib) * Cin
+    xb = torch.full((n_x + (W + 2 * ib + 1) * Cin + 64,), float("nan"), device="cuda")
+    xb[:n_x] = xb0.flatten()[:n_x]
+    use_scale = epi != "plain"
+    up = torch.from_numpy(eng.conv_wino_pack_weights(w.numpy(), Cin, scale.numpy() if use_scale else None)).cuda()
+    ob = 1
+    yb = eng.padded_nhwc(N, H, W, Cout, ob, "cuda")
+    yb += 7.0  # poison: interior must be fully overwritten, the border untouched
+    ya = eng.padded_nhwc(N, H, W, Cout, ob, "cuda") if epi == "dual" else None
+    sc2, sh2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    rb = _to_padded(eng, res, Cout, ob) if epi in ("res_relu", "dual") else None
+    eng.conv3x3_wino_nhwc(xb, N, H, W, Cin, ib, up, bias.cuda() if use_scale else None, Cout, yb, ob, residual=rb,
+                          relu=epi in ("bias_relu", "res_relu"), y_act=ya, act_scale=sc2.cuda() if ya is not None else None,
+                          act_shift=sh2.cuda() if ya is not None else None)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w * (scale.view(-1, 1, 1, 1) if use_scale else 1.0), bias if use_scale else None, padding=1)
+    if epi in ("res_relu", "dual"):
+        ref = ref + res
+    if epi in ("bias_relu", "res_relu"):
+        ref = F.relu(ref)
+    got = _from_padded(eng, yb, N, H, W, Cout, ob)
+    assert torch.isfinite(got).all()
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < tol
+    full = yb[: N * (H + 2) * (W + 2) * Cout].view(N, H + 2, W + 2, Cout)
+    assert torch.all(full[:, 0] == 7.0) and torch.all(full[:, :, 0] == 7.0) and torch.all(full[:, -1] == 7.0) and torch.all(full[:, :, -1] == 7.0)
+    if epi == "dual":
+        ref_a = F.relu(ref * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1))
+        got_a = _from_padded(eng, ya, N, H, W, Cout, ob)
+        assert (got_a - ref_a).abs().max().item() < tol * 2
+
+
+def test_backbone_takes_the_winograd_path_at_full_batch(eng):
+    """a 576-row forward runs its 3x3 / stride-1 layers on the Winograd kernel (profiler row present), a 2-row forward stays on the direct
+    kernel's split-K path (grid too small), and both agree with each other on the rows they share"""
+    from tests.support import synthetic as syn
+
+    sd = syn.make_state_dict("vanilla_resnet34", 9, "logits", 1, seed=5)
+    bb = eng.Backbone("vanilla_resnet34", 9, "logits", 1, sd)
+    g = torch.Generator().manual_seed(0)
+    x2 = torch.rand(2, 9, 240, 320, generator=g)
+    x = x2.repeat(48, 1, 1, 1)   # 96 rows
+    outs = {}
+    for name, xx in (("small", x2), ("large", x)):
+        b = xx.shape[0]
+        xb = _to_padded(eng, xx, bb.c_in_p, bb.in_border)
+        out, feat = torch.empty(b, 1, device="cuda"), torch.empty(b, 512, device="cuda")
+        eng.profile_begin()
+        bb.forward(xb, b, 240, 320, out, None, feat)
+        prof = eng.profile_end()
+        outs[name] = (feat.cpu(), prof)
+    assert not any(k.startswith("conv3x3_wino") for k in outs["small"][1])
+    assert any(k.startswith("conv3x3_wino") for k in outs["large"][1])
+    assert (outs["large"][0][:2] - outs["small"][0]).abs().max().item() < 2e-5
+    assert torch.equal(outs["large"][0][:2], outs["large"][0][2:4])
+
+
 def test_conv_splitk_is_taken_and_deterministic(eng):
     """layer4-sized conv at batch 1 (M = 80 -> 4 tiles): the split-K path runs (profiler sees its kernels) and is bit-reproducible"""
     g = torch.Generator().manual_seed(1)
