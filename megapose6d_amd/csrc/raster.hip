@@ -58,11 +58,14 @@ struct CropArgs {
 };
 
 // per-view workspace, in ints (every section starts 16-byte aligned):
-//   [hdr HDR_INTS][tile_off n_tiles + 1][large: piece indices, 2 * max_faces][list: cap_list TileRec records of 8 ints]
+//   [hdr HDR_INTS][tile_off n_tiles + 1][tile_off_l n_tiles + 1][list_l: cap_large piece indices][list: cap_list TileRec records of 8 ints]
+// tile_off / list: the binned (small) pieces of every tile as 32-byte records; tile_off_l / list_l: the indices of the LARGE pieces
+// (too big for the 32-bit edge functions or touching > LARGE_TILES tiles) per tile they can own a sample in -- recomputed from the mesh
+// by the tile kernel, but only by the tiles they touch.
 struct BinLayout {
   long long view_ints;
-  int n_tiles, tiles_x, tiles_y, cap_list, max_faces;
-  int off_large, off_list;   // int offsets of the two sections inside a view's block
+  int n_tiles, tiles_x, tiles_y, cap_list, cap_large, max_faces;
+  int off_tl, off_large, off_list;   // int offsets of tile_off_l / list_l / list inside a view's block
 };
 
 __device__ __forceinline__ void tile_range(const Piece& p, int ns, int w, int h, int& tx0, int& ty0, int& tx1, int& ty1) {
@@ -107,20 +110,20 @@ __device__ __forceinline__ bool tile_touched(const TileTest& t, int tx, int ty) 
 __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
                                                           const float* __restrict__ TCO, const float* __restrict__ K, int h, int w, int ns,
                                                           int* __restrict__ ws, BinLayout lay) {
-  extern __shared__ int counts[];  // [n_tiles]: counters, then (in place) exclusive offsets = fill cursors
-  __shared__ int partial[BIN_THREADS];
-  __shared__ int s_nlarge;
+  extern __shared__ int counts[];  // [2][n_tiles]: counters of the binned / the large pieces, then (in place) exclusive offsets = fill cursors
+  __shared__ int partial[2][BIN_THREADS];
   const int view = blockIdx.x;
   const int tid = threadIdx.x;
   int* hdr = ws + (size_t)view * lay.view_ints;
   int* tile_off = hdr + HDR_INTS;
-  int* large = hdr + lay.off_large;
+  int* tile_off_l = hdr + lay.off_tl;
+  int* list_l = hdr + lay.off_large;
   rc::TileRec* list = reinterpret_cast<rc::TileRec*>(hdr + lay.off_list);
+  int* counts_l = counts + lay.n_tiles;
   const MeshDev m = meshes[mesh_ids[view]];
   const float* T = TCO + (size_t)view * 16;
   const float* Kv = K + (size_t)view * 9;
-  for (int i = tid; i < lay.n_tiles; i += BIN_THREADS) counts[i] = 0;
-  if (tid == 0) s_nlarge = 0;
+  for (int i = tid; i < 2 * lay.n_tiles; i += BIN_THREADS) counts[i] = 0;
   __syncthreads();
   const bool finite = rc::view_finite(T, Kv);  // non-finite pose / intrinsics: empty lists -> zero image (panda3d_batch_renderer.py:109-135)
   const int F = finite ? m.n_faces : 0;
@@ -134,42 +137,45 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1) continue;
-      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT) {
-        large[atomicAdd(&s_nlarge, 1)] = p.id;   // piece index == depth-tie id; every tile recomputes and sweeps these
-      } else {
-        const TileTest tt = tile_test_setup(p, ns);
-        for (int ty = ty0; ty <= ty1; ++ty)
-          for (int tx = tx0; tx <= tx1; ++tx)
-            if (tile_touched(tt, tx, ty)) atomicAdd(&counts[ty * lay.tiles_x + tx], 1);
-      }
+      int* cnt = ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT) ? counts_l : counts;
+      const TileTest tt = tile_test_setup(p, ns);
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx)
+          if (tile_touched(tt, tx, ty)) atomicAdd(&cnt[ty * lay.tiles_x + tx], 1);
     }
   }
   __syncthreads();
-  // ---- phase 2: exclusive scan of the tile counters (in place) ---------------------------------------------------------------
+  // ---- phase 2: exclusive scans of the two counter arrays (in place) ---------------------------------------------------------
   const int per = (lay.n_tiles + BIN_THREADS - 1) / BIN_THREADS;
   const int i0 = min(tid * per, lay.n_tiles), i1 = min(i0 + per, lay.n_tiles);
-  int sum = 0;
-  for (int i = i0; i < i1; ++i) sum += counts[i];
-  partial[tid] = sum;
+  int sum[2] = {0, 0};
+  for (int i = i0; i < i1; ++i) { sum[0] += counts[i]; sum[1] += counts_l[i]; }
+  partial[0][tid] = sum[0];
+  partial[1][tid] = sum[1];
   __syncthreads();
-  for (int d = 1; d < BIN_THREADS; d <<= 1) {  // Hillis-Steele inclusive scan over the 512 partial sums
-    const int v = tid >= d ? partial[tid - d] : 0;
+  for (int d = 1; d < BIN_THREADS; d <<= 1) {  // Hillis-Steele inclusive scan over the 512 partial sums (both arrays at once)
+    const int v0 = tid >= d ? partial[0][tid - d] : 0, v1 = tid >= d ? partial[1][tid - d] : 0;
     __syncthreads();
-    partial[tid] += v;
+    partial[0][tid] += v0;
+    partial[1][tid] += v1;
     __syncthreads();
   }
-  const int total = partial[BIN_THREADS - 1];
-  const bool overflow = total > lay.cap_list;
-  int run = partial[tid] - sum;
+  const int total = partial[0][BIN_THREADS - 1], total_l = partial[1][BIN_THREADS - 1];
+  const bool overflow = total > lay.cap_list || total_l > lay.cap_large;
+  int run = partial[0][tid] - sum[0], run_l = partial[1][tid] - sum[1];
   for (int i = i0; i < i1; ++i) {
-    const int c = counts[i];
+    const int c = counts[i], cl = counts_l[i];
     counts[i] = run;
     tile_off[i] = run;
     run += c;
+    counts_l[i] = run_l;
+    tile_off_l[i] = run_l;
+    run_l += cl;
   }
   if (tid == 0) {
     tile_off[lay.n_tiles] = total;
-    hdr[0] = s_nlarge;
+    tile_off_l[lay.n_tiles] = total_l;
+    hdr[0] = total_l;
     hdr[1] = total;
     hdr[2] = overflow ? 1 : 0;  // the lists do not fit: raster_tiles walks ALL piece indices of this view instead (slow, correct)
     hdr[3] = 0;
@@ -185,11 +191,15 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       if (p.id < 0) continue;
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
-      if (tx0 > tx1 || ty0 > ty1 || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT) continue;
+      if (tx0 > tx1 || ty0 > ty1) continue;
+      const bool is_large = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT;
       const TileTest tt = tile_test_setup(p, ns);
       for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx)
-          if (tile_touched(tt, tx, ty)) list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = rc::pack_tile_rec(p, tx * TILE, ty * TILE);
+        for (int tx = tx0; tx <= tx1; ++tx) {
+          if (!tile_touched(tt, tx, ty)) continue;
+          if (is_large) list_l[atomicAdd(&counts_l[ty * lay.tiles_x + tx], 1)] = p.id;   // piece index == depth-tie id
+          else list[atomicAdd(&counts[ty * lay.tiles_x + tx], 1)] = rc::pack_tile_rec(p, tx * TILE, ty * TILE);
+        }
     }
   }
 }
@@ -279,13 +289,16 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
     const bool ok = (ok_mask >> k) & 1u;
     const uint32_t rel_k = rel[k];
     unsigned long long bk = best[k];
+    // visits, software-pipelined: the record of the NEXT visit is requested before the current one is evaluated (the LDS latency
+    // of a visit would otherwise be exposed on every trip: the chain read -> 3 dot products -> compare -> depth is serial)
+#ifdef MP_RASTER_NOPIPE
     while (m) {
       const int j = __ffsll((long long)m) - 1;
       m &= m - 1ull;
-      const uint4 a = blk[j * 3], b = blk[j * 3 + 1], c = blk[j * 3 + 2];   // wave-uniform address: broadcast reads
+      const uint4 a = blk[j * 3], b = blk[j * 3 + 1], c = blk[j * 3 + 2];
       rc::BlkRec r;
       r.dxy[0] = a.x; r.dxy[1] = a.y; r.dxy[2] = a.z;
-      r.thr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);     // scalar: the three thresholds become SALU bit tests
+      r.thr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);
       r.e0[0] = (int)b.x; r.e0[1] = (int)b.y; r.e0[2] = (int)b.z;
       r.inv_area = __uint_as_float(b.w);
       r.iz[0] = __uint_as_float(c.x); r.iz[1] = __uint_as_float(c.y); r.iz[2] = __uint_as_float(c.z);
@@ -295,6 +308,32 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
         if (ok && key > bk) bk = key;
       });
     }
+#else
+    if (m) {
+      int j = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      uint4 a = blk[j * 3], b = blk[j * 3 + 1], c = blk[j * 3 + 2];   // wave-uniform address: broadcast reads
+      while (true) {
+        const bool more = m != 0ull;
+        const int jn = more ? __ffsll((long long)m) - 1 : j;
+        m &= m - 1ull;
+        const uint4 an = blk[jn * 3], bn = blk[jn * 3 + 1], cn = blk[jn * 3 + 2];
+        rc::BlkRec r;
+        r.dxy[0] = a.x; r.dxy[1] = a.y; r.dxy[2] = a.z;
+        r.thr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);     // scalar: the three thresholds become SALU bit tests
+        r.e0[0] = (int)b.x; r.e0[1] = (int)b.y; r.e0[2] = (int)b.z;
+        r.inv_area = __uint_as_float(b.w);
+        r.iz[0] = __uint_as_float(c.x); r.iz[1] = __uint_as_float(c.y); r.iz[2] = __uint_as_float(c.z);
+        r.key_lo = c.w;
+        rc::cover_sample_rel(r, rel_k, [&](float wsum) {
+          const unsigned long long key = rc::depth_key_lo(wsum, r.key_lo);
+          if (ok && key > bk) bk = key;
+        });
+        if (!more) break;
+        a = an; b = bn; c = cn;
+      }
+    }
+#endif
     best[k] = bk;
   }
   wave_lds_fence();   // the next batch rewrites the records
@@ -350,18 +389,8 @@ __host__ __device__ constexpr size_t tiles_zt_bytes(int ns) {
 }
 
 struct ViewHdr {   // what a wave needs to know about one view's lists for its tile (wave-uniform)
-  int begin, n_list, n_large, overflow;
+  int begin, n_list, begin_l, n_large, overflow;
 };
-__device__ __forceinline__ ViewHdr load_view_hdr(const int* __restrict__ ws, const BinLayout& lay, int view, int tile, int n_faces) {
-  const int* hdr = ws + (size_t)view * lay.view_ints;
-  const int* tile_off = hdr + HDR_INTS;
-  ViewHdr v;
-  v.overflow = hdr[2];
-  v.begin = v.overflow ? 0 : tile_off[tile];
-  v.n_list = v.overflow ? 2 * n_faces : tile_off[tile + 1] - v.begin;
-  v.n_large = v.overflow ? 0 : hdr[0];
-  return v;
-}
 
 // F16 (MP_RASTER_F16, the "fp16 renders" mode of BASELINE.json configs[4]): `out` holds IEEE binary16 elements -- same element
 // strides, every written channel (renders and the fused crop) is rounded to nearest-even on its way out; nothing else changes.
@@ -409,35 +438,79 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   }
   PROF_T0
 
-  // Software pipeline over the item's views (memory latency, not arithmetic, bounds this kernel): the list header of view r + 1 and
-  // the first 64 records of view r + 1 are requested before view r is processed.
+  // The list headers of the item's first FAST_VIEWS views are fetched at once, one view per lane (one memory round trip instead of one
+  // per view: most tiles of a crop are empty in every view, and for those the header is all there is to wait for), and moved to
+  // SCALAR registers right away.  (They must not live in per-lane registers across the view loop: a value that is read back with
+  // v_readlane is invisible to the register allocator's liveness -- a spill under a partial exec mask inside the loop would lose the
+  // lanes that are inactive there.)  Further views (never in the pose pipeline: 1 or 4 views per item) read their header when
+  // they are reached.  The first 64 records of view r + 1 are requested before view r is processed.
+  constexpr int FAST_VIEWS = 4;
   const int view0 = item * views_per_item;
-  ViewHdr hdr_cur = load_view_hdr(ws, lay, view0, tile, meshes[mesh_ids[view0]].n_faces);
-  ViewHdr hdr_nxt = hdr_cur;
-  if (views_per_item > 1) hdr_nxt = load_view_hdr(ws, lay, view0 + 1, tile, meshes[mesh_ids[view0 + 1]].n_faces);
+  auto fetch_hdr = [&](int view) {   // scalar loads (uniform address)
+    const int* hdr = ws + (size_t)view * lay.view_ints;
+    ViewHdr v;
+    v.overflow = hdr[2];
+    v.begin = 0; v.begin_l = 0; v.n_large = 0;
+    if (v.overflow) {   // rare: the view's lists did not fit -> its tiles walk all 2F piece indices through the recompute path
+      v.n_list = 2 * meshes[mesh_ids[view]].n_faces;
+    } else {
+      v.begin = hdr[HDR_INTS + tile];
+      v.n_list = hdr[HDR_INTS + tile + 1] - v.begin;
+      v.begin_l = hdr[lay.off_tl + tile];
+      v.n_large = hdr[lay.off_tl + tile + 1] - v.begin_l;
+    }
+    return v;
+  };
+  ViewHdr fast[FAST_VIEWS];
+  {
+    int h_begin = 0, h_nlist = 0, h_begin_l = 0, h_nlarge = 0, h_over = 0;
+    if (lane < min(views_per_item, FAST_VIEWS)) {
+      const int* hdr = ws + (size_t)(view0 + lane) * lay.view_ints;
+      h_over = hdr[2];
+      if (h_over) {
+        h_nlist = 2 * meshes[mesh_ids[view0 + lane]].n_faces;
+      } else {
+        h_begin = hdr[HDR_INTS + tile];
+        h_nlist = hdr[HDR_INTS + tile + 1] - h_begin;
+        h_begin_l = hdr[lay.off_tl + tile];
+        h_nlarge = hdr[lay.off_tl + tile + 1] - h_begin_l;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < FAST_VIEWS; ++q) {
+      fast[q].begin = rl(h_begin, q); fast[q].n_list = rl(h_nlist, q); fast[q].begin_l = rl(h_begin_l, q);
+      fast[q].n_large = rl(h_nlarge, q); fast[q].overflow = rl(h_over, q);
+    }
+  }
+  auto hdr_of = [&](int r) {   // r is wave-uniform: scalar selects
+    if (r >= FAST_VIEWS) return fetch_hdr(view0 + r);
+    ViewHdr v = fast[0];
+#pragma unroll
+    for (int q = 1; q < FAST_VIEWS; ++q)
+      if (r == q) v = fast[q];
+    return v;
+  };
+  ViewHdr vh_next = hdr_of(0);
   rc::TileRec rec_nxt;
   rec_nxt.id = -1;
   {
     const rc::TileRec* list0 = reinterpret_cast<const rc::TileRec*>(ws + (size_t)view0 * lay.view_ints + lay.off_list);
-    if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = load_tile_rec(list0 + hdr_cur.begin + lane);
+    if (!vh_next.overflow && lane < vh_next.n_list) rec_nxt = load_tile_rec(list0 + vh_next.begin + lane);
   }
   for (int r = 0; r < views_per_item; ++r) {
     const int view = view0 + r;
-    const int mesh_id = mesh_ids[view];
-    const MeshDev m = meshes[mesh_id];
     const float* T = TCO + (size_t)view * 16;
     const float* Kv = K + (size_t)view * 9;
     const int* vhdr = ws + (size_t)view * lay.view_ints;
     const int* large = vhdr + lay.off_large;
     const rc::TileRec* list = reinterpret_cast<const rc::TileRec*>(vhdr + lay.off_list);
-    const ViewHdr vh = hdr_cur;
+    const ViewHdr vh = vh_next;
     const rc::TileRec rec_first = rec_nxt;
-    hdr_cur = hdr_nxt;
-    if (r + 1 < views_per_item) {   // prefetch: first records of the next view, header of the one after
+    if (r + 1 < views_per_item) {   // prefetch: first records of the next view
+      vh_next = hdr_of(r + 1);
       const rc::TileRec* list_n = reinterpret_cast<const rc::TileRec*>(ws + (size_t)(view + 1) * lay.view_ints + lay.off_list);
       rec_nxt.id = -1;
-      if (!hdr_cur.overflow && lane < hdr_cur.n_list) rec_nxt = load_tile_rec(list_n + hdr_cur.begin + lane);
-      if (r + 2 < views_per_item) hdr_nxt = load_view_hdr(ws, lay, view + 2, tile, meshes[mesh_ids[view + 2]].n_faces);
+      if (!vh_next.overflow && lane < vh_next.n_list) rec_nxt = load_tile_rec(list_n + vh_next.begin + lane);
     }
     const int n_total = vh.n_list + vh.n_large;
     const long long cv = (long long)r * stride_view;
@@ -448,6 +521,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       PROF(0)
       continue;
     }
+    const int mesh_id = mesh_ids[view];
+    const MeshDev m = meshes[mesh_id];
     PROF(0)
     PROF_COUNT(11, 1)
     // ---- coverage + depth, binned records: block visits, the depth keys of the lane's samples in registers ---------------------
@@ -490,7 +565,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
       const int e = base + lane;
       Piece mine_p;
       mine_p.id = -1;
-      if (e < n_idx) rc::piece_from_index<true>(m, T, Kv, vh.overflow ? e : large[e], mine_p);
+      if (e < n_idx) rc::piece_from_index<true>(m, T, Kv, vh.overflow ? e : large[vh.begin_l + e], mine_p);
       int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
       if (mine_p.id >= 0) {
         rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
@@ -740,8 +815,10 @@ static BinLayout bin_layout(const mp_mesh_db* db, int h, int w) {
   lay.n_tiles = lay.tiles_x * lay.tiles_y;
   lay.max_faces = db->max_faces;
   lay.cap_list = 3 * db->max_faces + 2048;
-  lay.off_large = (HDR_INTS + lay.n_tiles + 1 + 3) & ~3;
-  lay.off_list = (lay.off_large + 2 * db->max_faces + 3) & ~3;
+  lay.cap_large = 4 * db->max_faces + 4096;
+  lay.off_tl = (HDR_INTS + lay.n_tiles + 1 + 3) & ~3;
+  lay.off_large = (lay.off_tl + lay.n_tiles + 1 + 3) & ~3;
+  lay.off_list = (lay.off_large + lay.cap_large + 3) & ~3;
   lay.view_ints = (long long)lay.off_list + (long long)lay.cap_list * (long long)(sizeof(rc::TileRec) / sizeof(int));
   return lay;
 }
@@ -756,7 +833,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
                               int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
                               int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream, const CropArgs& crop) {
   MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
-  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && h <= 1024 && views_per_item >= 1, "mp_raster_render: bad size");
+  MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && h <= 1024 && views_per_item >= 1 && views_per_item <= 64,
+             "mp_raster_render: bad size (h, w <= 1024; 1 <= views_per_item <= 64)");
   MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
   MP_REQUIRE((flags & ~(MP_RASTER_NORMALS | MP_RASTER_DEPTH | MP_RASTER_NORMALS_GL | MP_RASTER_MSAA4 | MP_RASTER_F16)) == 0,
              "mp_raster_render: unknown flag bits 0x%x", flags);
@@ -795,7 +873,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   }
   if (crop.images) mark(crop.c0, crop.C);
   {
-    const size_t lds = (size_t)lay.n_tiles * sizeof(int);
+    const size_t lds = (size_t)2 * lay.n_tiles * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
       MP_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bin, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));

@@ -137,7 +137,13 @@ void render_views(const MeshRef* meshes, const TexRef* texs, const int32_t* mesh
             entries.push_back(q);
             slots.push_back(imin(e - L.tile_off[tile], SLOT_NONE));
           }
-          for (int idx : L.large) { Piece q; piece_from_index<true>(m, T, Kv, idx, q); entries.push_back(q); slots.push_back(SLOT_NONE); }
+          for (int idx : L.large) {   // the tile's large list = the large pieces that can own a sample in it (exact tile test, as binned)
+            Piece q;
+            piece_from_index<true>(m, T, Kv, idx, q);
+            if (q.id < 0 || !tile_touched(tile_test_setup(q, NS), tx, ty)) continue;
+            entries.push_back(q);
+            slots.push_back(SLOT_NONE);
+          }
         }
         for (size_t ei = 0; ei < entries.size(); ++ei) {
           const Piece& p = entries[ei];

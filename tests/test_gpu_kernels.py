@@ -493,6 +493,35 @@ def test_conv_full_rounds_plus_splitk_tail(eng, shape):
     assert (outs[0][0] - outs[1][0]).abs().max() < 1e-4 * ref.abs().max()
 
 
+@pytest.mark.parametrize("flags", [1, 17])
+def test_raster_items_of_four_views_bit_exact_vs_oracle(eng, engine_meshes, flags):
+    """One launch, 3 items x 4 views (the refiner's layout: a wave walks the 4 views of its item) against the oracle, view by view, and
+    run to run.  Regression test: the per-view list headers used to be kept in per-lane registers and read back with v_readlane; a
+    register spill under a partial exec mask inside the view loop lost them for the later views (a few wrong pixels, nondeterministic)."""
+    from tests.support import synthetic as syn
+    from oracle import raster as orr
+
+    db = _mesh_db(eng, engine_meshes)
+    rng = np.random.RandomState(7)
+    n_items, V, h, w, Cp = 3, 4, 240, 320, 32
+    Tn = np.stack([syn.random_pose(rng, z_range=(0.3, 0.6)) for _ in range(n_items * V)])
+    Kn = np.repeat(syn.K_EXAMPLE[None].astype(np.float32), n_items * V, 0)
+    Kn[:, :2] *= 0.5
+    ids = torch.tensor([0, 1, 2], dtype=torch.int32).repeat_interleave(V).cuda()
+    ref = [orr.render(engine_meshes[v // V], Tn[v:v + 1], Kn[v:v + 1], h, w, flags | 1) for v in range(n_items * V)]
+    outs = []
+    for rep in range(3):
+        x = torch.full((n_items, h, w, Cp), -3.0, device="cuda")
+        eng.raster_render(db, ids, torch.from_numpy(Tn).cuda(), torch.from_numpy(Kn).cuda(), h, w, flags | 1, eng.make_lights(), x,
+                          h * w * Cp, w * Cp, Cp, 3, 6, -1, views_per_item=V, stride_view=6)
+        outs.append(x.cpu().numpy())
+    for v in range(n_items * V):
+        got = outs[0][v // V, :, :, 3 + 6 * (v % V): 9 + 6 * (v % V)]
+        assert np.array_equal(got[..., :3], ref[v][0][0]), f"view {v}: rgb differs from the oracle"
+        assert np.array_equal(got[..., 3:], ref[v][1][0]), f"view {v}: normals differ from the oracle"
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("C", [3, 4])
 def test_fused_crop_in_raster_launch_equals_standalone_crop(eng, engine_meshes, C):
     """mp_raster_render_crop: the crop role of the band kernel writes exactly what mp_crop_roi_align writes, and leaves the views alone"""
