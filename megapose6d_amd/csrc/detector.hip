@@ -908,6 +908,12 @@ extern "C" int mp_detector_forward(mp_detector* d, const float* d_images, int n,
   MP_REQUIRE(ws_bytes >= p.total * sizeof(float), "mp_detector_forward: workspace %zu < %zu bytes", ws_bytes, p.total * sizeof(float));
   MP_REQUIRE((long)n * p.a_total < (1L << 31) && (long)n * (d->C - 1) * d->cfg.rpn_post_nms_top_n < (1L << 31),
              "mp_detector_forward: %d images of %d anchors exceed the 32-bit index range of the selection kernels; split the batch", n, p.a_total);
+  // The selection kernels rank by counting (O(len^2) compares per segment: deterministic, no library sort).  That is ~3e9 compares for
+  // the 57.6 k P2 anchors of a 480x640 frame (1.5 ms) but grows quadratically: bound the segment sizes instead of degrading silently
+  // (torchvision's default 800x1333 transform gives ~200 k anchors on P2 = 4e10 compares per frame -- use a radix select there).
+  MP_REQUIRE((long)p.hr * p.wr <= 1024L * 1024L && d->C <= 256,
+             "mp_detector_forward: resized frame %dx%d / %d classes exceed what the rank-sort selection is sized for (<= 1024x1024, <= 256 classes)",
+             p.hr, p.wr, d->C);
   const mp_detector_config& cfg = d->cfg;
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)d_ws;

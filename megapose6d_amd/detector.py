@@ -47,7 +47,14 @@ class Detector(torch.nn.Module):
         """detector.py:63-136.  detection_th: keep detections scoring above it; mask_th: threshold of the soft masks;
         one_instance_per_class: keep the best detection of every (image, label)."""
         images = observation.images[:, [0, 1, 2]]  # [B,3,H,W]
-        outputs_ = self.model([image_n for image_n in images])
+        engine_model = hasattr(self.model, "compute_masks")
+        if engine_model:   # the engine's Mask R-CNN can skip its mask head + the pasted [n, D, H, W] masks when nobody reads them
+            saved, self.model.compute_masks = self.model.compute_masks, bool(output_masks and self.model.compute_masks)
+        try:
+            outputs_ = self.model([image_n for image_n in images])
+        finally:
+            if engine_model:
+                self.model.compute_masks = saved
         device = images.device
         infos, bboxes, masks = [], [], []
         for n, out_n in enumerate(outputs_):
@@ -58,7 +65,7 @@ class Detector(torch.nn.Module):
             scores_n = torch.as_tensor(out_n["scores"]).cpu().tolist()
             infos += [dict(batch_im_id=n, label=l, score=float(s)) for l, s in zip(labels_n, scores_n)]
             bboxes.append(torch.as_tensor(out_n["boxes"]).to(device))
-            if "masks" in out_n:
+            if "masks" in out_n and output_masks:   # (the [n, D, H, W] soft masks are only thresholded when the caller wants them)
                 masks.append(torch.as_tensor(out_n["masks"])[:, 0].to(device) > mask_th)
             elif output_masks:   # (engine model with compute_masks = False)
                 raise ValueError("output_masks=True, but the detection model returned no masks (DetectorMaskRCNN.compute_masks is off)")

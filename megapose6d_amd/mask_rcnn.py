@@ -56,10 +56,22 @@ class DetectorMaskRCNN(nn.Module):
         sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
         return super().load_state_dict(sd, strict=strict)
 
+    def invalidate(self) -> None:
+        """Drop the packed device weights (they are rebuilt from state_dict() on the next forward)."""
+        self._engine = None
+
+    def _fingerprint(self):
+        """cheap change detector for the packed device weights: the in-place version counters of every parameter / buffer and
+        the engine settings (an in-place weight edit, model.apply(...), or a changed override after the first forward rebuilds them)"""
+        return (tuple(t._version for t in list(self.parameters()) + list(self.buffers())), tuple(sorted(self.engine_overrides.items())),
+                self.min_size, self.max_size, self.anchor_sizes)
+
     def _net(self) -> eng.DetectorNet:
-        if self._engine is None:
+        fp = self._fingerprint()
+        if self._engine is None or fp != getattr(self, "_engine_fp", None):
             self._engine = eng.DetectorNet(self.state_dict(), self.n_classes, self.min_size, self.max_size,
                                            anchor_sizes=self.anchor_sizes, **self.engine_overrides)
+            self._engine_fp = fp
         return self._engine
 
     @torch.no_grad()
