@@ -269,6 +269,10 @@ int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const 
 /* precision: 0 = native fp32 MFMA (default, what mp_backbone_create builds), 9 / 6 = bf16x9 / bf16x6 split emulation */
 int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* h_state,
                           int n_tensors, int precision, mp_backbone** out);
+/* the same with the WideResNet width multiplier of `resnet34_width=N` (training/pose_models_cfg.py:114-116, models/wide_resnet.py:62:
+ * stage widths 64N .. 512N, features 512N); width = 1 for the released models */
+int mp_backbone_create_wide(int kind, int width, int c_in, int head_kind, int n_head_out, const mp_named_tensor* state, int n_tensors,
+                            int precision, mp_backbone** out);
 int mp_backbone_destroy(mp_backbone* bb);
 int mp_backbone_input_channels_padded(const mp_backbone* bb);
 int mp_backbone_input_border(const mp_backbone* bb);
@@ -312,7 +316,18 @@ int mp_init_poses_from_boxes(const float* d_boxes /*[b,4]*/, const float* d_K /*
 /*   TCV_O = make_TCO_multiview(...)              (lib3d/multiview.py:165-246; App. A.5)     */
 /*   boxes_rend/boxes_crop/K_crop from 2000 pts   (pose_rigid.py:180-247 crop_inputs)        */
 /*   KV_crop from 200 pts for views >= 1          (:249-303; KV_crop[:,0] = K_crop :551-552) */
-/* multiview: 0 = single view (V must be 1), 1 = "TCO+front_3views" (V = 4)                  */
+/* multiview: low byte = mode: 0 single view (V = 1), 1 "TCO+front_3views", 2 "TCO+front_1view", 3 "sphere_26views"            */
+/* (lib3d/multiview.py:197-234), | MP_MV_REMOVE_TCO (remove_TCO_rendering: the TCO view is not in the list and KV_crop[:,0] is  */
+/* NOT replaced by K_crop, models/pose_rigid.py:551-552), | MP_MV_INPLANE (views_inplane_rotations: every view 4x, rotated by   */
+/* 0/90/180/270 degrees about the optical axis, multiview.py:236-245).  V must equal mp_pose_multiview_n_views(multiview).       */
+/* mp_pose_prepare_ex additionally returns K_crop of crop_inputs ([b,3,3], what update_pose consumes) in d_K_main (may be NULL). */
+#define MP_MV_REMOVE_TCO 256
+#define MP_MV_INPLANE 512
+int mp_pose_multiview_n_views(int multiview);
+int mp_pose_prepare_ex(const float* d_TCO_in, const float* d_K, const int32_t* d_mesh_ids, const float* d_points, int n_pts_stride,
+                       int n_pts_main, int n_pts_views, int b, int V, int multiview, int im_h, int im_w, int out_h, int out_w, float lamb,
+                       float* d_TCO_n, float* d_tCR, float* d_TCV_O, float* d_KV_crop, float* d_boxes_rend, float* d_boxes_crop,
+                       float* d_K_main /*[b,3,3] or NULL*/, mp_stream stream);
 int mp_pose_prepare(const float* d_TCO_in /*[b,4,4]*/, const float* d_K /*[b,3,3]*/,
                     const int32_t* d_mesh_ids, const float* d_points /*[n_mesh,n_pts,3] sampled*/,
                     int n_pts_stride, int n_pts_main, int n_pts_views, int b, int V, int multiview,

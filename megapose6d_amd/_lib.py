@@ -121,6 +121,7 @@ SIGNATURES = {
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
     "mp_backbone_create_ex": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, _i, C.POINTER(_vp)]),
+    "mp_backbone_create_wide": (_i, [_i, _i, _i, _i, _i, C.POINTER(NamedTensor), _i, _i, C.POINTER(_vp)]),
     "mp_backbone_destroy": (_i, [_vp]),
     "mp_backbone_input_channels_padded": (_i, [_vp]),
     "mp_backbone_input_border": (_i, [_vp]),
@@ -134,6 +135,8 @@ SIGNATURES = {
     "mp_init_poses_from_boxes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mp_pose_prepare": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp]),
+    "mp_pose_multiview_n_views": (_i, [_i]),
+    "mp_pose_prepare_ex": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_icp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mp_icp_refine": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_pose_update": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),

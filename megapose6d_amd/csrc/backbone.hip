@@ -40,6 +40,8 @@ using namespace mp;
 
 struct mp_backbone {
   int kind, c_in, c_in_p, in_border, head_kind, n_out, n_feat;
+  int width = 1;      // WideResNet width multiplier (`resnet34_width=N`, training/pose_models_cfg.py:114-116): stage widths 64N .. 512N
+  int stageC[4] = {64, 128, 256, 512};
   int precision = 0;  // 0 native fp32 MFMA, 9 / 6 bf16 split products
   bool wide;
   ConvLayer stem;
@@ -188,7 +190,6 @@ Geometry geometry(const mp_backbone* bb, int h, int w) {
   return g;
 }
 
-const int kStageC[4] = {64, 128, 256, 512};
 
 }  // namespace
 
@@ -199,10 +200,17 @@ extern "C" int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_
 
 extern "C" int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
                                      int precision, mp_backbone** out) {
+  return mp_backbone_create_wide(kind, 1, c_in, head_kind, n_head_out, st, n_tensors, precision, out);
+}
+
+extern "C" int mp_backbone_create_wide(int kind, int width, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
+                                       int precision, mp_backbone** out) {
   MP_REQUIRE(out && st && n_tensors > 0, "mp_backbone_create: bad arguments");
   MP_REQUIRE(precision == 0 || precision == 9 || precision == 6, "mp_backbone_create: precision must be 0, 9 or 6");
   MP_REQUIRE(kind >= 0 && kind <= 2, "mp_backbone_create: unknown backbone kind %d", kind);
-  MP_REQUIRE(c_in >= 1 && c_in <= 64, "mp_backbone_create: bad c_in %d", c_in);
+  MP_REQUIRE(width >= 1 && width <= 8 && (width == 1 || kind != MP_BACKBONE_VANILLA_RESNET34),
+             "mp_backbone_create: width multiplier %d (1..8, WideResNets only: training/pose_models_cfg.py:114-116)", width);
+  MP_REQUIRE(c_in >= 1 && c_in <= 512, "mp_backbone_create: bad c_in %d", c_in);   // (sphere_26views: 3 + 27 * 6 = 165 input channels)
   StateMap sm;
   for (int i = 0; i < n_tensors; ++i) sm[st[i].name] = std::make_pair(st[i].h_data, st[i].numel);
   mp_backbone* bb = new mp_backbone();
@@ -213,22 +221,25 @@ extern "C" int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_he
   bb->c_in_p = (c_in + 3) / 4 * 4;
   bb->head_kind = head_kind;
   bb->n_out = n_head_out;
-  bb->n_feat = 512;
+  bb->width = width;
+  for (int k = 0; k < 4; ++k) bb->stageC[k] = bb->stageC[k] * width;
+  const int C0 = bb->stageC[0], NF = bb->stageC[3];
+  bb->n_feat = NF;
   int rc;
 #define MP_TRY(e) do { rc = (e); if (rc) { mp_backbone_destroy(bb); return rc; } } while (0)
   const std::string B = "backbone.";
   if (!bb->wide) {
     bb->in_border = 3;
-    MP_TRY(make_conv(bb, sm, B + "conv1.weight", B + "bn1", c_in, bb->c_in_p, 64, 7, 2, 3, &bb->stem));
+    MP_TRY(make_conv(bb, sm, B + "conv1.weight", B + "bn1", c_in, bb->c_in_p, C0, 7, 2, 3, &bb->stem));
   } else {
     bb->in_border = 2;
-    MP_TRY(make_conv(bb, sm, B + "conv1.weight", B + "bn1", c_in, bb->c_in_p, 64, 5, 2, 2, &bb->stem));
+    MP_TRY(make_conv(bb, sm, B + "conv1.weight", B + "bn1", c_in, bb->c_in_p, C0, 5, 2, 2, &bb->stem));
   }
   static const int n34[4] = {3, 4, 6, 3}, n18[4] = {2, 2, 2, 2};
   const int* nblocks = (kind == MP_BACKBONE_WIDE_RESNET18) ? n18 : n34;
-  int inplanes = 64;
+  int inplanes = C0;
   for (int s = 0; s < 4; ++s) {
-    const int planes = kStageC[s];
+    const int planes = bb->stageC[s];
     for (int i = 0; i < nblocks[s]; ++i) {
       Block blk;
       const int stride = (i == 0 && s > 0) ? 2 : 1;
@@ -259,10 +270,10 @@ extern "C" int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_he
     MP_TRY(upload(bb, std::vector<float>(fb, fb + 512), &bb->d_fc_b));
   }
   const std::string H = head_kind == 0 ? "pose_fc" : "views_logits_head";
-  const float* hw = find(sm, H + ".weight", (int64_t)n_head_out * 512);
+  const float* hw = find(sm, H + ".weight", (int64_t)n_head_out * NF);
   const float* hb = find(sm, H + ".bias", n_head_out);
   if (!hw || !hb) { mp_backbone_destroy(bb); return MP_ERR_INVALID; }
-  MP_TRY(upload(bb, std::vector<float>(hw, hw + (size_t)n_head_out * 512), &bb->d_head_w));
+  MP_TRY(upload(bb, std::vector<float>(hw, hw + (size_t)n_head_out * NF), &bb->d_head_w));
   MP_TRY(upload(bb, std::vector<float>(hb, hb + n_head_out), &bb->d_head_b));
 #undef MP_TRY
   *out = bb;
@@ -283,9 +294,9 @@ extern "C" int mp_backbone_input_border(const mp_backbone* bb) { return bb ? bb-
 extern "C" size_t mp_backbone_workspace_bytes(const mp_backbone* bb, int batch, int h, int w) {
   if (!bb || batch <= 0) return 0;
   const Geometry g = geometry(bb, h, w);
-  size_t fl = align_up(buf_floats(batch, g.h1, g.w1, 64), 64);
+  size_t fl = align_up(buf_floats(batch, g.h1, g.w1, bb->stageC[0]), 64);
   const int per_stage = bb->wide ? 4 : 3;
-  for (int s = 0; s < 4; ++s) fl += per_stage * align_up(buf_floats(batch, g.hs[s], g.ws[s], kStageC[s]), 64);
+  for (int s = 0; s < 4; ++s) fl += per_stage * align_up(buf_floats(batch, g.hs[s], g.ws[s], bb->stageC[s]), 64);
   fl += SPLITK_WS_FLOATS;
   return fl * sizeof(float);
 }
@@ -316,10 +327,10 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, 
     bb->ws_known.push_back({d_ws, batch, h, w});
   }
   float* p = (float*)d_ws;
-  float* S = p; p += align_up(buf_floats(batch, g.h1, g.w1, 64), 64);
+  float* S = p; p += align_up(buf_floats(batch, g.h1, g.w1, bb->stageC[0]), 64);
   float *A[4], *Aact[4], *Bf[4], *Cf[4];
   for (int st = 0; st < 4; ++st) {
-    const size_t n = align_up(buf_floats(batch, g.hs[st], g.ws[st], kStageC[st]), 64);
+    const size_t n = align_up(buf_floats(batch, g.hs[st], g.ws[st], bb->stageC[st]), 64);
     A[st] = p; p += n;
     Aact[st] = nullptr;
     if (bb->wide) { Aact[st] = p; p += n; }
@@ -332,7 +343,7 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, 
   rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
   if (rc) return rc;
   const Block& b0 = bb->blocks[0];
-  rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, 64, 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
+  rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, bb->stageC[0], 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
                        bb->wide ? b0.pre.d_shift : nullptr, s);
   if (rc) return rc;
   const int nb = (int)bb->blocks.size();
@@ -369,7 +380,7 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, 
       if (rc) return rc;
     }
   }
-  return mp_pool_fc_heads(A[3], batch, g.hs[3], g.ws[3], 512, 1, bb->d_fc_w, bb->d_fc_b, 512, bb->d_head_w, bb->d_head_b, bb->n_out,
+  return mp_pool_fc_heads(A[3], batch, g.hs[3], g.ws[3], bb->stageC[3], 1, bb->d_fc_w, bb->d_fc_b, bb->n_feat, bb->d_head_w, bb->d_head_b, bb->n_out,
                           d_feat, d_out, d_sigmoid, s);
 }
 
@@ -395,6 +406,6 @@ extern "C" double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int
     if (blk.has_down) f += conv_flops(blk.down, g.hs[so], g.ws[so]);
   }
   if (!bb->wide) f += 2.0 * 512 * 512;
-  f += 2.0 * 512 * bb->n_out;
+  f += 2.0 * bb->n_feat * bb->n_out;
   return f * batch;
 }

@@ -126,16 +126,26 @@ __global__ __launch_bounds__(256) void pose_prepare_kernel(
     const float* __restrict__ TCO_in, const float* __restrict__ K, const int32_t* __restrict__ mesh_ids,
     const float* __restrict__ points, int n_pts_stride, int n_pts_main, int n_pts_views, int V, int multiview, int im_h,
     int im_w, int out_h, int out_w, float lamb, float* __restrict__ TCO_n, float* __restrict__ tCR_out,
-    float* __restrict__ TCV_O, float* __restrict__ KV_crop, float* __restrict__ boxes_rend, float* __restrict__ boxes_crop) {
+    float* __restrict__ TCV_O, float* __restrict__ KV_crop, float* __restrict__ boxes_rend, float* __restrict__ boxes_crop,
+    float* __restrict__ K_main) {
   __shared__ float Tn[16];
   __shared__ float Tv[16];
   __shared__ float P[12];
   __shared__ float red[4][4];
   const int row = blockIdx.x, view = blockIdx.y;
   const float* Ki = K + (size_t)row * 9;
+  // view list of the mode (lib3d/multiview.py:197-246): [TCO unless removed] + the mode's camera offsets; with in-plane rotations
+  // every entry is repeated 4x (rotated by 0 / 90 / 180 / 270 degrees about the optical axis).  blockIdx.y == V (only launched when
+  // the TCO rendering is removed) is the MAIN unit: crop_inputs of the observation from TCO itself (models/pose_rigid.py:180-247).
+  const int mode = multiview & 255;
+  const bool remove_tco = (multiview & MP_MV_REMOVE_TCO) != 0, inplane = (multiview & MP_MV_INPLANE) != 0;
+  const bool main_only = view == V;
+  const int base = inplane ? view >> 2 : view, quarter = inplane ? view & 3 : 0;
+  const bool is_tco = main_only || mode == 0 || (!remove_tco && base == 0);
+  const bool is_main = remove_tco ? main_only : (view == 0);
   if (threadIdx.x == 0) {
     normalize_T_dev(TCO_in + (size_t)row * 16, Tn);
-    if (view == 0 || multiview == 0) {
+    if (is_tco) {
       for (int k = 0; k < 16; ++k) Tv[k] = Tn[k];
     } else {
       // TOC = inv(TCO_n)
@@ -151,9 +161,23 @@ __global__ __launch_bounds__(256) void pose_prepare_kernel(
       const float radius = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
       V3 lx, ly, lz;
       look_at(p0, ref, up, lx, ly, lz);
-      // "TCO+front_3views" offsets (multiview.py:104-112): view 1 -> (0,0,0), 2 -> (+1,0,0), 3 -> (-1,0,0)
-      const float ox = (view == 2 ? 1.0f : (view == 3 ? -1.0f : 0.0f)) * radius;
-      const V3 pn = v3(p0.x + lx.x * ox, p0.y + lx.y * ox, p0.z + lx.z * ox);
+      // camera offsets in the look-at frame (x right, y forward, z up), in units of |tCR|:
+      //   "TCO+front_3views" (multiview.py:104-112): (0,0,0), (+1,0,0), (-1,0,0);  "TCO+front_1view" (:95-101): (0,0,0);
+      //   "sphere_26views" (:150-162): y in [0,1,2] x x in [0,-1,1] x z in [0,1,-1] without (0,1,0)
+      const int oi = base - (remove_tco ? 0 : 1);
+      float fx_o = 0.f, fy_o = 0.f, fz_o = 0.f;
+      if (mode == 1) {
+        fx_o = oi == 1 ? 1.0f : (oi == 2 ? -1.0f : 0.0f);
+      } else if (mode == 3) {
+        const int raw = oi >= 9 ? oi + 1 : oi;   // the skipped combination (x, y, z) = (0, 1, 0) is number 9 of the 27
+        const int yi = raw / 9, xi = (raw / 3) % 3, zi = raw % 3;
+        fy_o = (float)yi;
+        fx_o = xi == 0 ? 0.f : (xi == 1 ? -1.f : 1.f);
+        fz_o = zi == 0 ? 0.f : (zi == 1 ? 1.f : -1.f);
+      }
+      const float ox = fx_o * radius, oy = fy_o * radius, oz = fz_o * radius;
+      const V3 pn = v3(p0.x + lx.x * ox + ly.x * oy + lz.x * oz, p0.y + lx.y * ox + ly.y * oy + lz.y * oz,
+                       p0.z + lx.z * ox + ly.z * oy + lz.z * oz);
       V3 nx, ny, nz;
       look_at(pn, ref, up, nx, ny, nz);
       // TCV_O = [TCCGL Rn^T | -TCCGL Rn^T pn] : rows (x, -z, y)
@@ -162,19 +186,30 @@ __global__ __launch_bounds__(256) void pose_prepare_kernel(
       Tv[8] = ny.x; Tv[9] = ny.y; Tv[10] = ny.z; Tv[11] = -dot(ny, pn);
       Tv[12] = 0.f; Tv[13] = 0.f; Tv[14] = 0.f; Tv[15] = 1.f;
     }
+    if (quarter) {   // in-plane copy: R' = Rz(quarter * 90 deg) R, translation unchanged (multiview.py:236-245)
+      const float c = quarter == 2 ? -1.f : 0.f, sn = quarter == 1 ? 1.f : (quarter == 3 ? -1.f : 0.f);
+      for (int j = 0; j < 3; ++j) {
+        const float a0 = Tv[j], a1 = Tv[4 + j];
+        Tv[j] = c * a0 - sn * a1;
+        Tv[4 + j] = sn * a0 + c * a1;
+      }
+    }
     // P = K @ Tv[:3]  (3x4)
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 4; ++j) P[i * 4 + j] = Ki[i * 3] * Tv[j] + Ki[i * 3 + 1] * Tv[4 + j] + Ki[i * 3 + 2] * Tv[8 + j];
-    if (view == 0) {
+    if (is_main) {
       for (int k = 0; k < 16; ++k) TCO_n[(size_t)row * 16 + k] = Tn[k];
       tCR_out[(size_t)row * 3 + 0] = Tn[3];
       tCR_out[(size_t)row * 3 + 1] = Tn[7];
       tCR_out[(size_t)row * 3 + 2] = Tn[11];
     }
-    for (int k = 0; k < 16; ++k) TCV_O[((size_t)row * V + view) * 16 + k] = Tv[k];
+    if (!main_only)
+      for (int k = 0; k < 16; ++k) TCV_O[((size_t)row * V + view) * 16 + k] = Tv[k];
   }
   __syncthreads();
-  const int n_pts = (view == 0) ? n_pts_main : n_pts_views;
+  // crop_inputs samples 2000 points, compute_crops_multiview 200 (pose_rigid.py:213, :279); KV_crop[:, 0] = K_crop only when the TCO
+  // view is rendered (:551-552)
+  const int n_pts = is_main ? n_pts_main : n_pts_views;
   const float* pts = points + (size_t)mesh_ids[row] * n_pts_stride * 3;
   float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
   for (int i = threadIdx.x; i < n_pts; i += blockDim.x) {
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(256) void pose_prepare_kernel(
     const float width = fmaxf(xdist, ydist * r) * 2.0f * lamb;
     const float height = fmaxf(xdist / r, ydist) * 2.0f * lamb;
     const float x1 = xc - width / 2.0f, y1 = yc - height / 2.0f, x2 = xc + width / 2.0f, y2 = yc + height / 2.0f;
-    if (view == 0) {
+    if (is_main) {
       float* br = boxes_rend + (size_t)row * 4;
       br[0] = umin; br[1] = vmin; br[2] = umax; br[3] = vmax;
       float* bc = boxes_crop + (size_t)row * 4;
@@ -225,10 +260,18 @@ __global__ __launch_bounds__(256) void pose_prepare_kernel(
     const float fx = scale_x * Ki[0], fy = scale_y * Ki[4];
     cx = scaled_center_x + scale_x * orig_cx_diff;
     cy = scaled_center_y + scale_y * orig_cy_diff;
-    float* Ko = KV_crop + ((size_t)row * V + view) * 9;
-    Ko[0] = fx; Ko[1] = Ki[1]; Ko[2] = cx;
-    Ko[3] = Ki[3]; Ko[4] = fy; Ko[5] = cy;
-    Ko[6] = Ki[6]; Ko[7] = Ki[7]; Ko[8] = Ki[8];
+    if (!main_only) {
+      float* Ko = KV_crop + ((size_t)row * V + view) * 9;
+      Ko[0] = fx; Ko[1] = Ki[1]; Ko[2] = cx;
+      Ko[3] = Ki[3]; Ko[4] = fy; Ko[5] = cy;
+      Ko[6] = Ki[6]; Ko[7] = Ki[7]; Ko[8] = Ki[8];
+    }
+    if (is_main && K_main) {   // K_crop of crop_inputs: what update_pose consumes (pose_rigid.py:305-312)
+      float* Ko = K_main + (size_t)row * 9;
+      Ko[0] = fx; Ko[1] = Ki[1]; Ko[2] = cx;
+      Ko[3] = Ki[3]; Ko[4] = fy; Ko[5] = cy;
+      Ko[6] = Ki[6]; Ko[7] = Ki[7]; Ko[8] = Ki[8];
+    }
   }
 }
 
@@ -290,22 +333,43 @@ extern "C" int mp_init_poses_from_boxes(const float* d_boxes, const float* d_K, 
   return MP_OK;
 }
 
+extern "C" int mp_pose_multiview_n_views(int multiview) {
+  const int mode = multiview & 255;
+  if (mode < 0 || mode > 3) return -1;
+  if (mode == 0) return 1;
+  const int n_off = mode == 1 ? 3 : (mode == 2 ? 1 : 26);
+  const int n_base = ((multiview & MP_MV_REMOVE_TCO) ? 0 : 1) + n_off;
+  return n_base * ((multiview & MP_MV_INPLANE) ? 4 : 1);
+}
+
+extern "C" int mp_pose_prepare_ex(const float* d_TCO_in, const float* d_K, const int32_t* d_mesh_ids, const float* d_points,
+                                  int n_pts_stride, int n_pts_main, int n_pts_views, int b, int V, int multiview, int im_h,
+                                  int im_w, int out_h, int out_w, float lamb, float* d_TCO_n, float* d_tCR, float* d_TCV_O,
+                                  float* d_KV_crop, float* d_boxes_rend, float* d_boxes_crop, float* d_K_main, mp_stream stream) {
+  MP_REQUIRE(d_TCO_in && d_K && d_mesh_ids && d_points && d_TCO_n && d_tCR && d_TCV_O && d_KV_crop && d_boxes_rend && d_boxes_crop,
+             "mp_pose_prepare: null pointer");
+  const int v_need = mp_pose_multiview_n_views(multiview);
+  MP_REQUIRE(v_need > 0 && (multiview & ~(255 | MP_MV_REMOVE_TCO | MP_MV_INPLANE)) == 0, "mp_pose_prepare: unknown multiview code 0x%x", multiview);
+  MP_REQUIRE(V == v_need, "mp_pose_prepare: multiview 0x%x has %d views, got V=%d", multiview, v_need, V);
+  MP_REQUIRE(!(multiview & MP_MV_INPLANE) || (multiview & MP_MV_REMOVE_TCO), "mp_pose_prepare: views_inplane_rotations needs remove_TCO_rendering "
+             "(lib3d/multiview.py:237)");
+  MP_REQUIRE(n_pts_main <= n_pts_stride && n_pts_views <= n_pts_stride && n_pts_main > 0, "mp_pose_prepare: bad point counts");
+  if (b == 0) return MP_OK;
+  const bool extra = (multiview & 255) != 0 && (multiview & MP_MV_REMOVE_TCO);   // the TCO view is not rendered: one more unit for the main crop
+  ProfScope prof("pose_prepare", 0.0, (double)b * (12.0 * n_pts_main + (V - 1) * 12.0 * n_pts_views), (hipStream_t)stream);
+  hipLaunchKernelGGL(pose_prepare_kernel, dim3(b, V + (extra ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, d_TCO_in, d_K, d_mesh_ids, d_points,
+                     n_pts_stride, n_pts_main, n_pts_views, V, multiview, im_h, im_w, out_h, out_w, lamb, d_TCO_n, d_tCR, d_TCV_O,
+                     d_KV_crop, d_boxes_rend, d_boxes_crop, d_K_main);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}
+
 extern "C" int mp_pose_prepare(const float* d_TCO_in, const float* d_K, const int32_t* d_mesh_ids, const float* d_points,
                                int n_pts_stride, int n_pts_main, int n_pts_views, int b, int V, int multiview, int im_h,
                                int im_w, int out_h, int out_w, float lamb, float* d_TCO_n, float* d_tCR, float* d_TCV_O,
                                float* d_KV_crop, float* d_boxes_rend, float* d_boxes_crop, mp_stream stream) {
-  MP_REQUIRE(d_TCO_in && d_K && d_mesh_ids && d_points && d_TCO_n && d_tCR && d_TCV_O && d_KV_crop && d_boxes_rend && d_boxes_crop,
-             "mp_pose_prepare: null pointer");
-  MP_REQUIRE((multiview == 0 && V == 1) || (multiview == 1 && V == 4), "mp_pose_prepare: multiview %d needs V=%d", multiview,
-             multiview == 0 ? 1 : 4);
-  MP_REQUIRE(n_pts_main <= n_pts_stride && n_pts_views <= n_pts_stride && n_pts_main > 0, "mp_pose_prepare: bad point counts");
-  if (b == 0) return MP_OK;
-  ProfScope prof("pose_prepare", 0.0, (double)b * (12.0 * n_pts_main + (V - 1) * 12.0 * n_pts_views), (hipStream_t)stream);
-  hipLaunchKernelGGL(pose_prepare_kernel, dim3(b, V), dim3(256), 0, (hipStream_t)stream, d_TCO_in, d_K, d_mesh_ids, d_points,
-                     n_pts_stride, n_pts_main, n_pts_views, V, multiview, im_h, im_w, out_h, out_w, lamb, d_TCO_n, d_tCR, d_TCV_O,
-                     d_KV_crop, d_boxes_rend, d_boxes_crop);
-  MP_CHECK_HIP(hipGetLastError());
-  return MP_OK;
+  return mp_pose_prepare_ex(d_TCO_in, d_K, d_mesh_ids, d_points, n_pts_stride, n_pts_main, n_pts_views, b, V, multiview, im_h, im_w, out_h,
+                            out_w, lamb, d_TCO_n, d_tCR, d_TCV_O, d_KV_crop, d_boxes_rend, d_boxes_crop, nullptr, stream);
 }
 
 extern "C" int mp_pose_update(const float* d_TCO, const float* d_K_crop, int k_stride_floats, const float* d_out9,

@@ -358,8 +358,12 @@ class Backbone:
 
     def __init__(self, kind: str, c_in: int, head: str, n_out: int, state_dict: Dict[str, torch.Tensor], precision: int = 0):
         lib = _lib.load()
+        width = 1
+        if kind.startswith("resnet34_width="):   # training/pose_models_cfg.py:114-116: WideResNet34(width=int(...))
+            width, kind = int(kind.split("resnet34_width=")[1]), "resnet34"
         if kind not in BACKBONE_KINDS:
-            raise EngineError(f"unknown backbone '{kind}' (pose_models_cfg.py:106-118 supports {list(BACKBONE_KINDS)})")
+            raise EngineError(f"unknown backbone '{kind}' (pose_models_cfg.py:106-118 supports {list(BACKBONE_KINDS)} and resnet34_width=N)")
+        self.width = width
         keep = []
         items = []
         for k, v in state_dict.items():
@@ -372,7 +376,7 @@ class Backbone:
         for i, (k, a) in enumerate(items):
             arr[i] = NamedTensor(k, a.ctypes.data, a.size)
         h = C.c_void_p()
-        check(lib.mp_backbone_create_ex(BACKBONE_KINDS[kind], c_in, 0 if head == "pose" else 1, n_out, arr, len(items), precision, C.byref(h)))
+        check(lib.mp_backbone_create_wide(BACKBONE_KINDS[kind], width, c_in, 0 if head == "pose" else 1, n_out, arr, len(items), precision, C.byref(h)))
         self.precision = precision
         self.handle = h
         self.kind, self.c_in, self.n_out = kind, c_in, n_out
@@ -438,8 +442,18 @@ def init_poses_from_boxes(boxes, K, mesh_ids, rot_ids, R, ext) -> torch.Tensor:
     return TCO
 
 
+MV_MODES = {"TCO": 0, "1view_TCO": 0, "TCO+front_3views": 1, "TCO+front_1view": 2, "sphere_26views": 3}
+MV_REMOVE_TCO, MV_INPLANE = 256, 512
+
+
+def multiview_n_views(multiview: int) -> int:
+    return int(_lib.load().mp_pose_multiview_n_views(int(multiview)))
+
+
 def pose_prepare(TCO_in, K, mesh_ids, points, n_pts_main: int, n_pts_views: int, V: int, multiview: int, im_hw, out_hw,
-                 lamb: float = 1.4):
+                 lamb: float = 1.4, with_K_main: bool = False):
+    """-> (TCO_n, tCR, TCV_O [b,V,4,4], KV_crop [b,V,3,3], boxes_rend, boxes_crop[, K_main [b,3,3]]); `multiview` = MV_MODES code
+    | MV_REMOVE_TCO | MV_INPLANE (mp_pose_prepare_ex)."""
     TCO_in, K, points = _dev_f32(TCO_in), _dev_f32(K), _dev_f32(points)
     b = TCO_in.shape[0]
     dev = TCO_in.device
@@ -450,10 +464,13 @@ def pose_prepare(TCO_in, K, mesh_ids, points, n_pts_main: int, n_pts_views: int,
     KV = torch.empty(b, V, 3, 3, **f)
     boxes_rend = torch.empty(b, 4, **f)
     boxes_crop = torch.empty(b, 4, **f)
-    check(_lib.load().mp_pose_prepare(TCO_in.data_ptr(), K.data_ptr(), _dev_i32(mesh_ids).data_ptr(), points.data_ptr(),
-                                      points.shape[1], n_pts_main, n_pts_views, b, V, multiview, im_hw[0], im_hw[1], out_hw[0],
-                                      out_hw[1], lamb, TCO_n.data_ptr(), tCR.data_ptr(), TCV_O.data_ptr(), KV.data_ptr(),
-                                      boxes_rend.data_ptr(), boxes_crop.data_ptr(), _stream()))
+    K_main = torch.empty(b, 3, 3, **f) if with_K_main else None
+    check(_lib.load().mp_pose_prepare_ex(TCO_in.data_ptr(), K.data_ptr(), _dev_i32(mesh_ids).data_ptr(), points.data_ptr(),
+                                         points.shape[1], n_pts_main, n_pts_views, b, V, multiview, im_hw[0], im_hw[1], out_hw[0],
+                                         out_hw[1], lamb, TCO_n.data_ptr(), tCR.data_ptr(), TCV_O.data_ptr(), KV.data_ptr(),
+                                         boxes_rend.data_ptr(), boxes_crop.data_ptr(), _ptr(K_main), _stream()))
+    if with_K_main:
+        return TCO_n, tCR, TCV_O, KV, boxes_rend, boxes_crop, K_main
     return TCO_n, tCR, TCV_O, KV, boxes_rend, boxes_crop
 
 

@@ -157,9 +157,7 @@ def n_inputs_from_cfg(cfg) -> int:
 
 def create_model_pose(cfg, renderer: Panda3dBatchRenderer, mesh_db: BatchedMeshes) -> PosePredictor:
     backbone_str = cfg.backbone_str
-    if "resnet34_width=" in backbone_str:
-        raise NotImplementedError("width-multiplied WideResNets are not part of the released models")
-    backbone = HipBackbone(backbone_str, n_inputs_from_cfg(cfg))
+    backbone = HipBackbone(backbone_str, n_inputs_from_cfg(cfg))   # incl. "resnet34_width=N" (pose_models_cfg.py:114-116)
     return PosePredictor(
         backbone=backbone, renderer=renderer, mesh_db=mesh_db, render_size=(240, 320), n_rendered_views=cfg.n_rendered_views,
         views_inplane_rotations=cfg.views_inplane_rotations, multiview_type=cfg.multiview_type, render_normals=cfg.render_normals,

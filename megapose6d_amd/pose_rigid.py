@@ -50,21 +50,26 @@ class _PreActBlock(nn.Module):  # wide_resnet BasicBlockV2 parameter layout
 
 
 class HipBackbone(nn.Module):
-    """Hosts the weights of vanilla_resnet34 / WideResNet34 / WideResNet18 (pose_models_cfg.py:106-118)."""
+    """Hosts the weights of vanilla_resnet34 / WideResNet34 / WideResNet18 / WideResNet34 x width (pose_models_cfg.py:106-118)."""
 
     def __init__(self, backbone_str: str, n_inputs: int):
         super().__init__()
-        if backbone_str not in eng.BACKBONE_KINDS:
+        width = 1
+        base = backbone_str
+        if backbone_str.startswith("resnet34_width="):   # WideResNet34(width=N): stage widths 64N .. 512N (models/wide_resnet.py:62, :118-121)
+            width, base = int(backbone_str.split("resnet34_width=")[1]), "resnet34"
+        if base not in eng.BACKBONE_KINDS:
             raise ValueError("Unknown backbone", backbone_str)
         self.backbone_str = backbone_str
         self.n_inputs = n_inputs
-        self.n_features = 512
-        wide = backbone_str != "vanilla_resnet34"
-        self.conv1 = nn.Conv2d(n_inputs, 64, 5 if wide else 7, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        counts = [2, 2, 2, 2] if backbone_str == "resnet18" else [3, 4, 6, 3]
-        inplanes = 64
-        for s, (planes, n) in enumerate(zip([64, 128, 256, 512], counts)):
+        self.n_features = 512 * width
+        wide = base != "vanilla_resnet34"
+        widths = [64 * width, 128 * width, 256 * width, 512 * width]
+        self.conv1 = nn.Conv2d(n_inputs, widths[0], 5 if wide else 7, bias=False)
+        self.bn1 = nn.BatchNorm2d(widths[0])
+        counts = [2, 2, 2, 2] if base == "resnet18" else [3, 4, 6, 3]
+        inplanes = widths[0]
+        for s, (planes, n) in enumerate(zip(widths, counts)):
             blocks = []
             for i in range(n):
                 down = i == 0 and (s > 0 or inplanes != planes)
@@ -98,16 +103,22 @@ class PosePredictor(nn.Module):
         depth_normalization_type: Optional[str] = None,
     ):
         super().__init__()
-        if views_inplane_rotations or remove_TCO_rendering:
-            raise NotImplementedError("views_inplane_rotations / remove_TCO_rendering are not used by the released models")
-        if multiview_type in ("front_3views",):
-            multiview_type = "TCO+front_3views"  # pose_models_cfg.py:51-52
+        # legacy names (training/pose_models_cfg.py:49-54)
+        multiview_type = {"front_3views": "TCO+front_3views", "front_1view": "TCO+front_1view"}.get(multiview_type, multiview_type)
+        # The view list is what make_TCO_multiview returns (lib3d/multiview.py:165-246): n_views == 1 -> [TCO] whatever the type;
+        # else [TCO unless remove_TCO_rendering] + the type's camera offsets.  `views_inplane_rotations` is stored but -- exactly as
+        # in the reference -- never reaches make_TCO_multiview from forward() (models/pose_rigid.py:531-537 passes only
+        # remove_TCO_rendering; the 4x in-plane copies are used by the training loss only, megapose_forward_loss.py:115-116).
         if n_rendered_views == 1:
             self._mv_mode = 0
-        elif multiview_type == "TCO+front_3views" and n_rendered_views == 4:
-            self._mv_mode = 1
         else:
-            raise NotImplementedError(f"multiview_type={multiview_type} with {n_rendered_views} views")
+            if multiview_type not in eng.MV_MODES or eng.MV_MODES[multiview_type] == 0:
+                raise ValueError(multiview_type)   # lib3d/multiview.py:233-234 ("TCO+front_5views" is not implemented there either)
+            self._mv_mode = eng.MV_MODES[multiview_type] | (eng.MV_REMOVE_TCO if remove_TCO_rendering else 0)
+            n_list = eng.multiview_n_views(self._mv_mode)
+            if n_list != n_rendered_views:
+                raise ValueError(f"multiview_type={multiview_type} (remove_TCO_rendering={remove_TCO_rendering}) renders {n_list} views, "
+                                 f"the model is configured for {n_rendered_views}")
         self.backbone = backbone
         self.renderer = renderer
         self.mesh_db = mesh_db
@@ -243,8 +254,8 @@ class PosePredictor(nn.Module):
         H, W = images.shape[-2:]
         pts_ids, ren_ids = self._ids(labels, device)
         points = self.mesh_db.sampled_points(2000)
-        TCO_n, tCR, TCV_O, KV_crop, boxes_rend, boxes_crop = eng.pose_prepare(
-            TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode, (H, W), (h, w), 1.4)
+        TCO_n, tCR, TCV_O, KV_crop, boxes_rend, boxes_crop, K_main = eng.pose_prepare(
+            TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode, (H, W), (h, w), 1.4, with_K_main=True)
         x = self._x_buffer(b, device, slot)
         s_row, s_y, s_x, off = self._x_geometry()
         # the observation crop (channels 0..nin-1) is written by the rasteriser launch below (one launch fills the whole CNN input)
@@ -254,11 +265,22 @@ class PosePredictor(nn.Module):
         if events:
             ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
             ev[0].record()
-        view_ids = ren_ids.repeat_interleave(V) if V > 1 else ren_ids
-        self.renderer.render_into(view_ids, TCV_O.view(b * V, 4, 4), KV_crop.view(b * V, 3, 3), self._lights(), (h, w), x, s_row,
-                                  s_y, s_x, nin, nin + 3 if self.render_normals else -1,
-                                  nin + (6 if self.render_normals else 3) if self.render_depth else -1, off,
-                                  views_per_item=V, stride_view=nper, slot=slot, crop=(self._packed(images), im_ids, boxes_crop, 0))
+        # one launch writes at most 32 channels per pixel: the released recipes (<= 4 views) need one; longer view lists
+        # (sphere_26views) go in groups of views, the observation crop rides with the first
+        vg = max(1, (32 - nin) // nper)
+        for v0 in range(0, V, vg):
+            v1 = min(V, v0 + vg)
+            nv = v1 - v0
+            whole = nv == V
+            Tg = TCV_O.view(b * V, 4, 4) if whole else TCV_O[:, v0:v1].reshape(b * nv, 4, 4)
+            Kg = KV_crop.view(b * V, 3, 3) if whole else KV_crop[:, v0:v1].reshape(b * nv, 3, 3)
+            view_ids = ren_ids.repeat_interleave(nv) if nv > 1 else ren_ids
+            c0 = nin + nper * v0
+            self.renderer.render_into(view_ids, Tg, Kg, self._lights(), (h, w), x, s_row, s_y, s_x, c0,
+                                      c0 + 3 if self.render_normals else -1,
+                                      c0 + (6 if self.render_normals else 3) if self.render_depth else -1, off,
+                                      views_per_item=nv, stride_view=nper, slot=slot,
+                                      crop=(self._packed(images), im_ids, boxes_crop, 0) if v0 == 0 else None)
         render_time = time.time() - t0
         if ev is not None:
             ev[1].record()
@@ -278,7 +300,7 @@ class PosePredictor(nn.Module):
         bb.forward(x, b, h, w, out, sig, slot=slot)
         if ev is not None:
             ev[2].record()
-        return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,
+        return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, K_crop=K_main, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,
                     sigmoid=sig, render_time=render_time, events=ev)
 
     @staticmethod
@@ -316,9 +338,9 @@ class PosePredictor(nn.Module):
         nin = self._n_input_channels
         for n in range(n_iterations):
             st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=False, slot=slot, events=cuda_timer)
-            K_crop = st["KV_crop"][:, 0]
+            K_crop = st["K_crop"]   # crop_inputs' intrinsics (== KV_crop[:, 0] unless remove_TCO_rendering)
             if self.predict_pose_update:
-                TCO_output = eng.pose_update(st["TCO_n"], st["KV_crop"], st["out"], st["tCR"], 9 * self.n_rendered_views)
+                TCO_output = eng.pose_update(st["TCO_n"], K_crop, st["out"], st["tCR"], 9)
                 network_outputs = {"pose": st["out"]}
                 renderings_logits = torch.empty(bsz, self.n_rendered_views, dtype=TCO.dtype, device=device)
             else:
@@ -355,7 +377,7 @@ class PosePredictor(nn.Module):
         # CudaTimer.end() (training/utils.py:224-264).  cuda_timer=False: model_time = 0.0 as in the reference, render_time =
         # host time to enqueue the (asynchronous) render launch.
         out = {"logits": st["out"], "scores": st["sigmoid"], "time": 0.0, "render_time": st["render_time"], "model_time": 0.0,
-               "TCO_n": st["TCO_n"], "K_crop": st["KV_crop"][:, 0], "boxes_rend": st["boxes_rend"], "boxes_crop": st["boxes_crop"],
+               "TCO_n": st["TCO_n"], "K_crop": st["K_crop"], "boxes_rend": st["boxes_rend"], "boxes_crop": st["boxes_crop"],
                "events": st["events"]}
         if cuda_timer and not defer_timing:
             torch.cuda.synchronize()

@@ -64,7 +64,7 @@ def wide_resnet_features(sd: Dict[str, torch.Tensor], x: torch.Tensor, prefix="b
 
 
 def net_forward(sd: Dict[str, torch.Tensor], backbone_str: str, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-    feat = vanilla_resnet34_features(sd, x) if backbone_str == "vanilla_resnet34" else wide_resnet_features(sd, x)
+    feat = vanilla_resnet34_features(sd, x) if backbone_str == "vanilla_resnet34" else wide_resnet_features(sd, x)   # (any width: shapes come from sd)
     out = {"features": feat}
     if "pose_fc.weight" in sd:
         out["pose"] = F.linear(feat, sd["pose_fc.weight"], sd["pose_fc.bias"])

@@ -68,6 +68,15 @@ def geometry_vectors(r) -> dict:
     out["so3_72"] = r.tu.load_SO3_grid(72)
     out["so3_576"] = r.tu.load_SO3_grid(576)
     out["mv_TCV_O"] = r.mv.make_TCO_multiview(Tn, Tn[:, :3, 3], multiview_type="TCO+front_3views", n_views=4)
+    # the other view lists of lib3d/multiview.py:197-246 (transforms3d is absent: its euler2mat(0, 0, angle) = Rz(angle) is stubbed)
+    import transforms3d
+
+    transforms3d.euler.euler2mat = lambda ai, aj, ak: np.array([[np.cos(ak), -np.sin(ak), 0], [np.sin(ak), np.cos(ak), 0], [0, 0, 1.0]])
+    out["mv_TCV_O_front1"] = r.mv.make_TCO_multiview(Tn, Tn[:, :3, 3], multiview_type="TCO+front_1view", n_views=2)
+    out["mv_TCV_O_sphere26"] = r.mv.make_TCO_multiview(Tn, Tn[:, :3, 3], multiview_type="sphere_26views", n_views=27)
+    out["mv_TCV_O_front3_noTCO"] = r.mv.make_TCO_multiview(Tn, Tn[:, :3, 3], multiview_type="TCO+front_3views", n_views=3, remove_TCO_rendering=True)
+    out["mv_TCV_O_front3_noTCO_inplane"] = r.mv.make_TCO_multiview(Tn, Tn[:, :3, 3], multiview_type="TCO+front_3views", n_views=12,
+                                                                    remove_TCO_rendering=True, views_inplane_rotations=True)
     from oracle import thirdparty as tp
 
     img = torch.rand(2, 4, 60, 80, generator=g)
@@ -91,12 +100,14 @@ def backbone_vectors(r) -> dict:
     out = {}
     g = torch.Generator().manual_seed(7)
     for kind, c_in, head, n_out in (("vanilla_resnet34", 9, "logits", 1), ("vanilla_resnet34", 27, "pose", 9), ("resnet34", 27, "pose", 9),
-                                    ("resnet18", 9, "logits", 1), ("resnet34", 32, "pose", 9)):
+                                    ("resnet18", 9, "logits", 1), ("resnet34", 32, "pose", 9), ("resnet34_width=2", 9, "logits", 1)):
         sd = syn.make_state_dict(kind, c_in, head, n_out, seed=1)
         if kind == "vanilla_resnet34":
             m = r.tvr.resnet34(num_classes=512, n_input_channels=c_in)
         elif kind == "resnet34":
             m = r.wr.WideResNet34(n_inputs=c_in)
+        elif kind.startswith("resnet34_width="):   # training/pose_models_cfg.py:114-116
+            m = r.wr.WideResNet34(n_inputs=c_in, width=int(kind.split("resnet34_width=")[1]))
         else:
             m = r.wr.WideResNet18(n_inputs=c_in)
         bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}

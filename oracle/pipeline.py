@@ -99,12 +99,14 @@ class OraclePosePredictor:
             images = images[:, :3]
         TCO_n = og.normalize_T(TCO_in)
         tCR = TCO_n[:, :3, 3].clone()
-        TCV_O = og.make_TCO_multiview(TCO_n, tCR, self.cfg.multiview_type, self.V)
+        remove = bool(getattr(self.cfg, "remove_TCO_rendering", False))
+        TCV_O = og.make_TCO_multiview(TCO_n, tCR, self.cfg.multiview_type, self.V, remove_TCO_rendering=remove)
         tCV_R = TCV_O[..., :3, 3]
         crops, K_crop, boxes_rend, boxes_crop = self.crop_inputs(images, im_ids, K, TCO_n, tCR, labels)
         if self.V > 1:
             KV = self.crops_multiview(tuple(images.shape[-2:]), K, TCV_O, tCV_R, labels)
-            KV[:, 0] = K_crop
+            if not remove:   # models/pose_rigid.py:551-552
+                KV[:, 0] = K_crop
         else:
             KV = K_crop.unsqueeze(1)
         renders = self.render_multiview(labels, TCV_O, KV)

@@ -227,6 +227,7 @@ def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: i
     sd: Dict[str, torch.Tensor] = {}
     B = "backbone."
     stages = [64, 128, 256, 512]
+    n_feat = 512
     if backbone_str == "vanilla_resnet34":
         sd[B + "conv1.weight"] = _conv_w(g, 64, c_in, 7)
         _bn(sd, g, B + "bn1", 64)
@@ -245,11 +246,14 @@ def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: i
                     _bn(sd, g, P + "downsample.1", planes)
                 inpl = planes
         _linear(sd, g, B + "fc", 512, 512)
-    elif backbone_str in ("resnet34", "resnet18"):
-        sd[B + "conv1.weight"] = _conv_w(g, 64, c_in, 5)
-        _bn(sd, g, B + "bn1", 64)
-        inpl = 64
-        for s, (planes, nb) in enumerate(zip(stages, [3, 4, 6, 3] if backbone_str == "resnet34" else [2, 2, 2, 2])):
+    elif backbone_str in ("resnet34", "resnet18") or backbone_str.startswith("resnet34_width="):
+        if backbone_str.startswith("resnet34_width="):   # WideResNet34(width=N), models/wide_resnet.py:62
+            stages = [c * int(backbone_str.split("=")[1]) for c in stages]
+        n_feat = stages[3]
+        sd[B + "conv1.weight"] = _conv_w(g, stages[0], c_in, 5)
+        _bn(sd, g, B + "bn1", stages[0])
+        inpl = stages[0]
+        for s, (planes, nb) in enumerate(zip(stages, [2, 2, 2, 2] if backbone_str == "resnet18" else [3, 4, 6, 3])):
             for i in range(nb):
                 P = f"{B}layer{s + 1}.{i}."
                 stride = 2 if (i == 0 and s > 0) else 1
@@ -263,10 +267,10 @@ def make_state_dict(backbone_str: str, c_in: int, head: str, n_out: int, seed: i
     else:
         raise ValueError(backbone_str)
     if head == "pose":
-        _linear(sd, g, "pose_fc", 9, 512, scale=pose_head_scale)
+        _linear(sd, g, "pose_fc", 9, n_feat, scale=pose_head_scale)
         sd["pose_fc.bias"] = sd["pose_fc.bias"] + torch.tensor([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0])
     else:
-        _linear(sd, g, "views_logits_head", n_out, 512, scale=LOGIT_HEAD_SCALE)
+        _linear(sd, g, "views_logits_head", n_out, n_feat, scale=LOGIT_HEAD_SCALE)
     return sd
 
 

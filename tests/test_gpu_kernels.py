@@ -229,7 +229,7 @@ def test_maxpool_and_tail(eng):
 
 @pytest.mark.parametrize("kind,c_in,head,n_out", [("vanilla_resnet34", 9, "logits", 1), ("vanilla_resnet34", 27, "pose", 9),
                                                   ("resnet34", 27, "pose", 9), ("resnet18", 9, "logits", 1),
-                                                  ("vanilla_resnet34", 32, "pose", 9)])
+                                                  ("vanilla_resnet34", 32, "pose", 9), ("resnet34_width=2", 9, "logits", 1)])
 def test_backbone_matches_oracle(eng, kind, c_in, head, n_out):
     from tests.support import synthetic as syn
     from oracle import backbones as ob
@@ -241,7 +241,7 @@ def test_backbone_matches_oracle(eng, kind, c_in, head, n_out):
     x = torch.rand(b, c_in, h, w, generator=g)
     xb = _to_padded(eng, x, bb.c_in_p, bb.in_border)
     out = torch.empty(b, n_out, device="cuda")
-    feat = torch.empty(b, 512, device="cuda")
+    feat = torch.empty(b, 512 * getattr(bb, "width", 1), device="cuda")
     bb.forward(xb, b, h, w, out, None, feat)
     # run twice: the second call must reuse the workspace (no re-zeroing) and give identical results
     out2 = torch.empty_like(out)
@@ -354,6 +354,87 @@ def test_crop_roi_align_vs_oracle(eng, C):
     assert torch.all(out[..., 0] == 0)
 
 
+MV_CASES = [("TCO+front_1view", False, False), ("sphere_26views", False, False), ("TCO+front_3views", True, False),
+            ("TCO+front_1view", True, False), ("TCO+front_3views", True, True), ("sphere_26views", True, True)]
+
+
+@pytest.mark.parametrize("mvt,remove,inplane", MV_CASES)
+def test_pose_prepare_every_multiview_mode_vs_oracle(eng, engine_meshes, mvt, remove, inplane):
+    """mp_pose_prepare_ex for the view lists of lib3d/multiview.py:197-246 beyond the released recipe: cameras vs the oracle restatement
+    (itself pinned to the reference function's outputs, tests/test_oracle_golden.py), per-view crop intrinsics from 200 points, and the
+    main crop (K_crop / boxes of crop_inputs, 2000 points) whether or not the TCO view is in the list (models/pose_rigid.py:540-552)."""
+    from tests.support import synthetic as syn
+    from oracle import geometry as og
+
+    rng = np.random.RandomState(13)
+    b = 5
+    pts = og.pad_stack_points([torch.from_numpy(m["points"]) for m in engine_meshes])
+    pts_s = pts[:, og.sample_point_ids(pts.shape[1], 2000)]
+    mesh_ids = torch.tensor(rng.randint(0, 3, size=b), dtype=torch.int32)
+    T = torch.from_numpy(np.stack([syn.random_pose(rng) for _ in range(b)]))
+    K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None], b, 0)).float()
+    code = eng.MV_MODES[mvt] | (eng.MV_REMOVE_TCO if remove else 0) | (eng.MV_INPLANE if inplane else 0)
+    V = eng.multiview_n_views(code)
+    TCO_n, tCR, TCV, KV, brend, bcrop, K_main = [t.cpu() for t in eng.pose_prepare(T.cuda(), K.cuda(), mesh_ids.cuda(), pts_s.cuda(), 2000, 200, V, code,
+                                                                                     (480, 640), (240, 320), with_K_main=True)]
+    Tn = og.normalize_T(T)
+    tcr = Tn[:, :3, 3]
+    TV = og.make_TCO_multiview(Tn, tcr, mvt, V, remove_TCO_rendering=remove, views_inplane_rotations=inplane)
+    assert TV.shape == TCV.shape and (TCV - TV).abs().max() < 3e-6
+    P = pts_s[mesh_ids.long()]
+    br = og.boxes_from_uv(og.project_points_robust(P, K, Tn))
+    bc = og.crop_boxes_robust(br, K, Tn, tcr, P, (480, 640))
+    Kc = og.get_K_crop_resize(K, bc, (240, 320))
+    assert (brend - br).abs().max() < 2e-3 and (bcrop - bc).abs().max() < 2e-3
+    assert ((K_main - Kc).abs() / Kc.abs().clamp(min=1.0)).max() < 1e-4
+    Pv = P[:, :200].unsqueeze(1).repeat(1, V, 1, 1).flatten(0, 1)
+    TVf, Kf = TV.flatten(0, 1), K.unsqueeze(1).repeat(1, V, 1, 1).flatten(0, 1)
+    bcv = og.crop_boxes_robust(og.boxes_from_uv(og.project_points_robust(Pv, Kf, TVf)), Kf, TVf, TVf[:, :3, 3], Pv, (480, 640))
+    Kcv = og.get_K_crop_resize(Kf, bcv, (240, 320)).view(b, V, 3, 3)
+    if not remove:
+        Kcv[:, 0] = Kc
+    assert ((KV - Kcv).abs() / Kcv.abs().clamp(min=1.0)).max() < 2e-4
+
+
+@pytest.mark.parametrize("mvt,remove", [("TCO+front_1view", False), ("TCO+front_3views", True), ("sphere_26views", False)])
+def test_pose_predictor_forward_other_multiview_modes_vs_oracle(engine_meshes, object_dataset, mvt, remove):
+    """PosePredictor.forward with the view lists the released recipes do not use (2 / 3 / 27 rendered views; the 27-view input needs
+    several rasteriser launches per step): raw network output and updated pose against the oracle predictor, 2 iterations."""
+    from types import SimpleNamespace
+
+    from megapose6d_amd import engine as eng
+    from megapose6d_amd.load_model import build_pose_model
+    from megapose6d_amd.mesh_db import MeshDataBase
+    from megapose6d_amd.renderer import Panda3dBatchRenderer
+    from oracle import pipeline as op
+    from oracle import raster as orr
+    from tests.support import synthetic as syn
+
+    code = eng.MV_MODES[mvt] | (eng.MV_REMOVE_TCO if remove else 0)
+    V = eng.multiview_n_views(code)
+    cfg = syn.make_cfg("refiner")
+    cfg.multiview_type, cfg.n_rendered_views, cfg.remove_TCO_rendering = mvt, V, remove
+    sd = syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), "pose", 9, seed=21)
+    renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
+    db = MeshDataBase.from_object_ds(object_dataset).batched()
+    model = build_pose_model(cfg, sd, renderer, db.cuda())
+    labels = [object_dataset[0].label, object_dataset[1].label]
+    rng = np.random.RandomState(4)
+    T0 = torch.from_numpy(np.stack([syn.random_pose(rng, (0.45, 0.6), 0.1) for _ in labels]))
+    K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None], 2, 0)).float()
+    images = torch.rand(2, 3, 480, 640, generator=torch.Generator().manual_seed(2))
+    images = torch.round(images * 255) / 255
+    meshes = {o.label: m for o, m in zip(object_dataset.list_objects, engine_meshes)}
+    opred = op.OraclePosePredictor(cfg, sd, db.labels.tolist(), db.points, orr.OracleBatchRenderer(meshes))
+    ref = opred.forward(images, torch.arange(2), K, labels, T0, 2)
+    got = model(images=images.cuda(), K=K.cuda(), labels=labels, TCO=T0.cuda(), n_iterations=2)
+    for n in range(2):
+        o = got[f"iteration={n + 1}"]
+        assert (o.network_outputs["pose"].cpu() - ref[n]["net"]["pose"]).abs().max().item() < 1e-4, n
+        assert (o.TCO_output.cpu() - ref[n]["TCO_output"]).abs().max().item() < 1e-4, n
+        assert (o.KV_crop.cpu() - ref[n]["KV_crop"]).abs().div(ref[n]["KV_crop"].abs().clamp(min=1)).max().item() < 2e-4
+
+
 def test_pose_ops_vs_oracle(eng, engine_meshes):
     from tests.support import synthetic as syn
     from oracle import geometry as og
@@ -449,7 +530,7 @@ def test_backbone_bf16x9_matches_oracle(eng):
     x = torch.rand(b, 27, h, w, generator=torch.Generator().manual_seed(0))
     xb = _to_padded(eng, x, bb.c_in_p, bb.in_border)
     out = torch.empty(b, 9, device="cuda")
-    feat = torch.empty(b, 512, device="cuda")
+    feat = torch.empty(b, 512 * getattr(bb, "width", 1), device="cuda")
     bb.forward(xb, b, h, w, out, None, feat)
     torch.cuda.synchronize()
     ref = ob.net_forward(sd, "vanilla_resnet34", x)

@@ -48,6 +48,12 @@ def test_geometry_against_reference_outputs(geo):
     assert torch.equal(ps, t(geo["pad_stack"]))
     mv = og.make_TCO_multiview(Tn, Tn[:, :3, 3], "TCO+front_3views", 4)
     assert (mv - t(geo["mv_TCV_O"])).abs().max() < 1e-6
+    # the other view lists of lib3d/multiview.py:197-246, as the reference function returned them
+    for key, args in {"mv_TCV_O_front1": ("TCO+front_1view", 2, False, False), "mv_TCV_O_sphere26": ("sphere_26views", 27, False, False),
+                      "mv_TCV_O_front3_noTCO": ("TCO+front_3views", 3, True, False),
+                      "mv_TCV_O_front3_noTCO_inplane": ("TCO+front_3views", 12, True, True)}.items():
+        mv = og.make_TCO_multiview(Tn, Tn[:, :3, 3], *args)
+        assert mv.shape == t(geo[key]).shape and (mv - t(geo[key])).abs().max() < 1e-6, key
 
 
 def test_so3_grid_matches_reference(geo):
