@@ -231,6 +231,48 @@ def extras(est, obs, det, steps: int) -> dict:
                 "note": "Detector front-end: DetectorMaskRCNN (ResNet-50 + FPN Mask R-CNN, 22 classes, masks included) on one 640x480 frame, "
                         "one native call per frame (mp_detector_forward) + the host read of the detection count; informational"}
     guarded("detector_front_end", detector_line)
+    def other_workload(cfg_id: int, backbone: str, k_hyp: int, note: str):
+        """a second, driver-visible line on another BASELINE configuration / backbone: own estimator, 1 warm-up + 2 timed calls, with the
+        dominant conv kernel's rate from the in-library event profiler (never `value`)"""
+        import shutil
+        import tempfile
+
+        from megapose6d_amd import engine as eng_
+
+        tmp2 = tempfile.mkdtemp(prefix="mp_bench_extra_")
+        try:
+            est2, obs2, det2, _, desc2, n_obj2, run2 = build_workload(cfg_id, 1, backbone, tmp2, 0, k_hyp)
+            est2.run_inference_pipeline(obs2, detections=det2, **run2)
+            torch.cuda.synchronize()
+            eng_.profile_begin()
+            eng_.conv_wino_stats(reset=True)
+            n_t = 2
+            t0 = time.perf_counter()
+            for _ in range(n_t):
+                est2.run_inference_pipeline(obs2, detections=det2, **run2)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n_t
+            prof2 = eng_.profile_end()
+            wd, we = eng_.conv_wino_stats(reset=True)
+            conv2 = {k: v for k, v in prof2.items() if k.startswith("conv_nhwc_f32") or k.startswith("conv3x3_wino")}
+            dom = max(conv2, key=lambda k: conv2[k]["ms"])
+            rast = sum(v["ms"] for k, v in prof2.items() if k.startswith("raster_")) / n_t
+            line = {"workload": desc2, "ms_per_call": dt * 1e3, "pose_hypotheses_per_s": n_obj2 * N_HYP / dt, "dominant_conv_kernel": dom,
+                    "dominant_conv_tflops_algorithmic": conv2[dom]["flops"] / (conv2[dom]["ms"] * 1e-3) / 1e12,
+                    "all_conv_kernels_tflops_algorithmic": sum(v["flops"] for v in conv2.values()) / (sum(v["ms"] for v in conv2.values()) * 1e-3) / 1e12,
+                    "winograd_executed_over_algorithmic": (we / wd) if wd else None, "raster_ms_per_call": rast, "note": note}
+            del est2, obs2, det2
+            torch.cuda.empty_cache()
+            return line
+        finally:
+            shutil.rmtree(tmp2, ignore_errors=True)
+
+    guarded("released_recipe_64_detections_K5", lambda: other_workload(
+        4, "vanilla_resnet34", 5, "BASELINE configs[3] on one GPU with the RELEASED inference parameters (n_pose_hypotheses = 5, utils/load_model.py:31-34): "
+        "64 detections over 8 frames, 36 864 coarse rows + 320 x 5 refiner rows + 320 score rows per call"))
+    guarded("wide_resnet34_backbone", lambda: other_workload(
+        2, "resnet34", N_HYP, "the `value` workload on the OTHER backbone the reference can ship (backbone_str 'resnet34' = WideResNet-34, "
+        "training/pose_models_cfg.py:110-111; the released config.yaml is not available offline to tell which one it is)"))
     for prec in (9, 6):
         def split(prec=prec):
             for m in (est.coarse_model, est.refiner_model):
@@ -460,7 +502,7 @@ def main():
             # one all-gather per stage (coarse | refiner, all iterations packed | scoring); config 5 adds none (ICP shards by object)
             assert abs(out["rccl"]["all_gathers_per_step"] - 3.0) < 1e-9, out["rccl"]
         if world == 1 and a.config == 2 and not a.no_extras:
-            out["extras"] = extras(est, obs, det, a.steps)
+            out["extras"] = extras(est, obs, det, min(a.steps, 3))   # (secondary lines: at most 3 timed calls each)
         if world == 1 and a.config == 5 and not a.no_extras:   # the "fp16 renders" variant BASELINE.json names for this configuration
             try:
                 est.render_dtype = torch.float16

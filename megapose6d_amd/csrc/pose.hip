@@ -348,14 +348,17 @@ extern "C" int mp_pose_prepare_ex(const float* d_TCO_in, const float* d_K, const
                                   float* d_KV_crop, float* d_boxes_rend, float* d_boxes_crop, float* d_K_main, mp_stream stream) {
   MP_REQUIRE(d_TCO_in && d_K && d_mesh_ids && d_points && d_TCO_n && d_tCR && d_TCV_O && d_KV_crop && d_boxes_rend && d_boxes_crop,
              "mp_pose_prepare: null pointer");
-  const int v_need = mp_pose_multiview_n_views(multiview);
+  int v_need = mp_pose_multiview_n_views(multiview);
+  // one view: make_TCO_multiview returns [TCO] whatever the type (lib3d/multiview.py:186-193); remove_TCO_rendering still decides
+  // whether that view's intrinsics are crop_inputs' K_crop or the 200-point multiview crop (models/pose_rigid.py:550-552)
+  if (v_need == 1) multiview &= MP_MV_REMOVE_TCO;
   MP_REQUIRE(v_need > 0 && (multiview & ~(255 | MP_MV_REMOVE_TCO | MP_MV_INPLANE)) == 0, "mp_pose_prepare: unknown multiview code 0x%x", multiview);
   MP_REQUIRE(V == v_need, "mp_pose_prepare: multiview 0x%x has %d views, got V=%d", multiview, v_need, V);
   MP_REQUIRE(!(multiview & MP_MV_INPLANE) || (multiview & MP_MV_REMOVE_TCO), "mp_pose_prepare: views_inplane_rotations needs remove_TCO_rendering "
              "(lib3d/multiview.py:237)");
   MP_REQUIRE(n_pts_main <= n_pts_stride && n_pts_views <= n_pts_stride && n_pts_main > 0, "mp_pose_prepare: bad point counts");
   if (b == 0) return MP_OK;
-  const bool extra = (multiview & 255) != 0 && (multiview & MP_MV_REMOVE_TCO);   // the TCO view is not rendered: one more unit for the main crop
+  const bool extra = (multiview & MP_MV_REMOVE_TCO) != 0;   // no view carries crop_inputs' 2000-point crop: one more unit computes it
   ProfScope prof("pose_prepare", 0.0, (double)b * (12.0 * n_pts_main + (V - 1) * 12.0 * n_pts_views), (hipStream_t)stream);
   hipLaunchKernelGGL(pose_prepare_kernel, dim3(b, V + (extra ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, d_TCO_in, d_K, d_mesh_ids, d_points,
                      n_pts_stride, n_pts_main, n_pts_views, V, multiview, im_h, im_w, out_h, out_w, lamb, d_TCO_n, d_tCR, d_TCV_O,

@@ -110,7 +110,9 @@ class PosePredictor(nn.Module):
         # in the reference -- never reaches make_TCO_multiview from forward() (models/pose_rigid.py:531-537 passes only
         # remove_TCO_rendering; the 4x in-plane copies are used by the training loss only, megapose_forward_loss.py:115-116).
         if n_rendered_views == 1:
-            self._mv_mode = 0
+            # (forward() of a one-view model with remove_TCO_rendering -- the released COARSE recipe, run_megapose_training.py:131-142 --
+            #  renders with the 200-point multiview crop camera, pose_rigid.py:550-552; forward_coarse, the hot path, never does)
+            self._mv_mode = eng.MV_REMOVE_TCO if remove_TCO_rendering else 0
         else:
             if multiview_type not in eng.MV_MODES or eng.MV_MODES[multiview_type] == 0:
                 raise ValueError(multiview_type)   # lib3d/multiview.py:233-234 ("TCO+front_5views" is not implemented there either)
@@ -241,7 +243,7 @@ class PosePredictor(nn.Module):
 
     # -- the fused step ------------------------------------------------------------------------------------------
     def _step(self, images: torch.Tensor, im_ids: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO_in: torch.Tensor,
-              want_sigmoid: bool, slot: int = 0, events: bool = False):
+              want_sigmoid: bool, slot: int = 0, events: bool = False, mv_mode: Optional[int] = None):
         """images [n_im,C,H,W] (C already trimmed to the model's input channels), im_ids [b] row -> image.
         Returns dict of device tensors; the CNN input stays in self._x.
         `events=True` records three HIP events on the launch stream (before the render+crop launch, after it, after the
@@ -255,7 +257,7 @@ class PosePredictor(nn.Module):
         pts_ids, ren_ids = self._ids(labels, device)
         points = self.mesh_db.sampled_points(2000)
         TCO_n, tCR, TCV_O, KV_crop, boxes_rend, boxes_crop, K_main = eng.pose_prepare(
-            TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode, (H, W), (h, w), 1.4, with_K_main=True)
+            TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode if mv_mode is None else mv_mode, (H, W), (h, w), 1.4, with_K_main=True)
         x = self._x_buffer(b, device, slot)
         s_row, s_y, s_x, off = self._x_geometry()
         # the observation crop (channels 0..nin-1) is written by the rasteriser launch below (one launch fills the whole CNN input)
@@ -371,7 +373,7 @@ class PosePredictor(nn.Module):
         if im_ids is None:
             assert images.shape[0] == bsz
             im_ids = torch.arange(bsz, dtype=torch.int32, device=TCO_input.device)
-        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True, slot=slot, events=cuda_timer)
+        st = self._step(images, im_ids, K, labels, TCO_input, want_sigmoid=True, slot=slot, events=cuda_timer, mv_mode=0)   # forward_coarse: KV_crop = K_crop (pose_rigid.py:683-685)
         # cuda_timer=True: `events` lets the caller resolve DEVICE render / model times once per stage (PoseEstimator does, after
         # its single synchronisation); a direct caller gets them here at the price of a synchronise, like the reference's
         # CudaTimer.end() (training/utils.py:224-264).  cuda_timer=False: model_time = 0.0 as in the reference, render_time =

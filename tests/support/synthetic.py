@@ -279,9 +279,10 @@ def make_cfg(role: str, backbone_str: str = "vanilla_resnet34", rgbd: bool = Fal
     recipes (scripts/run_megapose_training.py:120-153): refiner = 4 views TCO+front_3views + normals;
     coarse = 1 view, logits head, no pose head."""
     if role == "coarse":
-        return SimpleNamespace(backbone_str=backbone_str, n_rendered_views=1, multiview_type="TCO", views_inplane_rotations=False,
+        # (make_coarse_cfg, scripts/run_megapose_training.py:131-142: one view, "1view_TCO", remove_TCO_rendering = True)
+        return SimpleNamespace(backbone_str=backbone_str, n_rendered_views=1, multiview_type="1view_TCO", views_inplane_rotations=False,
                                render_normals=True, render_depth=False, input_depth=False, predict_rendered_views_logits=True,
-                               remove_TCO_rendering=False, predict_pose_update=False, depth_normalization_type="tCR_scale_clamp_center",
+                               remove_TCO_rendering=True, predict_pose_update=False, depth_normalization_type="tCR_scale_clamp_center",
                                depth_augmentation=False, renderer="panda3d")
     return SimpleNamespace(backbone_str=backbone_str, n_rendered_views=4, multiview_type="TCO+front_3views", views_inplane_rotations=False,
                            render_normals=True, render_depth=rgbd, input_depth=rgbd, predict_rendered_views_logits=False,

@@ -416,8 +416,8 @@ def test_pose_predictor_forward_other_multiview_modes_vs_oracle(engine_meshes, o
     cfg.multiview_type, cfg.n_rendered_views, cfg.remove_TCO_rendering = mvt, V, remove
     sd = syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), "pose", 9, seed=21)
     renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
-    db = MeshDataBase.from_object_ds(object_dataset).batched()
-    model = build_pose_model(cfg, sd, renderer, db.cuda())
+    db = MeshDataBase.from_object_ds(object_dataset).batched()   # (CPU copy for the oracle; .cuda() moves a database in place)
+    model = build_pose_model(cfg, sd, renderer, MeshDataBase.from_object_ds(object_dataset).batched().cuda())
     labels = [object_dataset[0].label, object_dataset[1].label]
     rng = np.random.RandomState(4)
     T0 = torch.from_numpy(np.stack([syn.random_pose(rng, (0.45, 0.6), 0.1) for _ in labels]))
