@@ -357,6 +357,20 @@ int mp_icp_refine(const float* d_depth_meas, int n_images, const int32_t* d_im_i
                   int n_iterations, int n_levels, float tolerance, int n_min_points, int user_masks, float* d_TCO_out,
                   int32_t* d_retval, float* d_residual, void* d_workspace, size_t workspace_bytes, mp_stream stream);
 
+/* The same refiner with the REFERENCE's algorithm, step for step (csrc/icp_nn.hip): get_normal (hole fill, Gaussian sigma 2, gradient,
+ * inference/icp_refiner.py:37-95), getXYZ, masks / 1000-point rule, centroid pre-shift, and OpenCV's ppf_match_3d ICP as restated in
+ * oracle/icp_opencv.py (mean / scale normalisation, 4 levels, exact nearest neighbours, median + 2.5 MAD rejection, one-to-one filter,
+ * linearised point-to-plane solve, relative-change stop).  Arguments as mp_icp_refine (n_iterations = 100, n_levels = 4, tolerance = 0.05
+ * are the reference's) except d_masks: the caller's per-frame masks [n_images][H][W] uint8 (icp_refiner.py:249-250: they replace the
+ * threshold mask and only select points -- the measured depth is passed unmasked, its normals come from the whole frame) or NULL; d_iters (optional, [n_rows][8] int32) receives the iterations run per level.  At most
+ * mp_icp_nn_max_points() mask pixels per object (more -> that object is rejected, retval -1). */
+int mp_icp_nn_max_points(void);
+size_t mp_icp_nn_workspace_bytes(int n_images, int n_rows, int H, int W);
+int mp_icp_refine_nn(const float* d_depth_meas, int n_images, const int32_t* d_im_ids, const float* d_depth_rend, const float* d_K_images,
+                     const float* d_K_rows, const float* d_TCO, int n_rows, int H, int W, int n_iterations, int n_levels, float tolerance,
+                     int n_min_points, const unsigned char* d_masks, float* d_TCO_out, int32_t* d_retval, float* d_residual, int32_t* d_iters,
+                     void* d_ws, size_t ws_bytes, mp_stream stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Detector network: replaces the torchvision Mask R-CNN    */
 /* behind `self.model([image_n ...])` in inference/detector.py:92                          */

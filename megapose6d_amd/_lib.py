@@ -139,6 +139,9 @@ SIGNATURES = {
     "mp_pose_prepare_ex": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_icp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mp_icp_refine": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_icp_nn_max_points": (_i, []),
+    "mp_icp_nn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mp_icp_refine_nn": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_pose_update": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "mp_detector_default_config": (_i, [C.POINTER(DetectorConfig), _i, _i, _i]),
     "mp_detector_state_spec": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_int32)]),

@@ -485,9 +485,12 @@ def pose_update(TCO, K_crop, out9, tCR, k_stride_floats: int = 9) -> torch.Tenso
 
 def icp_refine(depth_meas: torch.Tensor, im_ids: torch.Tensor, depth_rend: torch.Tensor, K_images: torch.Tensor, K_rows: torch.Tensor,
                TCO: torch.Tensor, n_iterations: int = 100, n_levels: int = 4, tolerance: float = 0.05, n_min_points: int = 1000,
-               user_masks: bool = False):
+               user_masks: bool = False, association: str = "nn", return_iters: bool = False, masks: Optional[torch.Tensor] = None):
     """-> (TCO_refined [N,4,4], retval [N] int32 (0 ok / -1 input pose kept), residual [N]).  `user_masks`: the caller's masks
-    are already applied to depth_meas; the 0.1 m measured-vs-rendered threshold mask is then not used (icp_refiner.py:249-250)."""
+    are already applied to depth_meas; the 0.1 m measured-vs-rendered threshold mask is then not used (icp_refiner.py:249-250).
+    association: "nn" = the reference's algorithm step for step (mp_icp_refine_nn: get_normal + OpenCV-style nearest-neighbour ICP);
+    "projective" = the faster projective-association point-to-plane ICP (mp_icp_refine).  `masks` ("nn" only): the caller's per-frame
+    masks [n_images,H,W], passed separately (depth_meas stays unmasked: the reference takes its normals from the whole frame)."""
     lib = _lib.load()
     depth_meas, depth_rend = _dev_f32(depth_meas), _dev_f32(depth_rend)
     K_images, K_rows, TCO = _dev_f32(K_images), _dev_f32(K_rows), _dev_f32(TCO)
@@ -498,6 +501,22 @@ def icp_refine(depth_meas: torch.Tensor, im_ids: torch.Tensor, depth_rend: torch
     out = torch.empty_like(TCO)
     retval = torch.empty(N, dtype=torch.int32, device=dev)
     residual = torch.empty(N, dtype=torch.float32, device=dev)
+    if association == "nn":
+        if user_masks:
+            raise ValueError('association="nn" takes the caller\'s masks through `masks`, not pre-multiplied into the depth')
+        if masks is not None:
+            masks = (masks.to(dev) > 0).to(torch.uint8).contiguous()
+            assert masks.shape == depth_meas.shape
+        ws = torch.empty(lib.mp_icp_nn_workspace_bytes(n_im, N, H, W), dtype=torch.uint8, device=dev)
+        iters = torch.zeros(N, 8, dtype=torch.int32, device=dev) if return_iters else None
+        check(lib.mp_icp_refine_nn(depth_meas.data_ptr(), n_im, _dev_i32(im_ids).data_ptr(), depth_rend.data_ptr(), K_images.data_ptr(),
+                                   K_rows.data_ptr(), TCO.data_ptr(), N, H, W, n_iterations, n_levels, tolerance, n_min_points, _ptr(masks),
+                                   out.data_ptr(), retval.data_ptr(), residual.data_ptr(), _ptr(iters), ws.data_ptr(), ws.numel(), _stream()))
+        return (out, retval, residual, iters) if return_iters else (out, retval, residual)
+    if association != "projective":
+        raise ValueError(f"association must be 'nn' or 'projective', got {association!r}")
+    if masks is not None:
+        raise ValueError('association="projective" takes masks pre-multiplied into depth_meas (user_masks=True)')
     ws = torch.empty(lib.mp_icp_workspace_bytes(n_im, N, H, W), dtype=torch.uint8, device=dev)
     check(lib.mp_icp_refine(depth_meas.data_ptr(), n_im, _dev_i32(im_ids).data_ptr(), depth_rend.data_ptr(), K_images.data_ptr(),
                             K_rows.data_ptr(), TCO.data_ptr(), N, H, W, n_iterations, n_levels, tolerance, n_min_points, int(user_masks), out.data_ptr(),

@@ -14,8 +14,9 @@ calls restated from their published sources, because neither package is installe
   reproduced; holes are filled by an onion-peel mean of valid 8-neighbours (same role: no zero-depth cliffs under the Gaussian).
   `scipy.ndimage.gaussian_filter(., 2)` and `np.gradient(., 2, edge_order=2)` are the reference's own calls.
 
-TEST INFRASTRUCTURE ONLY: tests compare the engine's on-device refiner (csrc/icp.hip, a projective-association point-to-plane ICP)
-with this restatement on synthetic scenes and state the bounds within which the two agree."""
+TEST INFRASTRUCTURE ONLY: tests compare the engine's on-device refiners with this restatement on synthetic scenes -- csrc/icp_nn.hip
+(the default: this algorithm step for step, in the same arithmetic; measured bit-identical poses) and csrc/icp.hip (the optional
+projective-association point-to-plane ICP; the tests state the bounds within which it agrees)."""
 from __future__ import annotations
 
 import numpy as np
@@ -133,8 +134,9 @@ def _point_to_plane(src: np.ndarray, dst: np.ndarray):
 
 
 def opencv_icp(src_pc: np.ndarray, dst_pc: np.ndarray, iterations: int = 100, tolerance: float = 0.05, rejection_scale: float = 2.5,
-               num_levels: int = 4):
-    """registerModelToScene(srcPC [n,6], dstPC [m,6]) -> (retval 0, residual, pose 4x4 mapping src onto dst)"""
+               num_levels: int = 4, info: dict | None = None):
+    """registerModelToScene(srcPC [n,6], dstPC [m,6]) -> (retval 0, residual, pose 4x4 mapping src onto dst).
+    `info` (optional dict) receives telemetry: 'iters' = iterations run per level (index = level)."""
     n = src_pc.shape[0]
     src = src_pc.astype(np.float32).copy()
     dst = dst_pc.astype(np.float32).copy()
@@ -191,6 +193,8 @@ def opencv_icp(src_pc: np.ndarray, dst_pc: np.ndarray, iterations: int = 100, to
             i += 1
         pose = pose_x @ pose
         residual = fval_min
+        if info is not None:
+            info.setdefault("iters", [0] * num_levels)[level] = i
     R, c = pose[:3, :3], pose[:3, 3]
     c = c / scale + mean_avg - R @ mean_avg
     out = np.eye(4)
@@ -206,9 +210,12 @@ def compute_masks_threshold(depth_rendered: np.ndarray, depth_measured: np.ndarr
     return mask_measured
 
 
-def icp_refinement(depth_measured, depth_rendered, object_mask_measured, cam_K, TCO_pred, n_min_points=1000):
+def icp_refinement(depth_measured, depth_rendered, object_mask_measured, cam_K, TCO_pred, n_min_points=1000, info=None):
     """icp_refiner.py:128-175 -> (TCO_refined, retval, residual); retval -1 = rejected (the caller keeps the input pose)"""
-    fx, fy, cx, cy = float(cam_K[0, 0]), float(cam_K[1, 1]), float(cam_K[0, 2]), float(cam_K[1, 2])
+    # the reference hands numpy SCALARS of the float32 intrinsics to getXYZ / get_normal (:135-150), not python floats: `1 / fx` and every
+    # product of the int16 offset table with it are then float32 operations (under numpy 1.x value-based casting and NEP 50 alike)
+    cam_K = np.asarray(cam_K, dtype=np.float32)
+    fx, fy, cx, cy = cam_K[0, 0], cam_K[1, 1], cam_K[0, 2], cam_K[1, 2]
     H, W = depth_measured.shape
     pts_tgt = np.zeros((H, W, 6), np.float32)
     pts_tgt[:, :, :3] = get_xyz(depth_measured, fx, fy, cx, cy)
@@ -222,12 +229,13 @@ def icp_refinement(depth_measured, depth_rendered, object_mask_measured, cam_K, 
     pts_src = pts_src[np.logical_and(depth_valid, depth_rendered > 0)]
     if len(pts_tgt) < n_min_points or len(pts_src) < n_min_points:
         return TCO_pred.copy(), -1, -1.0
-    T = TCO_pred.astype(np.float64).copy()
+    T = np.asarray(TCO_pred, dtype=np.float32).copy()                  # (the reference's pose is a float32 array; += stays float32)
+    # np.mean over axis 0 of a float32 [n, 3] view: a SEQUENTIAL float32 accumulation (pairwise summation only runs along the fast axis)
     shift = pts_tgt[:, :3].mean(0) - pts_src[:, :3].mean(0)
     T[:3, 3] += shift.reshape(-1)
     pts_src[:, :3] += shift[None]
     tolerance = 0.05
-    retval, residual, pose = opencv_icp(pts_src.reshape(-1, 6), pts_tgt.reshape(-1, 6), 100, tolerance, 2.5, 4)
+    retval, residual, pose = opencv_icp(pts_src.reshape(-1, 6), pts_tgt.reshape(-1, 6), 100, tolerance, 2.5, 4, info=info)
     T = pose @ T
     if residual > tolerance or residual < 0:
         retval = -1
