@@ -249,6 +249,7 @@ struct NnScratch {   // per object, global memory (cap points each)
   float* d2;         // [cap]
   float* dev;        // [cap]
   int* nn;           // [cap]
+  unsigned long long* nnkey;   // [cap] nearest-neighbour merge across scene segments: (distance bits | scene index) per model point
   unsigned long long* key;   // [cap] picky filter: (d2 bits << 32 | model index) per scene point
 };
 
@@ -308,13 +309,13 @@ __device__ __forceinline__ void transform_point(const float* p, const double* T,
   o[3] = (float)a; o[4] = (float)b; o[5] = (float)c;
 }
 
-struct NnPtrs { float *src, *dst, *src_t, *moved, *dst_s, *d2, *dev; int* nn; unsigned long long* key; };
+struct NnPtrs { float *src, *dst, *src_t, *moved, *dst_s, *d2, *dev; int* nn; unsigned long long *key, *nnkey; };
 
 __device__ __forceinline__ NnPtrs row_ptrs(const NnScratch& sc, int row, int cap) {
   NnPtrs p;
   p.src = sc.src + (size_t)row * cap * 6; p.dst = sc.dst + (size_t)row * cap * 6; p.src_t = sc.src_t + (size_t)row * cap * 6;
   p.moved = sc.moved + (size_t)row * cap * 6; p.dst_s = sc.dst_s + (size_t)row * cap * 6;
-  p.d2 = sc.d2 + (size_t)row * cap; p.dev = sc.dev + (size_t)row * cap; p.nn = sc.nn + (size_t)row * cap; p.key = sc.key + (size_t)row * cap;
+  p.d2 = sc.d2 + (size_t)row * cap; p.dev = sc.dev + (size_t)row * cap; p.nn = sc.nn + (size_t)row * cap; p.key = sc.key + (size_t)row * cap; p.nnkey = sc.nnkey + (size_t)row * cap;
   return p;
 }
 
@@ -331,6 +332,7 @@ __device__ void level_start(NnRow& R, const NnPtrs& P, const double* pose, int l
     float o[6];
     transform_point(P.src + (size_t)i * step * 6, pose, o);
     for (int k = 0; k < 6; ++k) { P.src_t[(size_t)i * 6 + k] = o[k]; P.moved[(size_t)i * 6 + k] = o[k]; }
+    P.nnkey[i] = ~0ull;
   }
   for (int i = tid; i < ml; i += NN_THREADS)
     for (int k = 0; k < 6; ++k) P.dst_s[(size_t)i * 6 + k] = P.dst[(size_t)i * step * 6 + k];
@@ -427,53 +429,60 @@ __global__ __launch_bounds__(NN_THREADS) void icpnn_begin(NnScratch sc, int cap,
   level_start(R, P, pose_s, num_levels - 1, iterations, tolerance);
 }
 
-// exact nearest neighbour (float64 distances of the float32 clouds, like a kd-tree's exact answer) of a chunk of the moved model points in
-// the level's scene, which is tiled through LDS.  Grid (chunks, objects); objects that are finished / chunks past the level's points exit.
-constexpr int SEARCH_THREADS = 256, SEARCH_PER = 4, SEARCH_TILE = 1024;
+// exact nearest neighbour (float64 distances of the float32 clouds, like a kd-tree's exact answer) of the moved model points in the level's
+// scene.  The (model chunk of 512) x (scene segment of 1024) work items of an object are spread over SEARCH_WGS workgroups so that the
+// critical path does not grow with the scene; a workgroup keeps its best per model point in registers (exact float64 comparison, ties ->
+// the lowest scene index) and merges across segments with one 64-bit atomicMin per point on (top 48 bits of the float64 distance | 16-bit
+// scene index).  icpnn_step re-evaluates the exact distance to the winner, so the 36-bit mantissa only decides between candidates of
+// DIFFERENT segments that agree to 1.5e-11 relative.  Objects that are finished exit at once.
+constexpr int SEARCH_THREADS = 256, SEARCH_PER = 2, SEARCH_TILE = 1024, SEARCH_SEG = 1024, SEARCH_WGS = 256;
 __global__ __launch_bounds__(SEARCH_THREADS) void icpnn_search(NnScratch sc, int cap, const NnRow* __restrict__ rows) {
   __shared__ double tile[SEARCH_TILE * 3];
   const int row = blockIdx.y, tid = threadIdx.x;
   const NnRow& R = rows[row];
   if (R.status == 0 || R.active == 0) return;
   const int nl = R.nl, ml = R.ml;
-  const int base = blockIdx.x * SEARCH_THREADS * SEARCH_PER;
-  if (base >= nl) return;
+  const int chunks = (nl + SEARCH_THREADS * SEARCH_PER - 1) / (SEARCH_THREADS * SEARCH_PER), segs = (ml + SEARCH_SEG - 1) / SEARCH_SEG;
   const float* moved = sc.moved + (size_t)row * cap * 6;
   const float* dst_s = sc.dst_s + (size_t)row * cap * 6;
-  double px[SEARCH_PER], py[SEARCH_PER], pz[SEARCH_PER], best[SEARCH_PER];
-  int bi[SEARCH_PER];
+  unsigned long long* nnkey = sc.nnkey + (size_t)row * cap;
+  for (int item = blockIdx.x; item < chunks * segs; item += gridDim.x) {
+    const int base = (item / segs) * SEARCH_THREADS * SEARCH_PER;
+    const int s0 = (item % segs) * SEARCH_SEG, s1 = min(ml, s0 + SEARCH_SEG);
+    double px[SEARCH_PER], py[SEARCH_PER], pz[SEARCH_PER], best[SEARCH_PER];
+    int bi[SEARCH_PER];
 #pragma unroll
-  for (int q = 0; q < SEARCH_PER; ++q) {
-    const int i = base + q * SEARCH_THREADS + tid;
-    const int ii = i < nl ? i : base;
-    px[q] = (double)moved[(size_t)ii * 6]; py[q] = (double)moved[(size_t)ii * 6 + 1]; pz[q] = (double)moved[(size_t)ii * 6 + 2];
-    best[q] = INFINITY;
-    bi[q] = 0;
-  }
-  for (int t0 = 0; t0 < ml; t0 += SEARCH_TILE) {
-    const int tn = min(SEARCH_TILE, ml - t0);
-    __syncthreads();
-    for (int j = tid; j < tn; j += SEARCH_THREADS) {
-      tile[j * 3] = (double)dst_s[(size_t)(t0 + j) * 6]; tile[j * 3 + 1] = (double)dst_s[(size_t)(t0 + j) * 6 + 1];
-      tile[j * 3 + 2] = (double)dst_s[(size_t)(t0 + j) * 6 + 2];
+    for (int q = 0; q < SEARCH_PER; ++q) {
+      const int i = base + q * SEARCH_THREADS + tid;
+      const int ii = i < nl ? i : base;
+      px[q] = (double)moved[(size_t)ii * 6]; py[q] = (double)moved[(size_t)ii * 6 + 1]; pz[q] = (double)moved[(size_t)ii * 6 + 2];
+      best[q] = INFINITY;
+      bi[q] = s0;
     }
-    __syncthreads();
-    for (int j = 0; j < tn; ++j) {
-      const double qx = tile[j * 3], qy = tile[j * 3 + 1], qz = tile[j * 3 + 2];
+    for (int t0 = s0; t0 < s1; t0 += SEARCH_TILE) {
+      const int tn = min(SEARCH_TILE, s1 - t0);
+      __syncthreads();
+      for (int j = tid; j < tn; j += SEARCH_THREADS) {
+        tile[j * 3] = (double)dst_s[(size_t)(t0 + j) * 6]; tile[j * 3 + 1] = (double)dst_s[(size_t)(t0 + j) * 6 + 1];
+        tile[j * 3 + 2] = (double)dst_s[(size_t)(t0 + j) * 6 + 2];
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int j = 0; j < tn; ++j) {   // (unrolled: the LDS reads of four scene points are in flight under the arithmetic of the previous ones)
+        const double qx = tile[j * 3], qy = tile[j * 3 + 1], qz = tile[j * 3 + 2];
 #pragma unroll
-      for (int q = 0; q < SEARCH_PER; ++q) {
-        const double dx = px[q] - qx, dy = py[q] - qy, dz = pz[q] - qz;
-        const double dsq = (dx * dx + dy * dy) + dz * dz;
-        if (dsq < best[q]) { best[q] = dsq; bi[q] = t0 + j; }   // ties: the lowest scene index
+        for (int q = 0; q < SEARCH_PER; ++q) {
+          const double dx = px[q] - qx, dy = py[q] - qy, dz = pz[q] - qz;
+          const double dsq = (dx * dx + dy * dy) + dz * dz;
+          if (dsq < best[q]) { best[q] = dsq; bi[q] = t0 + j; }   // ties: the lowest scene index
+        }
       }
     }
-  }
-  int* nn = sc.nn + (size_t)row * cap;
-  float* d2 = sc.d2 + (size_t)row * cap;
 #pragma unroll
-  for (int q = 0; q < SEARCH_PER; ++q) {
-    const int i = base + q * SEARCH_THREADS + tid;
-    if (i < nl) { nn[i] = bi[q]; d2[i] = (float)best[q]; }   // FLANN's L2 functor: the SQUARED distance, a float32
+    for (int q = 0; q < SEARCH_PER; ++q) {
+      const int i = base + q * SEARCH_THREADS + tid;
+      if (i < nl) atomicMin(&nnkey[i], ((unsigned long long)__double_as_longlong(best[q]) & ~0xFFFFull) | (unsigned long long)bi[q]);
+    }
   }
 }
 
@@ -502,6 +511,17 @@ __global__ __launch_bounds__(NN_THREADS) void icpnn_step(NnScratch sc, int cap, 
   const int* nn = P.nn;
   unsigned long long* key = P.key;
   __syncthreads();   // (every thread has read the row before thread 0 may rewrite it)
+  // ---- the search's winners: scene index from the merged key, the distance again in exact float64 -> float32 (FLANN's L2 functor returns
+  // the SQUARED distance of the float32 cloud); the keys are reset for the next search -----------------------------------------------------
+  for (int i = tid; i < nl; i += NN_THREADS) {
+    const int j = (int)(P.nnkey[i] & 0xFFFFull);
+    P.nnkey[i] = ~0ull;
+    const double dx = (double)moved[(size_t)i * 6] - (double)dst_s[(size_t)j * 6], dy = (double)moved[(size_t)i * 6 + 1] - (double)dst_s[(size_t)j * 6 + 1],
+                 dz = (double)moved[(size_t)i * 6 + 2] - (double)dst_s[(size_t)j * 6 + 2];
+    P.nn[i] = j;
+    d2[i] = (float)((dx * dx + dy * dy) + dz * dz);
+  }
+  __syncthreads();
   // ---- robust rejection threshold: median + scale * 1.48257968 * MAD (lower medians) --------------------------------------------------
   float thr = INFINITY;
   if (rejection_scale > 0.f) {
@@ -674,7 +694,7 @@ using namespace mp;
 
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" int mp_icp_nn_max_points(void) { return 65536; }
+extern "C" int mp_icp_nn_max_points(void) { return 65536; }   // (the search packs a scene index into 16 bits)
 
 extern "C" size_t mp_icp_nn_workspace_bytes(int n_images, int n_rows, int H, int W) {
   const size_t px = (size_t)H * W, cap = (size_t)mp_icp_nn_max_points();
@@ -683,7 +703,7 @@ extern "C" size_t mp_icp_nn_workspace_bytes(int n_images, int n_rows, int H, int
   b += 3 * a256(imgs * px * 4);            // fill ping / pong, gaussian temp
   b += 2 * a256(imgs * px);                // valid ping / pong
   b += a256(imgs * px * 6 * 4);            // points + normals of every image
-  b += 5 * a256((size_t)n_rows * cap * 6 * 4) + 2 * a256((size_t)n_rows * cap * 4) + a256((size_t)n_rows * cap * 4) + a256((size_t)n_rows * cap * 8);
+  b += 5 * a256((size_t)n_rows * cap * 6 * 4) + 2 * a256((size_t)n_rows * cap * 4) + a256((size_t)n_rows * cap * 4) + 2 * a256((size_t)n_rows * cap * 8);
   b += a256((size_t)n_rows * sizeof(NnRow)) + a256(imgs * 4) + 4096;
   return b;
 }
@@ -720,6 +740,7 @@ extern "C" int mp_icp_refine_nn(const float* d_depth_meas, int n_images, const i
   sc.dev = (float*)take((size_t)n_rows * cap * 4);
   sc.nn = (int*)take((size_t)n_rows * cap * 4);
   sc.key = (unsigned long long*)take((size_t)n_rows * cap * 8);
+  sc.nnkey = (unsigned long long*)take((size_t)n_rows * cap * 8);
   NnRow* rows = (NnRow*)take((size_t)n_rows * sizeof(NnRow));
   ProfScope prof("icp_refine_nn", 0.0, (double)imgs * px * 40.0, s);
   // batch the images: raw = [measured frames | rendered depths]
@@ -754,7 +775,7 @@ extern "C" int mp_icp_refine_nn(const float* d_depth_meas, int n_images, const i
   hipLaunchKernelGGL(icpnn_begin, dim3(n_rows), dim3(NN_THREADS), 0, s, sc, (int)cap, rows, n_iterations, tolerance, n_levels);
   int total_it = 0;
   for (int level = 0; level < n_levels; ++level) total_it += (int)rint((double)n_iterations / (level + 1));
-  const dim3 sg(ceil_div((int)cap, SEARCH_THREADS * SEARCH_PER), n_rows);
+  const dim3 sg(SEARCH_WGS, n_rows);
   for (int k = 0; k < total_it; ++k) {
     hipLaunchKernelGGL(icpnn_search, sg, dim3(SEARCH_THREADS), 0, s, sc, (int)cap, rows);
     hipLaunchKernelGGL(icpnn_step, dim3(n_rows), dim3(NN_THREADS), 0, s, sc, (int)cap, rows, n_iterations, tolerance, 2.5f);

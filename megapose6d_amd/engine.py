@@ -69,14 +69,26 @@ def conv_wino_stats(reset: bool = True) -> Tuple[float, float]:
     return a.value, b.value
 
 
+_PROFILING = False
+
+
+def profiling() -> bool:
+    """True between profile_begin() and profile_end() (the per-launch event profiler is on: graph capture is then avoided)"""
+    return _PROFILING
+
+
 def profile_begin() -> None:
+    global _PROFILING
     check(_lib.load().mp_profile_begin())
+    _PROFILING = True
 
 
 def profile_end() -> Dict[str, Dict[str, float]]:
     """Stop the per-launch event profiler and return {kernel: {launches, ms, flops, bytes}} (synchronises)."""
+    global _PROFILING
     lib = _lib.load()
     check(lib.mp_profile_end())
+    _PROFILING = False
     out: Dict[str, Dict[str, float]] = {}
     i = 0
     while True:

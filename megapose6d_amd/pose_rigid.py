@@ -10,6 +10,8 @@ nothing synchronises.
 """
 from __future__ import annotations
 
+import os
+
 import time
 from collections import defaultdict
 from types import SimpleNamespace
@@ -81,6 +83,53 @@ class HipBackbone(nn.Module):
 
     def forward(self, x):  # pragma: no cover - the graph is executed by the HIP engine through PosePredictor
         raise RuntimeError("HipBackbone only hosts parameters; use PosePredictor.net_forward (HIP engine)")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _RefinerGraph:
+    """One captured refiner call of `rows` rows: n_iterations x (pose_prepare, render + crop, backbone, pose update) on static buffers."""
+
+    def __init__(self, model: "PosePredictor", rows: int, n_iterations: int, slot: int, packed: "eng.PackedObservation", device):
+        V = model.n_rendered_views
+        self.TCO = torch.zeros(rows, 4, 4, dtype=torch.float32, device=device)
+        self.K = torch.zeros(rows, 3, 3, dtype=torch.float32, device=device)
+        self.im_ids = torch.zeros(rows, dtype=torch.int32, device=device)
+        self.pts_ids = torch.zeros(rows, dtype=torch.int32, device=device)
+        self.ren_ids = torch.zeros(rows, dtype=torch.int32, device=device)
+        self.obs = eng.PackedObservation.__new__(eng.PackedObservation)
+        self.obs.n_im, self.obs.C, self.obs.H, self.obs.W = packed.n_im, packed.C, packed.H, packed.W
+        self.obs.data = torch.empty_like(packed.data)
+        width = sum(wd for _, wd in model._graph_widths())
+        self.pack = torch.zeros(n_iterations, rows, width, dtype=torch.float32, device=device)
+        self.graph = torch.cuda.CUDAGraph()
+        self._fill = None
+        self._model, self._n_iterations, self._slot = model, n_iterations, slot
+
+    def _body(self):
+        m = self._model
+        TCO_input = self.TCO
+        dummy = [""] * self.TCO.shape[0]
+        for n in range(self._n_iterations):
+            st = m._step(None, self.im_ids, self.K, dummy, TCO_input, want_sigmoid=False, slot=self._slot, ids=(self.pts_ids, self.ren_ids),
+                         packed=self.obs)
+            TCO_output = eng.pose_update(st["TCO_n"], st["K_crop"], st["out"], st["tCR"], 9)
+            torch.cat([st["TCO_n"].flatten(1), TCO_output.flatten(1), st["K_crop"].flatten(1), st["KV_crop"].flatten(1), st["boxes_rend"],
+                       st["boxes_crop"], st["out"], st["tCR"], st["TCV_O"].flatten(1)], dim=1, out=self.pack[n])
+            TCO_input = TCO_output
+
+    def run(self, TCO, K, im_ids, ids, packed) -> torch.Tensor:
+        self.TCO.copy_(TCO)
+        self.K.copy_(K)
+        self.im_ids.copy_(im_ids)
+        self.pts_ids.copy_(ids[0])
+        self.ren_ids.copy_(ids[1])
+        self.obs.data.copy_(packed.data)
+        if self._fill is None:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self._body()
+            self._fill = True
+        self.graph.replay()
+        return self.pack.clone()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -171,6 +220,13 @@ class PosePredictor(nn.Module):
         self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
         self._x_rows: Dict[int, int] = {}
         self._label_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        # hipGraph capture of small refiner calls (n_iterations x ~45 launches for a handful of rows): calls of at most `graph_rows`
+        # rows are captured once per (rows, frame shape, n_iterations, slot) and replayed.  OFF by default (0): measured on the MI355X
+        # (tests/test_gpu_refiner_graph.py, 1 row x 5 iterations) replay 5.98 ms vs eager 5.96 ms -- the launches are asynchronous and
+        # the small-batch call is bound by the device time of ~40 dependent small-grid kernels per iteration, not by launch latency
+        self.graph_rows: int = int(os.environ.get("MP_REFINER_GRAPH_ROWS", "0"))
+        self._graphs: Dict[tuple, "_RefinerGraph"] = {}
+        self._graph_seen: Dict[tuple, int] = {}
 
     # -- engine plumbing -----------------------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
@@ -243,9 +299,10 @@ class PosePredictor(nn.Module):
 
     # -- the fused step ------------------------------------------------------------------------------------------
     def _step(self, images: torch.Tensor, im_ids: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO_in: torch.Tensor,
-              want_sigmoid: bool, slot: int = 0, events: bool = False, mv_mode: Optional[int] = None):
+              want_sigmoid: bool, slot: int = 0, events: bool = False, mv_mode: Optional[int] = None, ids=None, packed=None):
         """images [n_im,C,H,W] (C already trimmed to the model's input channels), im_ids [b] row -> image.
-        Returns dict of device tensors; the CNN input stays in self._x.
+        Returns dict of device tensors; the CNN input stays in self._x.  `ids` = (pts_ids, ren_ids) / `packed` = the NHWC4
+        observation override what `labels` / `images` would give (the graph-captured refiner call feeds static buffers).
         `events=True` records three HIP events on the launch stream (before the render+crop launch, after it, after the
         backbone) so that the caller can report DEVICE render / model times (`step_times`); without them `render_time`
         is the host time spent enqueueing the render (the launch is asynchronous, unlike the reference's Panda3D call)."""
@@ -253,8 +310,8 @@ class PosePredictor(nn.Module):
         b = TCO_in.shape[0]
         V = self.n_rendered_views
         h, w = self.render_size
-        H, W = images.shape[-2:]
-        pts_ids, ren_ids = self._ids(labels, device)
+        H, W = images.shape[-2:] if packed is None else (packed.H, packed.W)
+        pts_ids, ren_ids = self._ids(labels, device) if ids is None else ids
         points = self.mesh_db.sampled_points(2000)
         TCO_n, tCR, TCV_O, KV_crop, boxes_rend, boxes_crop, K_main = eng.pose_prepare(
             TCO_in, K, pts_ids, points, 2000, 200, V, self._mv_mode if mv_mode is None else mv_mode, (H, W), (h, w), 1.4, with_K_main=True)
@@ -282,7 +339,7 @@ class PosePredictor(nn.Module):
                                       c0 + 3 if self.render_normals else -1,
                                       c0 + (6 if self.render_normals else 3) if self.render_depth else -1, off,
                                       views_per_item=nv, stride_view=nper, slot=slot,
-                                      crop=(self._packed(images), im_ids, boxes_crop, 0) if v0 == 0 else None)
+                                      crop=((self._packed(images) if packed is None else packed), im_ids, boxes_crop, 0) if v0 == 0 else None)
         render_time = time.time() - t0
         if ev is not None:
             ev[1].record()
@@ -335,6 +392,11 @@ class PosePredictor(nn.Module):
         if im_ids is None:
             assert images.shape[0] == bsz
             im_ids = torch.arange(bsz, dtype=torch.int32, device=device)
+        if (self.predict_pose_update and 0 < bsz <= self.graph_rows and not materialize and not cuda_timer and not eng.profiling()
+                and self.render_dtype == torch.float32):
+            graphed = self._forward_graphed(images, K, labels, TCO, n_iterations, im_ids, slot)
+            if graphed is not None:
+                return graphed
         outputs: Dict[str, PosePredictorOutput] = dict()
         TCO_input = TCO
         nin = self._n_input_channels
@@ -359,6 +421,47 @@ class PosePredictor(nn.Module):
                 boxes_rend=st["boxes_rend"], boxes_crop=st["boxes_crop"], renderings_logits=renderings_logits,
                 timing_dict={"render": st["render_time"], "events": st["events"]})
             TCO_input = TCO_output
+        return outputs
+
+    # -- hipGraph path of small refiner calls -----------------------------------------------------------------------
+    def _graph_widths(self):
+        V = self.n_rendered_views
+        return (("TCO_n", 16), ("TCO_out", 16), ("K_crop", 9), ("KV_crop", 9 * V), ("boxes_rend", 4), ("boxes_crop", 4), ("out", 9),
+                ("tCR", 3), ("TCV_O", 16 * V))
+
+    def _forward_graphed(self, images, K, labels, TCO, n_iterations, im_ids, slot) -> Optional[Dict[str, PosePredictorOutput]]:
+        """The same call as the loop in forward(), captured once as a hipGraph (torch.cuda.CUDAGraph = hipStreamBeginCapture /
+        hipGraphLaunch around this library's launches) and replayed: the first call of a shape runs eagerly (it also warms every
+        lazily-sized workspace), the second captures, later ones copy the inputs into the graph's static buffers, replay, and clone the
+        packed per-iteration results.  Returns None while the shape is still in its eager warm-up call."""
+        device = TCO.device
+        b = TCO.shape[0]
+        key = (b, n_iterations, slot, tuple(images.shape), str(device), self._mv_mode)
+        packed = self._packed(images)
+        ids = self._ids(labels, device)
+        g = self._graphs.get(key)
+        if g is None:
+            seen = self._graph_seen.get(key, 0)
+            self._graph_seen[key] = seen + 1
+            if seen == 0:
+                return None
+            if len(self._graphs) >= 32:
+                self._graphs.clear()
+            g = self._graphs[key] = _RefinerGraph(self, b, n_iterations, slot, packed, device)
+        res = g.run(TCO, K, im_ids, ids, packed)
+        V = self.n_rendered_views
+        outputs: Dict[str, PosePredictorOutput] = dict()
+        for n in range(n_iterations):
+            f, o = {}, 0
+            for name, wd in self._graph_widths():
+                f[name] = res[n, :, o:o + wd]
+                o += wd
+            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
+                renders=None, images_crop=None, TCO_input=f["TCO_n"].reshape(b, 4, 4), TCO_output=f["TCO_out"].reshape(b, 4, 4),
+                TCV_O_input=f["TCV_O"].reshape(b, V, 4, 4), tCR=f["tCR"], labels=labels, K=K, K_crop=f["K_crop"].reshape(b, 3, 3),
+                KV_crop=f["KV_crop"].reshape(b, V, 3, 3), network_outputs={"pose": f["out"]}, boxes_rend=f["boxes_rend"],
+                boxes_crop=f["boxes_crop"], renderings_logits=torch.empty(b, V, dtype=TCO.dtype, device=device),
+                timing_dict={"render": 0.0, "events": None})
         return outputs
 
     @torch.no_grad()

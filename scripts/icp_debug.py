@@ -52,6 +52,7 @@ for _ in range(3):
 for _ in range(3):
     take(N * cap * 4)
 take(N * cap * 8)
+take(N * cap * 8)
 o_rows = take(0)
 row_dt = np.dtype([("n", "i4"), ("m", "i4"), ("status", "i4"), ("iters", "i4", 8), ("active", "i4"), ("level", "i4"), ("it", "i4"), ("nl", "i4"),
                    ("ml", "i4"), ("max_it", "i4"), ("tol_p", "f8"), ("fval", "f8", 3), ("pose_x", "f8", 16), ("scale", "f8"), ("mean_avg", "f8", 3),
