@@ -451,7 +451,7 @@ def main():
                    and v["ms"] == max(vv["ms"] for kk, vv in prof.items() if kk.startswith("raster_"))), None)
         rb_name = next((k for k, v in prof.items() if v is rb), None)
         traffic, traffic_src, r_traffic = None, None, None
-        tfile = next((f for f in (ROOT / "profiles" / "r02_traffic.json", ROOT / "profiles" / "r01_conv_traffic.json") if f.is_file()), None)
+        tfile = next((f for f in (ROOT / "profiles" / "r03_traffic.json", ROOT / "profiles" / "r02_traffic.json") if f.is_file()), None)
         if tfile is not None:  # PMC cannot be sampled from inside the process: committed rocprofv3 --pmc summary of the same command
             tj = json.loads(tfile.read_text())
             k = tj["kernels"].get(dom_name.replace(" ", ""))

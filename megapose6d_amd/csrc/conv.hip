@@ -941,11 +941,21 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     if (p.run % BK != 0) return small ? launch_splitk<128, 64, 64, 32, 8193, true>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193, true>(p, s, alg_k);
     return small ? launch_splitk<128, 64, 64, 32, 8193>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193>(p, s, alg_k);
   }
+  // The product library holds ONE schedule (8449).  The alternatives measured against it on the MI355X -- persistent workgroups (24833),
+  // the LDS-transposed 16-byte epilogue (73985), both (90369), 64-bit global_load addressing (257): all bit-identical, all within +-1 %
+  // (profiles/r03_conv_ab_epilogue_persistent.txt) -- are compiled only into MP_CONV_EXPERIMENTS builds (scripts/microbench).
+#ifdef MP_CONV_EXPERIMENTS
   const bool vec = (variant & 65536) != 0;   // LDS-transposed 16-byte epilogue (A/B against the dword epilogue)
+#else
+  (void)variant;
+#endif
   if (plan.mode == 2) {  // whole rounds single-pass, the tiles of the half-empty last round split along K
     int rc2;
+#ifdef MP_CONV_EXPERIMENTS
     if (vec) rc2 = small ? launch<128, 64, 64, 32, 73985>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 73985>(p, s, alg_k, plan.n_main);
-    else rc2 = small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 8449>(p, s, alg_k, plan.n_main);
+    else
+#endif
+    rc2 = small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k, plan.n_main) : launch<128, 128, 64, 64, 8449>(p, s, alg_k, plan.n_main);
     if (rc2) return rc2;
     p.chunks_per_split = plan.chunks_per_split;
     p.k_split = plan.k_split;
@@ -955,16 +965,21 @@ extern "C" int mp_conv2d_nhwc(const mp_conv_desc* d, mp_stream stream) {
     return small ? launch_splitk<128, 64, 64, 32, 8193>(p, s, alg_k) : launch_splitk<128, 128, 64, 64, 8193>(p, s, alg_k);
   }
   if (p.run % BK != 0) {  // ragged K (stems): per-lane K bookkeeping
+#ifdef MP_CONV_EXPERIMENTS
     if (vec) return small ? launch<128, 64, 64, 32, 73985, true>(p, s, alg_k) : launch<128, 128, 64, 64, 73985, true>(p, s, alg_k);
+#endif
     return small ? launch<128, 64, 64, 32, 8449, true>(p, s, alg_k) : launch<128, 128, 64, 64, 8449, true>(p, s, alg_k);
   }
+#ifdef MP_CONV_EXPERIMENTS
   switch (variant) {  // every variant computes the same result; the others are kept for A/B timing
     case 257: return small ? launch<128, 64, 64, 32, 257>(p, s, alg_k) : launch<128, 128, 64, 64, 257>(p, s, alg_k);  // the default schedule with global_load (64-bit lane addresses)
     case 24833: return small ? launch<128, 64, 64, 32, 24833>(p, s, alg_k) : launch<128, 128, 64, 64, 24833>(p, s, alg_k);  // 8449 with persistent workgroups
     case 73985: return small ? launch<128, 64, 64, 32, 73985>(p, s, alg_k) : launch<128, 128, 64, 64, 73985>(p, s, alg_k);  // 8449 + 16-byte epilogue
     case 90369: return small ? launch<128, 64, 64, 32, 90369>(p, s, alg_k) : launch<128, 128, 64, 64, 90369>(p, s, alg_k);  // persistent + 16-byte epilogue
-    default: return small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k) : launch<128, 128, 64, 64, 8449>(p, s, alg_k);
+    default: break;
   }
+#endif
+  return small ? launch<128, 64, 64, 32, 8449>(p, s, alg_k) : launch<128, 128, 64, 64, 8449>(p, s, alg_k);
 }
 
 extern "C" int mp_conv2d_plan(const mp_conv_desc* d, int n_cu, int32_t* out5) {

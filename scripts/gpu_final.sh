@@ -1,14 +1,16 @@
 #!/bin/bash
-# Final measurement call of a round (run through gpurun): pipeline tests, bench lines, rocprofv3 kernel stats of the bench command and
-# the three PMC passes (ONE hardware counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_*) that feed profiles/rNN_traffic.json.
+# Final measurement call of a round (run through gpurun): the whole GPU test suite, smoke, the driver's bench command, the other configs,
+# rocprofv3 kernel stats of the bench command and the three PMC passes (ONE hardware counter group per pass: FETCH_SIZE | WRITE_SIZE |
+# SQ_*) that feed profiles/rNN_traffic.json (scripts/pmc_summary.py).
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
 mkdir -p $O
 R="$GRAFT_REPO_ROOT"
-timeout 240 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q > $O/pytest_pipeline.log 2>&1; echo "rc=$?" >> $O/pytest_pipeline.log
-timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "rc=$?" >> $O/bench_n1.err
+timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log
+timeout 700 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; echo "rc=$?" >> $O/bench_n1.err
 for c in 3 4 5; do timeout 200 python bench.py --config $c --steps 1 --warmup 1 > $O/bench_c$c.json 2> $O/bench_c$c.err; done
-MP_PROF_DETAIL=1 timeout 100 python scripts/profile_layers.py > $O/layers.log 2>&1
+timeout 200 python scripts/icp_timing.py > $O/icp_timing.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python $R/bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline > $R/$O/stats.log 2>&1
@@ -19,3 +21,4 @@ timeout 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MF
 cd $R
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*.csv" -size +30M -delete
+tail -n 3 $O/pytest_gpu.log; tail -n 2 $O/smoke.log; tail -c 400 $O/bench_n1.json; tail -n 2 $O/bench_n1.err

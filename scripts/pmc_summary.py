@@ -22,6 +22,8 @@ def short_name(k: str) -> str:
         if len(args) >= 7 and args[6] in ("true", "1"):
             s += "/splitk"
         return s
+    if name == "conv3x3_wino_f32":
+        return "conv3x3_wino_f32<64t,64c>"   # (the in-library profiler's row name of the Winograd kernel)
     return name
 
 
