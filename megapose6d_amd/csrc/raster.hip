@@ -41,7 +41,9 @@ typedef rc::TexRef TexDev;
 typedef rc::Lights LightsDev;
 
 #ifndef MP_RASTER_WAVES
-#define MP_RASTER_WAVES 4   // waves per SIMD the tile kernel is compiled for (register budget 512 / MP_RASTER_WAVES)
+#define MP_RASTER_WAVES 3   // waves per SIMD the tile kernel is compiled for (register budget 512 / MP_RASTER_WAVES).  Measured on one
+                            // box, config-2 step (profiles/r03_raster_waves_ab.txt): 4 waves = 128 VGPRs + 284 B/lane of spills (16.7 GB written
+                            // per 4.9-GB launch) 60.4 ms; 3 waves = 164 VGPRs, no spills, 55.2 ms
 #endif
 constexpr int BIN_THREADS = 512;
 constexpr int LARGE_TILES = 16;    // a piece whose bbox touches more tiles is not replicated into tile lists
