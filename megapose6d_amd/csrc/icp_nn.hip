@@ -21,6 +21,7 @@
 // medians, 64-bit atomicMin one-to-one filter, float64 normal equations reduced in a fixed order (deterministic), Cholesky solve.
 // Arithmetic follows the restatement (float32 where numpy / OpenCV hold float32, float64 where they compute in double).
 // Roofline: latency / VALU-bound tail work of config 5 (once per detection after the CNN stages), negligible next to them.
+#include <algorithm>
 #include <cmath>
 
 #include "common.h"
@@ -29,6 +30,7 @@ namespace mp {
 
 constexpr int NN_THREADS = 1024;
 constexpr int FILL_RINGS = 10;
+constexpr int IDX_BITS = 18;           // scene index bits of the nearest-neighbour merge key -> at most 2^18 points per object
 constexpr int GAUSS_RADIUS = 8;        // scipy.ndimage.gaussian_filter(sigma=2): truncate 4.0 -> radius int(4 * 2 + 0.5) = 8
 
 // ---- preparation ------------------------------------------------------------------------------------------------------------------
@@ -432,9 +434,9 @@ __global__ __launch_bounds__(NN_THREADS) void icpnn_begin(NnScratch sc, int cap,
 // exact nearest neighbour (float64 distances of the float32 clouds, like a kd-tree's exact answer) of the moved model points in the level's
 // scene.  The (model chunk of 512) x (scene segment of 1024) work items of an object are spread over SEARCH_WGS workgroups so that the
 // critical path does not grow with the scene; a workgroup keeps its best per model point in registers (exact float64 comparison, ties ->
-// the lowest scene index) and merges across segments with one 64-bit atomicMin per point on (top 48 bits of the float64 distance | 16-bit
-// scene index).  icpnn_step re-evaluates the exact distance to the winner, so the 36-bit mantissa only decides between candidates of
-// DIFFERENT segments that agree to 1.5e-11 relative.  Objects that are finished exit at once.
+// the lowest scene index) and merges across segments with one 64-bit atomicMin per point on (top 46 bits of the float64 distance | 18-bit
+// scene index).  icpnn_step re-evaluates the exact distance to the winner, so the 34-bit mantissa only decides between candidates of
+// DIFFERENT segments that agree to 6e-11 relative.  Objects that are finished exit at once.
 constexpr int SEARCH_THREADS = 256, SEARCH_PER = 2, SEARCH_TILE = 1024, SEARCH_SEG = 1024, SEARCH_WGS = 256;
 __global__ __launch_bounds__(SEARCH_THREADS) void icpnn_search(NnScratch sc, int cap, const NnRow* __restrict__ rows) {
   __shared__ double tile[SEARCH_TILE * 3];
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void icpnn_search(NnScratch sc, int
 #pragma unroll
     for (int q = 0; q < SEARCH_PER; ++q) {
       const int i = base + q * SEARCH_THREADS + tid;
-      if (i < nl) atomicMin(&nnkey[i], ((unsigned long long)__double_as_longlong(best[q]) & ~0xFFFFull) | (unsigned long long)bi[q]);
+      if (i < nl) atomicMin(&nnkey[i], ((unsigned long long)__double_as_longlong(best[q]) & ~((1ull << IDX_BITS) - 1ull)) | (unsigned long long)bi[q]);
     }
   }
 }
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(NN_THREADS) void icpnn_step(NnScratch sc, int cap, 
   // ---- the search's winners: scene index from the merged key, the distance again in exact float64 -> float32 (FLANN's L2 functor returns
   // the SQUARED distance of the float32 cloud); the keys are reset for the next search -----------------------------------------------------
   for (int i = tid; i < nl; i += NN_THREADS) {
-    const int j = (int)(P.nnkey[i] & 0xFFFFull);
+    const int j = (int)(P.nnkey[i] & ((1ull << IDX_BITS) - 1ull));
     P.nnkey[i] = ~0ull;
     const double dx = (double)moved[(size_t)i * 6] - (double)dst_s[(size_t)j * 6], dy = (double)moved[(size_t)i * 6 + 1] - (double)dst_s[(size_t)j * 6 + 1],
                  dz = (double)moved[(size_t)i * 6 + 2] - (double)dst_s[(size_t)j * 6 + 2];
@@ -694,10 +696,13 @@ using namespace mp;
 
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" int mp_icp_nn_max_points(void) { return 65536; }   // (the search packs a scene index into 16 bits)
+extern "C" int mp_icp_nn_max_points(void) { return 1 << IDX_BITS; }   // (the search packs a scene index into IDX_BITS bits)
+
+// points per object the buffers of a call are sized for: every pixel of the frame, up to the key's limit
+static size_t nn_cap(int H, int W) { return std::min((size_t)H * W, (size_t)1 << IDX_BITS); }
 
 extern "C" size_t mp_icp_nn_workspace_bytes(int n_images, int n_rows, int H, int W) {
-  const size_t px = (size_t)H * W, cap = (size_t)mp_icp_nn_max_points();
+  const size_t px = (size_t)H * W, cap = nn_cap(H, W);
   const size_t imgs = (size_t)n_images + n_rows;
   size_t b = 0;
   b += 3 * a256(imgs * px * 4);            // fill ping / pong, gaussian temp
@@ -720,7 +725,7 @@ extern "C" int mp_icp_refine_nn(const float* d_depth_meas, int n_images, const i
   if (n_rows == 0) return MP_OK;
   MP_REQUIRE(n_rows <= 65535 && n_images <= 65535, "mp_icp_refine_nn: at most 65535 rows / images");
   hipStream_t s = (hipStream_t)stream;
-  const size_t px = (size_t)H * W, cap = (size_t)mp_icp_nn_max_points();
+  const size_t px = (size_t)H * W, cap = nn_cap(H, W);
   const int imgs = n_images + n_rows;   // image batch: the measured frames first, then the rendered depth of every object
   unsigned char* w = (unsigned char*)d_ws;
   auto take = [&](size_t bytes) { unsigned char* p = w; w += a256(bytes); return p; };

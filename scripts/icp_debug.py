@@ -36,7 +36,7 @@ assert rc == 0
 torch.cuda.synchronize()
 w = ws.cpu().numpy()
 a256 = lambda v: (v + 255) & ~255
-px, cap, imgs = H * W, lib.mp_icp_nn_max_points(), 2 * N
+px, cap, imgs = H * W, min(H * W, lib.mp_icp_nn_max_points()), 2 * N
 off = 0
 def take(nbytes):
     global off

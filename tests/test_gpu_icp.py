@@ -191,6 +191,49 @@ def test_default_refiner_is_the_reference_algorithm_step_for_step_on_12_scenes()
     assert n_rejected == 1
 
 
+def test_default_refiner_on_an_object_covering_a_quarter_of_the_frame():
+    """More than 2^16 mask pixels (a close-up: 84 k of the 307 k pixels): the search's scene index has 18 bits and the buffers are sized by
+    the frame, so the object is refined -- and still bit for bit like the restatement -- instead of being rejected for its size."""
+    from megapose6d_amd import mesh_io
+    from megapose6d_amd.icp_refiner import ICPRefiner
+    from megapose6d_amd.renderer import Panda3dBatchRenderer
+    from megapose6d_amd.tcoll import PandasTensorCollection
+    from oracle import icp as oicp
+    from oracle import icp_opencv as ocv
+    from oracle import raster as orr
+    from tests.support import synthetic as syn
+
+    ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_icp_big_"), n_objects=3, seed=31)
+    mesh = mesh_io.load_rigid_object(ds.list_objects[2])
+    K = syn.K_EXAMPLE.astype(np.float32)
+    rng = np.random.RandomState(5)
+    for _ in range(2):   # (the pose stream that gives the 84 k-pixel view)
+        gt = syn.random_pose(rng, (0.27, 0.271), 0.0)
+    dm = orr.render(mesh, gt[None], K[None], 480, 640, 2)[2][0]
+    dm = np.where(dm > 0, dm + np.random.RandomState(1).randn(480, 640).astype(np.float32) * 0.001, dm).astype(np.float32)
+    init = gt.copy().astype(np.float64)
+    init[:3, :3] = oicp._rodrigues(np.deg2rad(2.0) * np.array([0.5, -1.0, 0.7])) @ init[:3, :3]
+    init[:3, 3] += np.array([0.004, -0.003, 0.006])
+    init = init.astype(np.float32)
+    r = Panda3dBatchRenderer(ds, n_workers=1)
+    ref = ICPRefiner(None, r)
+    Kt = torch.from_numpy(K).cuda()[None]
+    preds = PandasTensorCollection(pd.DataFrame(dict(label=[ds.list_objects[2].label], batch_im_id=[0], instance_id=0)), poses=torch.from_numpy(init[None]).cuda())
+    out, extra = ref.refine_poses(preds, depth=torch.from_numpy(dm[None]).cuda(), K=Kt)
+    rend = r.render_depth([ds.list_objects[2].label], torch.from_numpy(init[None]).cuda(), Kt, (480, 640)).cpu().numpy()[0]
+    mask = ocv.compute_masks_threshold(rend, dm)
+    n_pts = int((mask & (dm > 0.2) & (dm < 5)).sum())
+    assert n_pts > 65536, n_pts
+    info = {}
+    T_cv, rv_cv, res_cv = ocv.icp_refinement(dm, rend, mask, K, init, info=info)
+    assert rv_cv == 0 and extra["retval"].item() == 0
+    assert extra["iterations_per_level"][0].tolist() == info["iters"]
+    err = np.abs(out.poses[0].cpu().numpy() - T_cv).max()
+    print(f"{n_pts} points, iterations {info['iters']}, max |pose - restatement| {err:.3e}")
+    assert err <= 1e-6
+    assert np.linalg.norm(out.poses[0].cpu().numpy()[:3, 3] - gt[:3, 3]) < 0.5 * np.linalg.norm(init[:3, 3] - gt[:3, 3])
+
+
 def test_user_masks_replace_threshold_mask_on_device():
     """icp_refiner.py:249-250: with caller masks a pose 15 cm off in depth is refined (the threshold mask alone would reject it)"""
     from tests.support import synthetic as syn

@@ -49,15 +49,15 @@ def test_detector_matches_the_oracle_goldens(case):
         assert np.abs(f[:, ::4, ::4, ::16] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), l
         assert abs(np.abs(f).mean() - float(g[f"P{l}_absmean"][0])) < 1e-4
     props, pcnt = net.debug_tensor("proposals").cpu().numpy(), net.debug_tensor("proposal_counts").cpu().numpy().ravel()
-    assert (np.abs(pcnt - g["proposal_counts"]) <= 2).all()
+    assert (pcnt == g["proposal_counts"]).all()   # (measured on the MI355X: every proposal identical; tolerances are what is achieved)
     assert np.abs(props[:, :16] - g["proposals_first64"][:, :16]).max() < 5e-2   # the best proposals, in place
     for i in range(n):
         k = int(g["counts"][i])
         o = out[i]
-        assert abs(len(o["boxes"]) - k) <= 3
+        assert len(o["boxes"]) == k
         assert o["masks"].shape == (len(o["boxes"]), 1, H, W) and o["labels"].dtype == torch.int64
         found = _match(o["boxes"].cpu().numpy(), o["scores"].cpu().numpy(), o["labels"].cpu().numpy(), g["boxes"][i, :k], g["scores"][i, :k], g["labels"][i, :k])
-        assert found >= k - 3 - k // 20, (found, k)
+        assert found >= k - 1, (found, k)   # (one slot of slack for an exact score tie at the cut)
         s = o["scores"].cpu().numpy()
         assert (s[:-1] >= s[1:]).all() and 0 <= float(o["masks"].min()) and float(o["masks"].max()) <= 1
     # deterministic
