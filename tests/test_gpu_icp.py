@@ -252,5 +252,13 @@ def test_user_masks_replace_threshold_mask_on_device():
     ref = ICPRefiner(None, r)
     _, e0 = ref.refine_poses(preds, depth=depth, K=K[None])
     assert e0["retval"].item() == -1
-    out, e1 = ref.refine_poses(preds, masks=(depth > 0), depth=depth, K=K[None])
+    # a mask that is NOT the object's silhouette (a band of it): it only selects points, the normals still come from the whole frame
+    mask = (depth > 0) & (torch.arange(640, device="cuda")[None, None, :] % 7 != 0)
+    out, e1 = ref.refine_poses(preds, masks=mask, depth=depth, K=K[None])
     assert e1["retval"].item() == 0 and np.linalg.norm(out.poses[0].cpu().numpy()[:3, 3] - gt[:3, 3]) < 5e-3
+    # ... and it is the reference's algorithm with that mask (oracle/icp_opencv.py), bit for bit
+    from oracle import icp_opencv as ocv
+
+    rend = r.render_depth([ds[0].label], torch.from_numpy(off[None]).cuda(), K[None], (480, 640)).cpu().numpy()[0]
+    T_cv, rv_cv, _ = ocv.icp_refinement(depth[0].cpu().numpy(), rend, mask[0].cpu().numpy(), syn.K_EXAMPLE.astype(np.float32), off.astype(np.float32))
+    assert rv_cv == 0 and np.abs(out.poses[0].cpu().numpy() - T_cv).max() <= 1e-6
