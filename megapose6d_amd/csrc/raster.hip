@@ -390,6 +390,7 @@ __host__ __device__ constexpr size_t tiles_zt_bytes(int ns) {
              ? (size_t)64 * ns * (sizeof(unsigned long long) + sizeof(unsigned)) : 64 * sizeof(rc::BlkRec);
 }
 
+constexpr size_t HDR_LDS_BYTES = 128;   // per wave: the list headers of an item's first four views (5 ints each)
 struct ViewHdr {   // what a wave needs to know about one view's lists for its tile (wave-uniform)
   int begin, n_list, begin_l, n_large, overflow;
 };
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NB = NS == 1 ? 1 : 4;
   constexpr size_t ZT_BYTES = tiles_zt_bytes(NS);
-  const size_t per_wave = ZT_BYTES + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15);
+  const size_t per_wave = ZT_BYTES + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15) + HDR_LDS_BYTES;
   unsigned char* mine = lds_raw + (size_t)wave * per_wave;
   unsigned long long* zb = (unsigned long long*)mine;
   uint2* res = (uint2*)mine;                                    // aliases zb once the samples are in registers
@@ -441,10 +442,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   PROF_T0
 
   // The list headers of the item's first FAST_VIEWS views are fetched at once, one view per lane (one memory round trip instead of one
-  // per view: most tiles of a crop are empty in every view, and for those the header is all there is to wait for), and moved to
-  // SCALAR registers right away.  (They must not live in per-lane registers across the view loop: a value that is read back with
-  // v_readlane is invisible to the register allocator's liveness -- a spill under a partial exec mask inside the loop would lose the
-  // lanes that are inactive there.)  Further views (never in the pose pipeline: 1 or 4 views per item) read their header when
+  // per view: most tiles of a crop are empty in every view, and for those the header is all there is to wait for), and parked in a
+  // 80-byte slot of the wave's LDS slice; a view reads its five ints back with broadcast loads + readfirstlane.  (They must not live in
+  // per-lane registers across the view loop: a value that is read back with v_readlane is invisible to the register allocator's
+  // liveness -- a spill under a partial exec mask inside the loop would lose the lanes that are inactive there.  As an array of scalars
+  // the compiler put them in SCRATCH: 80 B per lane, 5 KB of dead stores per wave.)  Further views (never in the pose pipeline: 1 or 4 views per item) read their header when
   // they are reached.  The first 64 records of view r + 1 are requested before view r is processed.
   constexpr int FAST_VIEWS = 4;
   const int view0 = item * views_per_item;
@@ -463,10 +465,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     return v;
   };
-  ViewHdr fast[FAST_VIEWS];
+  int* hdr_lds = (int*)(mine + per_wave - HDR_LDS_BYTES);   // [FAST_VIEWS][5] ints of this wave (behind its staging area)
   {
-    int h_begin = 0, h_nlist = 0, h_begin_l = 0, h_nlarge = 0, h_over = 0;
     if (lane < min(views_per_item, FAST_VIEWS)) {
+      int h_begin = 0, h_nlist = 0, h_begin_l = 0, h_nlarge = 0, h_over = 0;
       const int* hdr = ws + (size_t)(view0 + lane) * lay.view_ints;
       h_over = hdr[2];
       if (h_over) {
@@ -477,19 +479,18 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         h_begin_l = hdr[lay.off_tl + tile];
         h_nlarge = hdr[lay.off_tl + tile + 1] - h_begin_l;
       }
+      int* d = hdr_lds + lane * 5;
+      d[0] = h_begin; d[1] = h_nlist; d[2] = h_begin_l; d[3] = h_nlarge; d[4] = h_over;
     }
-#pragma unroll
-    for (int q = 0; q < FAST_VIEWS; ++q) {
-      fast[q].begin = rl(h_begin, q); fast[q].n_list = rl(h_nlist, q); fast[q].begin_l = rl(h_begin_l, q);
-      fast[q].n_large = rl(h_nlarge, q); fast[q].overflow = rl(h_over, q);
-    }
+    wave_lds_fence();
   }
-  auto hdr_of = [&](int r) {   // r is wave-uniform: scalar selects
+  auto hdr_of = [&](int r) {   // r is wave-uniform: broadcast LDS reads, straight into scalar registers
     if (r >= FAST_VIEWS) return fetch_hdr(view0 + r);
-    ViewHdr v = fast[0];
-#pragma unroll
-    for (int q = 1; q < FAST_VIEWS; ++q)
-      if (r == q) v = fast[q];
+    const int* d = hdr_lds + r * 5;
+    ViewHdr v;
+    v.begin = __builtin_amdgcn_readfirstlane(d[0]); v.n_list = __builtin_amdgcn_readfirstlane(d[1]);
+    v.begin_l = __builtin_amdgcn_readfirstlane(d[2]); v.n_large = __builtin_amdgcn_readfirstlane(d[3]);
+    v.overflow = __builtin_amdgcn_readfirstlane(d[4]);
     return v;
   };
   ViewHdr vh_next = hdr_of(0);
@@ -888,7 +889,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
   const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
   MP_REQUIRE(n_wg < (1LL << 31), "mp_raster_render: grid too large");
-  const size_t lds = (size_t)TILE_WAVES * (tiles_zt_bytes(ns) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15));
+  const size_t lds = (size_t)TILE_WAVES * (tiles_zt_bytes(ns) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15) + HDR_LDS_BYTES);
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
