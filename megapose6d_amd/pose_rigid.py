@@ -231,7 +231,14 @@ class PosePredictor(nn.Module):
     # -- engine plumbing -----------------------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
         self._engine_bb = None
+        self.invalidate_graphs()   # captured refiner calls hold the old engine's device pointers
         return super().load_state_dict(*args, **kwargs)
+
+    def invalidate_graphs(self) -> None:
+        """Drop the captured refiner calls (`graph_rows` > 0): needed whenever the engine backbone, the renderer's mesh database or a
+        mode such as `conv_precision` changes after a capture; `load_state_dict` does it itself."""
+        self._graphs.clear()
+        self._graph_seen.clear()
 
     def _backbone_engine(self) -> eng.Backbone:
         if self._engine_bb is None:
