@@ -236,7 +236,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ unsigned long long g_raster_prof[16];
 #define PROF_T0                                              \
   unsigned long long prof_t = __builtin_readcyclecounter(); \
-  unsigned long long prof_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   /* 9.. = counters: visits, records, tile-views, batches */
+  unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   /* 9..12 = counters: visits, records, tile-views, batches; 13 / 14 = cycles of a batch's set-up / visits */
 #define PROF(slot)                                                  \
   {                                                                 \
     const unsigned long long prof_n = __builtin_readcyclecounter(); \
@@ -245,7 +245,7 @@ __device__ unsigned long long g_raster_prof[16];
   }
 #define PROF_FLUSH                                                                  \
   if (lane == 0 && (blockIdx.x & 31) == 0) {                                        \
-    for (int k = 0; k < 13; ++k) atomicAdd(&g_raster_prof[k], prof_acc[k]);         \
+    for (int k = 0; k < 16; ++k) atomicAdd(&g_raster_prof[k], prof_acc[k]);         \
   }
 #define PROF_COUNT(slot, n) prof_acc[slot] += (unsigned long long)(n);
 #else
@@ -266,6 +266,9 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
                                                    const uint32_t (&rel)[NS == 1 ? 1 : 4], unsigned ok_mask, uint4* blk,
                                                    unsigned long long (&best)[NS == 1 ? 1 : 4], unsigned long long* n_visits = nullptr) {
   constexpr int NB = NS == 1 ? 1 : 4;
+#ifdef MP_RASTER_PROF
+  const unsigned long long prof_ta = __builtin_readcyclecounter();
+#endif
   rc::BlkRec mine;
   memset(&mine, 0, sizeof(mine));
   int rxmin = 0, rxmax = -1, rymin = 0, rymax = -1;
@@ -282,9 +285,20 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
     d[2] = make_uint4(__float_as_uint(mine.iz[0]), __float_as_uint(mine.iz[1]), __float_as_uint(mine.iz[2]), mine.key_lo);
   }
   wave_lds_fence();
+#ifdef MP_RASTER_PROF   // (probe only: the block tests are hoisted so that set-up and visits can be timed apart)
+  unsigned long long touched[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) touched[k] = __ballot(active && rc::blk_touched(mine, rxmin, rxmax, rymin, rymax, NS, k));
+  const unsigned long long prof_tb = __builtin_readcyclecounter();
+  if (n_visits) n_visits[4] += prof_tb - prof_ta;
+#endif
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
+#ifdef MP_RASTER_PROF
+    unsigned long long m = touched[k];
+#else
     unsigned long long m = __ballot(active && rc::blk_touched(mine, rxmin, rxmax, rymin, rymax, NS, k));
+#endif
 #ifdef MP_RASTER_PROF
     if (n_visits) *n_visits += __popcll(m);
 #endif
@@ -339,6 +353,9 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
     best[k] = bk;
   }
   wave_lds_fence();   // the next batch rewrites the records
+#ifdef MP_RASTER_PROF
+  if (n_visits) n_visits[5] += __builtin_readcyclecounter() - prof_tb;
+#endif
 }
 
 // ---- coverage form 2 (the view's "large" list and the overflow fallback only): wave-per-piece sweep with the 64-bit edge functions.
@@ -405,7 +422,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop) {
   // LDS per wave: zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32 | stage [64][run] floats
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // (a readfirstlane'd wave index makes the LDS bases scalar -- and the kernel 4 % slower, measured)
   constexpr int NB = NS == 1 ? 1 : 4;
   constexpr size_t ZT_BYTES = tiles_zt_bytes(NS);
   const size_t per_wave = ZT_BYTES + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15) + HDR_LDS_BYTES;
@@ -541,6 +558,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
           const rc::TileRec rec = base == 0 ? rec_first : load_tile_rec(list + vh.begin + e);
           rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
         }
+#ifdef MP_RASTER_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (probe only: the wait for the records counts as list fetch, not as coverage)
+#endif
         PROF(1)
         int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
         if (mine_p.id >= 0) {

@@ -39,6 +39,9 @@ for label, f, zr in (("zoomed (object fills the view)", 1500.0, (0.4, 0.6)), ("p
         if buf[11]:
             print(f"    per tile-view with geometry: {buf[10] / buf[11]:.1f} records, {buf[9] / buf[11]:.1f} visits, {buf[12] / buf[11]:.2f} batches "
                   f"(sampled waves: {buf[11]} tile-views)")
+            if buf[12]:
+                print(f"    inside the block-visit phase, wave cycles per batch: set-up (BlkRec, block tests) {buf[13] / buf[12]:.0f}, visits {buf[14] / buf[12]:.0f} "
+                      f"= {100.0 * buf[13] / max(tot, 1):.1f} % / {100.0 * buf[14] / max(tot, 1):.1f} % of all wave cycles (the wait for the records is counted as list fetch)")
         print(f"{label}, flags={flags}: {e0.elapsed_time(e1):.2f} ms; wave-cycles by phase: " +
               ", ".join(f"{names[i]} {100.0 * buf[i] / tot:.1f}%" for i in range(9)) + f"  (total {tot / 1e9:.2f} G wave-cycles)", flush=True)
     cov = (out[..., 3:6].sum(-1) > 0).float().mean().item()
