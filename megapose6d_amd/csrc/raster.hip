@@ -334,17 +334,18 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
         const int jn = more ? __ffsll((long long)m) - 1 : j;
         m &= m - 1ull;
         const uint4 an = blk[jn * 3], bn = blk[jn * 3 + 1], cn = blk[jn * 3 + 2];
-        rc::BlkRec r;
-        r.dxy[0] = a.x; r.dxy[1] = a.y; r.dxy[2] = a.z;
-        r.thr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);     // scalar: the three thresholds become SALU bit tests
-        r.e0[0] = (int)b.x; r.e0[1] = (int)b.y; r.e0[2] = (int)b.z;
-        r.inv_area = __uint_as_float(b.w);
-        r.iz[0] = __uint_as_float(c.x); r.iz[1] = __uint_as_float(c.y); r.iz[2] = __uint_as_float(c.z);
-        r.key_lo = c.w;
-        rc::cover_sample_rel(r, rel_k, [&](float wsum) {
-          const unsigned long long key = rc::depth_key_lo(wsum, r.key_lo);
-          if (ok && key > bk) bk = key;
-        });
+        // rc::cover_sample_rel, branch-free (the same operations in the same order for a covered sample; an uncovered one computes
+        // garbage that the final select drops): coverage is the common case of a visit, and the exec-mask branch around the depth
+        // arithmetic cost more than the arithmetic
+        const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);   // scalar: the three thresholds become SALU bit tests
+        const int E0 = rc::dot2_i16(a.x, rel_k, (int)b.x), E1 = rc::dot2_i16(a.y, rel_k, (int)b.y), E2 = rc::dot2_i16(a.z, rel_k, (int)b.z);
+        bool in = ok & (E0 >= (int)(thr & 1u)) & (E1 >= (int)((thr >> 1) & 1u)) & (E2 >= (int)((thr >> 2) & 1u));
+        const float ia = __uint_as_float(b.w);
+        const float b0 = (float)E0 * ia, b1 = (float)E1 * ia, b2 = (float)E2 * ia;
+        const float wsum = fmaf(b2, __uint_as_float(c.z), fmaf(b1, __uint_as_float(c.y), b0 * __uint_as_float(c.x)));
+        in = in & rc::depth_in_range(wsum);
+        const unsigned long long key = rc::depth_key_lo(wsum, c.w);
+        bk = (in & (key > bk)) ? key : bk;
         if (!more) break;
         a = an; b = bn; c = cn;
       }
