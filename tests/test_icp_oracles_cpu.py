@@ -3,8 +3,10 @@ against the restatement of the REFERENCE's refiner (oracle/icp_opencv.py: get_no
 association, icp_refiner.py:37-175) on synthetic scenes.  Stated bounds: identical accept/reject decisions; accepted poses within
 1 mm / 2 degrees of each other; both within 1 mm of the ground truth translation."""
 import tempfile
+from pathlib import Path
 
 import numpy as np
+import pytest
 
 
 def _rot_err_deg(A, B):
@@ -84,3 +86,21 @@ def test_user_masks_replace_the_threshold_mask():
     seg = dm > 0   # a perfect segmentation of the object
     T1, r1, _ = oicp.icp_refine(np.where(seg, dm, 0), dr, K, off, user_masks=True)
     assert r1 == 0 and np.linalg.norm(T1[:3, 3] - gt[:3, 3]) < 5e-3
+
+
+@pytest.mark.skipif(not Path("/root/reference/src/megapose/__init__.py").is_file(), reason="reference sources only exist in the build container")
+def test_restatement_is_pinned_to_the_references_own_refiner_code_around_opencv():
+    """getXYZ, get_normal, compute_masks and the orchestration of icp_refinement (mask / range selection, 1000-point rule, centroid
+    pre-shift, float32 pose update, accept rule) are the REFERENCE's functions, imported and run; only cv2.inpaint and
+    cv2.ppf_match_3d_ICP are stand-ins (the oracle's own): everything of row a20 except those two third-party calls is pinned
+    bit for bit (tests/_ref_icp_check.py)."""
+    import json
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "tests" / "_ref_icp_check.py")], capture_output=True, text=True, timeout=1200)
+    line = next((l for l in p.stdout.splitlines() if l.startswith("REF_ICP_JSON ")), None)
+    assert line is not None, p.stdout[-2000:] + p.stderr[-4000:]
+    problems = json.loads(line[len("REF_ICP_JSON "):])
+    assert problems == [], "\n".join(problems)
