@@ -236,6 +236,23 @@ int mp_conv3x3_wino_nhwc(const mp_conv_desc* desc, const float* d_u, mp_stream s
 /* totals over the Winograd launches since the last reset: algorithmic (direct-convolution) FLOPs and the FLOPs actually executed */
 int mp_conv_wino_stats(double* direct_flops, double* executed_flops, int reset);
 
+/* Stem convolution on the bf16 MFMA through EXACT operand pieces (csrc/conv_stem.hip; same call site as mp_conv2d_nhwc for the first
+ * layer: models/torchvision_resnet.py:213-216, models/wide_resnet.py:65-67).  The render channels of the CNN input are 8-bit integers
+ * k / 255 by the reference's contract (uint8 -> float, panda3d_batch_renderer.py:261-274): k is ONE bf16 exactly; the weights (BN scale
+ * and 1/255 folded in) and the fp32 observation-crop channels are split by truncation into three bf16 pieces each (24 = 3 x 8 mantissa
+ * bits), so every bf16 x bf16 product is exact in the fp32 accumulator and the result differs from the fp32 convolution only in the
+ * order of the fp32 additions -- at 3/16 (9/16 for the crop channels) of the fp32-MFMA time.
+ * Input = "xrec": padded NHWC of bf16 RECORDS, mp_xrec_elements(n_f32, n_u8) = roundup8(3 n_f32 + n_u8) elements per pixel:
+ *   [x1,x2,x3 of fp32 channel 0 | .. | channel n_f32-1 | k of integer channel 0 | .. | zero padding]   (what MP_RASTER_XREC writes).
+ * mp_conv_stem_xrec: desc as for mp_conv2d_nhwc with d_x = the record tensor, C ignored, c_real = n_f32 + n_u8; KH = KW in {5, 7},
+ * stride 2, Cout % 64 == 0, records of 16..40 elements, no residual / second output. */
+int mp_xrec_elements(int n_f32, int n_u8);
+int mp_conv_stem_supported(int KS, int n_f32, int n_u8);
+size_t mp_conv_stem_packed_bytes(int KS, int n_f32, int n_u8, int Cout);
+int mp_conv_stem_pack_weights(const float* h_w_oihw, int Cout, int Cin, int KS, int n_f32, const float* h_scale /*[Cout] or NULL*/,
+                              void* h_packed);
+int mp_conv_stem_xrec(const mp_conv_desc* desc, const void* d_packed, int n_f32, mp_stream stream);
+
 /* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
 int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,
                     int out_border, float* d_y_act, const float* d_act_scale, const float* d_act_shift,

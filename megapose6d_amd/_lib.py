@@ -117,6 +117,11 @@ SIGNATURES = {
     "mp_conv_wino_eligible": (_i, [C.POINTER(ConvDesc), _i]),
     "mp_conv3x3_wino_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _vp]),
     "mp_conv_wino_stats": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
+    "mp_xrec_elements": (_i, [_i, _i]),
+    "mp_conv_stem_supported": (_i, [_i, _i, _i]),
+    "mp_conv_stem_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "mp_conv_stem_pack_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mp_conv_stem_xrec": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),

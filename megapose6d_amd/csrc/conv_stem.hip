@@ -1,0 +1,328 @@
+// conv_stem.hip -- the stem convolution (7x7 / 5x5, stride 2) on the bf16 MFMA through EXACT operand pieces, gfx950.
+//
+// Replaces the first convolution behind `self.backbone(x)` (reference: src/megapose/models/pose_rigid.py:323; layers
+// src/megapose/models/torchvision_resnet.py:213-216 conv1/bn1/relu, src/megapose/models/wide_resnet.py:65-67) -- 24 % of a
+// config-2 step on the fp32 MFMA (conv.hip, 0.75 of the fp32 matrix peak: nothing left to gain there).
+//
+// Why this is exact and not a reduced-precision mode.  All but three of the CNN input channels are RENDERS, and a render value is
+// an 8-bit integer k / 255 by the reference's own contract (uint8 framebuffer -> float, panda3d_batch_renderer.py:261-274; the
+// 4x multisample resolve rounds to 8 bits again).  k <= 255 has 8 significant bits = ONE bf16, exactly.  A weight w (eval-BN scale
+// and the 1/255 folded in) is split by truncation into three bf16 pieces w = w1 + w2 + w3 EXACTLY (24 = 3 x 8 mantissa bits).
+// Every product k * w_i then has <= 16 significant bits: exact in the MFMA's fp32 accumulator.  The three observation-crop
+// channels (roi_align output: general fp32) are split the same way, x = x1 + x2 + x3, and get all 9 exact piece products.  So
+//     y = sum_taps ( sum_i k w_i  |  sum_{i,j} x_i w_j )      accumulated in fp32
+// differs from the fp32-MFMA convolution only in the ORDER of fp32 additions (same error class as any re-association, far below
+// the Winograd layers' 1e-6) -- but v_mfma_f32_16x16x32_bf16 retires 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32:
+// 3 (9) bf16 products per fp32 product = 3/16 (9/16) of the matrix time.
+//
+// Input ("xrec", written by raster_tiles with MP_RASTER_XREC): padded NHWC of bf16 RECORDS, R = 8*Q elements per pixel:
+//   [x1,x2,x3 of fp32 channel 0 | ... channel n_f32-1 | k of integer channel 0 | ... | zero padding].
+// Structure (MI355X-first, not a GEMM library shape):
+//   * workgroup = 8 x 16 output pixels x 64 output channels, 4 waves, TWO workgroups per CU.  The input patch of the tile
+//     ((2*8+KH-2) x (2*16+KW-2) pixel records, 62 KB at 7x7 / Q = 5) is staged in LDS ONCE; there is no im2col anywhere: a K slice
+//     of 8 elements = one 16-byte chunk of one pixel record, so an A fragment of the 16x16x32 MFMA (lane = pixel l & 15, K group
+//     l >> 4 = slice 4t + (l >> 4)) is ONE ds_read_b128 at  pixel(l & 15) + tap/chunk offset(slice)  -- one address VGPR per step,
+//     the 8 M-tiles (output rows) of the tile are immediate offsets.  With stride 2 every pixel sits at an even 16-byte unit and
+//     consecutive slices at odd distance, which is exactly what the b128 lane groups need to be conflict-free (Q = 5).
+//   * wave w owns output channels 16w .. 16w+15 for all 128 pixels: 8 accumulators of 4 registers.  Its weight fragments come
+//     from L2 STRAIGHT into registers in fragment order (host-packed [cb][wave][step][piece][lane][8 bf16], 3 KB per step, prefetched
+//     two steps ahead): every weight byte is loaded by exactly one wave of the workgroup, no LDS write traffic.
+//   * per step: 8 ds_read_b128 + 3 buffer loads + 24 MFMAs (8 M-tiles x 3 weight pieces, same A fragment).
+//   * epilogue: bias (folded BN) + ReLU, the tile goes through the (now free) patch LDS and leaves as whole 256-byte pixel rows.
+// Roofline: MFMA (bf16) bound; algorithmic work = 2 * MACs of the direct convolution over the real channels.
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+
+namespace mp {
+namespace stem {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 16;   // output tile: 8 rows x 16 columns; M-tile j of the MFMA = output row j
+constexpr int NCO = 64;          // output channels per workgroup (4 waves x 16)
+
+struct Params {
+  const unsigned char* __restrict__ x;   // xrec tensor [N][Hp][Wp][8Q] bf16
+  const unsigned char* __restrict__ w;   // packed pieces
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  int N, Ho, Wo;
+  int Hp, Wp;            // padded input size in pixels
+  int in_off;            // in_border - pad
+  int Cout, Hop, Wop, out_border;
+  int tiles_x, tiles_y, n_cb;
+  int n_steps;           // even
+  int relu;
+  unsigned img_bytes;    // Hp * Wp * 16Q
+  unsigned out_bytes;
+};
+
+template <int KS, int Q>
+struct Geo {
+  static constexpr int PH = 2 * (TH - 1) + KS, PW = 2 * (TW - 1) + KS;   // patch size in pixels
+  static constexpr int ROW16 = PW * Q;                                    // 16-byte chunks per patch row
+  static constexpr int PITCH16 = ROW16 | 1;                               // odd pitch (in chunks): row wraps keep the odd slice distance
+  static constexpr int PITCH = PITCH16 * 16;
+  static constexpr int KWQ = KS * Q;                                      // slices per kernel row
+  static constexpr int S = KS * KWQ;                                      // slices in all
+  static constexpr int T = ((S + 3) / 4 + 1) / 2 * 2;                     // steps of 4 slices, even
+  static constexpr size_t PATCH = (size_t)(PH + 1) * PITCH;               // + one zero row: where the padding slices of the last steps point
+  static constexpr size_t OUT_TILE = (size_t)TH * TW * NCO * 4;           // the output tile is staged in the same memory
+  static constexpr size_t LDS = PATCH > OUT_TILE ? PATCH : OUT_TILE;
+  static_assert(4 * T + 4 - S <= KWQ, "padding slices (and the look-ahead read past the last step) must stay inside the extra row");
+};
+
+template <int KS, int Q>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem_bf16x3(Params p) {
+  using G = Geo<KS, Q>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int cb = wg % p.n_cb; wg /= p.n_cb;
+  const int tx = wg % p.tiles_x; wg /= p.tiles_x;
+  const int ty = wg % p.tiles_y;
+  const int n = wg / p.tiles_y;
+
+  // ---- patch: PH rows of ROW16 16-byte chunks, global -> registers -> LDS (rows beyond the image: range-checked to zero) ------------
+  {
+    const unsigned char* img = p.x + (size_t)n * p.img_bytes;
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, p.img_bytes, 0x00020000);
+    const int row_bytes = p.Wp * (16 * Q);
+    const int org = (2 * ty * TH + p.in_off) * row_bytes + (2 * tx * TW + p.in_off) * (16 * Q);
+    constexpr int N_CH = G::PH * G::ROW16, PER = (N_CH + 255) / 256;
+    constexpr int HALF = (PER + 1) / 2;
+    u32x4 v[HALF];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        const int c = tid + 256 * (h * HALF + k);
+        const int row = c / G::ROW16, col = c - row * G::ROW16;
+        v[k] = (c < N_CH) ? __builtin_amdgcn_raw_buffer_load_b128(r_x, org + row * row_bytes + col * 16, 0, 0) : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        const int c = tid + 256 * (h * HALF + k);
+        const int row = c / G::ROW16, col = c - row * G::ROW16;
+        if (c < N_CH) *reinterpret_cast<u32x4*>(lds + row * G::PITCH + col * 16) = v[k];
+      }
+    }
+    for (int c = tid; c < G::PITCH16; c += 256) *reinterpret_cast<u32x4*>(lds + G::PH * G::PITCH + c * 16) = u32x4{0, 0, 0, 0};
+  }
+
+  // ---- weights: this wave's stream [step][piece][lane][16 B] ----------------------------------------------------------------------
+  const size_t w_wave = ((size_t)cb * 4 + wave) * p.n_steps * 3072;
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + w_wave), 0, (unsigned)p.n_steps * 3072u, 0x00020000);
+  const int w_voff = lane * 16;
+  u32x4 b0[3], b1[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    b0[q] = __builtin_amdgcn_raw_buffer_load_b128(r_w, w_voff, q * 1024, 0);
+    b1[q] = __builtin_amdgcn_raw_buffer_load_b128(r_w, w_voff, 3072 + q * 1024, 0);
+  }
+
+  // ---- A addressing: lane = (pixel column i, slice group g); slice s = 4 t + g -> (kernel row, chunk in the row run) ----------------
+  const int i = lane & 15, g = lane >> 4;
+  int s_r = g;                                   // s % KWQ (g < KWQ)
+  int a_off = (2 * i) * (16 * Q) + g * 16;       // pixel (row 0, column i) + the slice's offset
+  auto advance = [&]() {                         // s += 4
+    s_r += 4;
+    a_off += 64;
+    if (s_r >= G::KWQ) { s_r -= G::KWQ; a_off += G::PITCH - G::KWQ * 16; }
+  };
+  f32x4 acc[TH];
+#pragma unroll
+  for (int j = 0; j < TH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a0[TH], a1[TH];
+
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TH; ++j) a0[j] = *reinterpret_cast<const u32x4*>(lds + a_off + j * 2 * G::PITCH);
+  advance();
+
+  const int n_pairs = p.n_steps >> 1;
+  for (int tp = 0; tp < n_pairs; ++tp) {
+    const int w_next = (2 * tp + 2) * 3072;   // (past the end in the last pair: range-checked, never used)
+    // even step: fragments a0 / b0; read a1 for the odd step
+#pragma unroll
+    for (int j = 0; j < TH; ++j) a1[j] = *reinterpret_cast<const u32x4*>(lds + a_off + j * 2 * G::PITCH);
+    advance();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bf16x8 bq = __builtin_bit_cast(bf16x8, b0[q]);
+#pragma unroll
+      for (int j = 0; j < TH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[j]), bq, acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b0[q] = __builtin_amdgcn_raw_buffer_load_b128(r_w, w_voff, w_next + q * 1024, 0);
+    // odd step: fragments a1 / b1; read a0 for the next even step
+#pragma unroll
+    for (int j = 0; j < TH; ++j) a0[j] = *reinterpret_cast<const u32x4*>(lds + a_off + j * 2 * G::PITCH);
+    advance();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bf16x8 bq = __builtin_bit_cast(bf16x8, b1[q]);
+#pragma unroll
+      for (int j = 0; j < TH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[j]), bq, acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b1[q] = __builtin_amdgcn_raw_buffer_load_b128(r_w, w_voff, w_next + 3072 + q * 1024, 0);
+  }
+
+  // ---- epilogue: bias + ReLU, through LDS, whole pixel rows out ------------------------------------------------------------------------
+  __syncthreads();   // every wave is done with the patch
+  {
+    const int co = cb * NCO + wave * 16 + i;
+    const float bias = p.bias ? p.bias[co] : 0.f;
+    float* tile = reinterpret_cast<float*>(lds);   // [128 pixels][64 channels]
+#pragma unroll
+    for (int j = 0; j < TH; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[j][r] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        tile[(j * TW + 4 * g + r) * NCO + wave * 16 + i] = v;   // C/D map: row (pixel) = 4 (lane >> 4) + r, column (channel) = lane & 15
+      }
+  }
+  __syncthreads();
+  {
+    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.out_bytes, 0x00020000);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+#pragma unroll
+    for (int k = 0; k < (TH * TW * NCO / 4) / 256; ++k) {
+      const int c = tid + 256 * k;          // 16-byte chunk of the tile: pixel c / 16, channels 4 (c % 16) ..
+      const int pix = c >> 4, part = c & 15;
+      const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(lds + c * 16);
+      const long off = (((long)n * p.Hop + oy + p.out_border) * p.Wop + ox + p.out_border) * p.Cout + cb * NCO + part * 4;
+      const unsigned voff = (oy < p.Ho && ox < p.Wo) ? (unsigned)(off * 4) : 0xFFFFFFF0u;   // outside the image: dropped by the range check
+      __builtin_amdgcn_raw_buffer_store_b128(v, r_y, (int)voff, 0, 0);
+    }
+  }
+}
+
+template <int KS, int Q>
+int launch(const Params& p, hipStream_t s, double flops, double bytes, const char* name) {
+  using G = Geo<KS, Q>;
+  static int attr_dev = -1;
+  int dev = 0;
+  MP_CHECK_HIP(hipGetDevice(&dev));
+  if (attr_dev != dev) {
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_bf16x3<KS, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+    attr_dev = dev;
+  }
+  ProfScope prof(name, flops, bytes, s);
+  hipLaunchKernelGGL((conv_stem_bf16x3<KS, Q>), dim3((unsigned)((long)p.N * p.tiles_y * p.tiles_x * p.n_cb)), dim3(256), G::LDS, s, p);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}
+
+inline int n_steps(int KS, int Q) { return ((KS * KS * Q + 3) / 4 + 1) / 2 * 2; }
+
+}  // namespace stem
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" int mp_xrec_elements(int n_f32, int n_u8) {
+  if (n_f32 < 0 || n_u8 < 0 || n_f32 + n_u8 <= 0) return 0;
+  return (3 * n_f32 + n_u8 + 7) / 8 * 8;
+}
+
+extern "C" int mp_conv_stem_supported(int KS, int n_f32, int n_u8) {
+  const int R = mp_xrec_elements(n_f32, n_u8);
+  return (KS == 7 || KS == 5) && R >= 16 && R <= 40 ? 1 : 0;
+}
+
+extern "C" size_t mp_conv_stem_packed_bytes(int KS, int n_f32, int n_u8, int Cout) {
+  const int Q = mp_xrec_elements(n_f32, n_u8) / 8;
+  return (size_t)(Cout / stem::NCO) * 4 * stem::n_steps(KS, Q) * 3072;
+}
+
+// exact truncation split of a float into three bf16 pieces (hi, mid, lo): v == hi + mid + lo
+static void split3(float v, unsigned short out[3]) {
+  unsigned vb, rb, qb;
+  memcpy(&vb, &v, 4);
+  const unsigned h = vb & 0xFFFF0000u;
+  float hf; memcpy(&hf, &h, 4);
+  const float r = v - hf;
+  memcpy(&rb, &r, 4);
+  const unsigned m = rb & 0xFFFF0000u;
+  float mf; memcpy(&mf, &m, 4);
+  const float q = r - mf;
+  memcpy(&qb, &q, 4);
+  out[0] = (unsigned short)(h >> 16); out[1] = (unsigned short)(m >> 16); out[2] = (unsigned short)(qb >> 16);
+}
+
+// packed[cb][wave][step][piece][lane][e]: lane = (cout = cb*64 + wave*16 + (lane & 15), slice group lane >> 4), slice s = 4 step + group
+// = (kh, kw, chunk q of the pixel record), element e of the chunk = record slot 8q + e -> input channel; piece = w1 | w2 | w3 of
+// w * scale (* 1/255 for the integer channels, one rounding of the exact product)
+extern "C" int mp_conv_stem_pack_weights(const float* w, int Cout, int Cin, int KS, int n_f32, const float* scale, void* packed) {
+  const int n_u8 = Cin - n_f32;
+  MP_REQUIRE(w && packed && n_f32 >= 0 && n_u8 >= 0 && Cout % stem::NCO == 0 && mp_conv_stem_supported(KS, n_f32, n_u8),
+             "mp_conv_stem_pack_weights: bad arguments (Cout %% 64, KS 5 | 7, 16 <= record <= 40 elements)");
+  const int R = mp_xrec_elements(n_f32, n_u8), Q = R / 8, T = stem::n_steps(KS, Q), S = KS * KS * Q;
+  unsigned short* out = (unsigned short*)packed;
+  memset(out, 0, mp_conv_stem_packed_bytes(KS, n_f32, n_u8, Cout));
+  for (int co = 0; co < Cout; ++co) {
+    const int cb = co / stem::NCO, wave = (co % stem::NCO) / 16, i = co % 16;
+    const double sc = scale ? (double)scale[co] : 1.0;
+    for (int s = 0; s < S; ++s) {
+      const int t = s / 4, g = s % 4;
+      const int kh = s / (KS * Q), rr = s % (KS * Q), kw = rr / Q, q = rr % Q;
+      for (int e = 0; e < 8; ++e) {
+        const int slot = 8 * q + e;
+        int ch;
+        double f;
+        if (slot < 3 * n_f32) { ch = slot / 3; f = sc; }
+        else if (slot < 3 * n_f32 + n_u8) { ch = n_f32 + slot - 3 * n_f32; f = sc / 255.0; }
+        else continue;
+        const float v = (float)((double)w[(((size_t)co * Cin + ch) * KS + kh) * KS + kw] * f);
+        unsigned short pc[3];
+        split3(v, pc);
+        for (int piece = 0; piece < 3; ++piece)
+          out[((((size_t)(cb * 4 + wave) * T + t) * 3 + piece) * 64 + (g * 16 + i)) * 8 + e] = pc[piece];
+      }
+    }
+  }
+  return MP_OK;
+}
+
+// d_x = xrec tensor (bf16 records, padded NHWC with border in_border); the other fields as mp_conv2d_nhwc; KH = KW in {5, 7},
+// stride 2, Cout % 64 == 0, no residual / second output
+extern "C" int mp_conv_stem_xrec(const mp_conv_desc* d, const void* d_packed, int n_f32, mp_stream stream) {
+  MP_REQUIRE(d && d->d_x && d_packed && d->d_y, "mp_conv_stem_xrec: null pointer");
+  const int n_u8 = d->c_real - n_f32;
+  MP_REQUIRE(d->KH == d->KW && d->stride == 2 && d->Cout % stem::NCO == 0 && !d->d_residual && !d->d_y_act && d->in_border >= d->pad &&
+                 mp_conv_stem_supported(d->KH, n_f32, n_u8),
+             "mp_conv_stem_xrec: unsupported layer (square 5x5 / 7x7, stride 2, Cout %% 64, c_real = real channels)");
+  const int R = mp_xrec_elements(n_f32, n_u8), Q = R / 8;
+  stem::Params p;
+  p.x = (const unsigned char*)d->d_x; p.w = (const unsigned char*)d_packed; p.bias = d->d_bias; p.y = d->d_y;
+  p.N = d->N;
+  p.Ho = (d->H + 2 * d->pad - d->KH) / 2 + 1; p.Wo = (d->W + 2 * d->pad - d->KW) / 2 + 1;
+  p.Hp = d->H + 2 * d->in_border; p.Wp = d->W + 2 * d->in_border; p.in_off = d->in_border - d->pad;
+  p.Cout = d->Cout; p.Hop = p.Ho + 2 * d->out_border; p.Wop = p.Wo + 2 * d->out_border; p.out_border = d->out_border;
+  p.tiles_x = ceil_div(p.Wo, stem::TW); p.tiles_y = ceil_div(p.Ho, stem::TH); p.n_cb = d->Cout / stem::NCO;
+  p.n_steps = stem::n_steps(d->KH, Q);
+  p.relu = d->relu;
+  const long img = (long)p.Hp * p.Wp * 16 * Q, outb = (long)d->N * p.Hop * p.Wop * d->Cout * 4;
+  MP_REQUIRE(img < (1L << 31) && outb < 0xFFFFFF00L && (long)d->N * p.tiles_y * p.tiles_x * p.n_cb < (1L << 31), "mp_conv_stem_xrec: tensor too large for 32-bit offsets");
+  p.img_bytes = (unsigned)img; p.out_bytes = (unsigned)outb;
+  const double M = (double)d->N * p.Ho * p.Wo;
+  const double flops = 2.0 * M * d->Cout * d->KH * d->KW * d->c_real;
+  const double bytes = (double)d->N * img + 4.0 * M * d->Cout + (double)mp_conv_stem_packed_bytes(d->KH, n_f32, n_u8, d->Cout);
+  hipStream_t s = (hipStream_t)stream;
+#define MP_STEM_GO(KSV, QV) \
+  if (d->KH == KSV && Q == QV) return stem::launch<KSV, QV>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");
+  MP_STEM_GO(7, 2) MP_STEM_GO(7, 3) MP_STEM_GO(7, 4) MP_STEM_GO(7, 5)
+  MP_STEM_GO(5, 2) MP_STEM_GO(5, 3) MP_STEM_GO(5, 4) MP_STEM_GO(5, 5)
+#undef MP_STEM_GO
+  set_error("mp_conv_stem_xrec: no instance for %dx%d, record of %d elements", d->KH, d->KW, R);
+  return MP_ERR_INVALID;
+}
