@@ -136,7 +136,7 @@ def parity_block(vals: dict, extra: dict) -> dict:
 
 def extras(est, obs, det, steps: int) -> dict:
     """Secondary numbers (NOT `value`): the released inference parameters (n_pose_hypotheses = 1 / 5) and the
-    optional split-precision conv modes on the headline workload.  Same timing discipline, 1 warm-up + `steps` timed calls."""
+    other modes on the headline workload.  Same timing discipline, 1 warm-up + `steps` timed calls."""
 
     def timed(k_hyp: int) -> float:
         est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=k_hyp)
@@ -273,19 +273,6 @@ def extras(est, obs, det, steps: int) -> dict:
     guarded("wide_resnet34_backbone", lambda: other_workload(
         2, "resnet34", N_HYP, "the `value` workload on the OTHER backbone the reference can ship (backbone_str 'resnet34' = WideResNet-34, "
         "training/pose_models_cfg.py:110-111; the released config.yaml is not available offline to tell which one it is)"))
-    for prec in (9, 6):
-        def split(prec=prec):
-            for m in (est.coarse_model, est.refiner_model):
-                m.conv_precision = prec
-                m._engine_bb = None
-            try:
-                return hyp_line("optional mode: fp32 operands split exactly into 3 bf16 pieces, bf16 MFMA, fp32 accumulate; narrower than "
-                                "the reference's fp32 when product terms are dropped (x6) -- never `value`")
-            finally:
-                for m in (est.coarse_model, est.refiner_model):
-                    m.conv_precision = 0
-                    m._engine_bb = None
-        guarded(f"conv_bf16x{prec}_split", split)
     return out
 
 
@@ -309,12 +296,12 @@ def _relaunch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def build_workload(cfg_id: int, world: int, backbone: str, tmp: str, precision: int, k_hyp: int):
+def build_workload(cfg_id: int, world: int, backbone: str, tmp: str, k_hyp: int):
     """-> (estimator, observation, detections, object dataset, description dict, n_objects, run kwargs)"""
     from tests.support.scene import make_multi_frame_scene, make_scene
     from tests.support import synthetic as syn
 
-    common = dict(SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1, n_streams=int(os.environ.get("MP_N_STREAMS", "1")), precision=precision)
+    common = dict(SO3_grid_size=N_HYP, tmp_dir=tmp, distributed=world > 1, n_streams=int(os.environ.get("MP_N_STREAMS", "1")))
     run = dict(n_refiner_iterations=N_ITERS, n_pose_hypotheses=k_hyp)
     if cfg_id == 2:
         n_obj = world  # weak scaling: one object x 576 hypotheses per GPU
@@ -354,8 +341,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-thread-sweep", default="", help="comma list of thread counts: time the cpu_baseline sample at each, write "
                                                           "gpurun_out/cpu_thread_sweep.json and exit")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (faithful K=1/K=5 configs, optional split-precision modes)")
-    ap.add_argument("--precision", type=int, default=0, help="0 = native fp32 MFMA (default, what `value` is quoted on); 9 / 6 = optional bf16 split modes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (faithful K=1/K=5 configs, other backbone / modes)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -376,7 +362,7 @@ def main():
 
     tmp = tempfile.mkdtemp(prefix=f"mp_bench_r{rank}_")
     k_hyp = a.k_hyp or (N_HYP if a.config in (2, 3) else 5)
-    est, obs, det, ds, desc, n_obj, run = build_workload(a.config, world, a.backbone, tmp, a.precision, k_hyp)
+    est, obs, det, ds, desc, n_obj, run = build_workload(a.config, world, a.backbone, tmp, k_hyp)
 
     if a.cpu_thread_sweep:
         res = {"host_cores": os.cpu_count(), "runs": []}
@@ -466,7 +452,7 @@ def main():
         out = {
             "metric": METRIC, "value": n_obj * N_HYP * a.steps / dt, "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == 0 else f"f32 via exact bf16x{a.precision} operand split (bf16 MFMA, fp32 accumulate)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "baseline_config": a.config, "objects": n_obj, "n_pose_hypotheses": k_hyp,
                        "rows_per_step": n_obj * rows_per_obj, "evals_per_s": n_obj * rows_per_obj * a.steps / dt,
                        "views_per_step": n_obj * views_per_obj,

@@ -109,6 +109,14 @@ float mp_mesh_db_radius(const mp_mesh_db* db, int mesh_id);
                                      mp_raster_render_crop, the observation crop) rounded to nearest-even.  The consumer is
                                      mp_backbone_forward_f16 / mp_conv_desc.x_f16.                                              */
 
+#define MP_RASTER_XREC 64u         /* d_out points at the bf16 pixel RECORDS of the exact-piece stem convolution (mp_conv_stem_xrec):
+                                     [x1,x2,x3 of every crop channel | the 8-bit integer k of every render channel (NOT divided by 255) |
+                                     zero padding], mp_xrec_elements(C_crop, n_render_channels) elements per pixel.  mp_raster_render_crop
+                                     only (c0_crop = 0, no depth channel, one launch writes every channel of the record); stride_v /
+                                     stride_y / stride_x count bf16 elements (stride_x = the record length), c_rgb / c_normals /
+                                     stride_view stay logical channel numbers.  The values are the ones the fp32 output holds: k = the
+                                     integer whose k / 255 the fp32 path stores, x1 + x2 + x3 = the fp32 crop value exactly.            */
+
 typedef struct {
   float ambient[3];        /* sum of ambient light colours                                  */
   int32_t n_point;         /* number of point lights (<= 8)                                 */
@@ -201,7 +209,7 @@ typedef struct {
   int64_t splitk_ws_floats;/* the K loop over several workgroups and reduce deterministically (fixed order); NULL = never    */
   int32_t x_f16;           /* != 0: d_x holds IEEE binary16 values in the same padded-NHWC geometry (what MP_RASTER_F16 writes);    */
                            /* the kernel widens them to fp32 on the way into LDS, arithmetic and outputs stay fp32.  Cout <= 64     */
-                           /* (the stem convolutions) and mp_conv2d_nhwc only (not the bf16 split modes)                            */
+                           /* (the stem convolutions)                                                                              */
 } mp_conv_desc;
 
 int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);
@@ -210,14 +218,6 @@ int mp_conv2d_nhwc(const mp_conv_desc* desc, mp_stream stream);
  * 1 = small grid, every tile split along K, 2 = whole rounds single-pass + split-K for the tiles of a half-empty last round. */
 int mp_conv2d_plan(const mp_conv_desc* desc, int n_cu, int32_t* out5);
 
-/* OPTIONAL fast mode: the same fp32 convolution evaluated with bf16 MFMA through an EXACT 3-way split of every operand
- * (x = hi + mid + lo, 3 x 8 mantissa bits; every partial product is exact in fp32, only the accumulation order differs from
- * the native fp32-MFMA path).  n_products = 9 (all pairs) or 6 (drops the pairs weighing <= 2^-24).  d_w must point at a
- * blob from mp_conv_pack_weights_split.  See csrc/conv_split.hip. */
-size_t mp_conv_packed_split_bytes(int Cin_p, int Cout, int KH, int KW);
-int mp_conv_pack_weights_split(const float* h_w_oihw, int Cout, int Cin, int KH, int KW, int Cin_p,
-                               const float* h_scale, void* h_packed);
-int mp_conv2d_nhwc_split(const mp_conv_desc* desc, int n_products, mp_stream stream);
 /* the name of the kernel instantiation mp_conv2d_nhwc would launch (for profiling)        */
 const char* mp_conv2d_kernel_name(const mp_conv_desc* desc);
 
@@ -283,13 +283,10 @@ typedef struct {
 /* views_logits_head.*.  head: 0 = pose_fc (9 outputs), 1 = views_logits_head (n_views).     */
 int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* h_state,
                        int n_tensors, mp_backbone** out);
-/* precision: 0 = native fp32 MFMA (default, what mp_backbone_create builds), 9 / 6 = bf16x9 / bf16x6 split emulation */
-int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* h_state,
-                          int n_tensors, int precision, mp_backbone** out);
 /* the same with the WideResNet width multiplier of `resnet34_width=N` (training/pose_models_cfg.py:114-116, models/wide_resnet.py:62:
  * stage widths 64N .. 512N, features 512N); width = 1 for the released models */
 int mp_backbone_create_wide(int kind, int width, int c_in, int head_kind, int n_head_out, const mp_named_tensor* state, int n_tensors,
-                            int precision, mp_backbone** out);
+                            mp_backbone** out);
 int mp_backbone_destroy(mp_backbone* bb);
 int mp_backbone_input_channels_padded(const mp_backbone* bb);
 int mp_backbone_input_border(const mp_backbone* bb);
@@ -303,11 +300,19 @@ int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int
                         float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
                         mp_stream stream);
 /* the same forward on a half-precision input tensor (binary16 elements, same padded-NHWC geometry: what the rasteriser writes  */
-/* with MP_RASTER_F16).  Only the stem convolution differs (it widens the halves on their way into LDS); native fp32 backbones  */
-/* only (precision 0).                                                                                                          */
+/* with MP_RASTER_F16).  Only the stem convolution differs (it widens the halves on their way into LDS).                       */
 int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, int h, int w, float* d_out,
                             float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
                             mp_stream stream);
+/* the same forward on the bf16 stem RECORDS the rasteriser writes with MP_RASTER_XREC (n_f32 fp32-kind channels first, all other   */
+/* input channels 8-bit integers): only the stem convolution differs (mp_conv_stem_xrec: exact bf16 pieces, 16x the fp32 MFMA rate). */
+/* mp_backbone_xrec_elements: record length in bf16 elements for this backbone (packs the piece blob on first use), 0 = the stem has   */
+/* no such form (records outside 16..40 elements): use mp_backbone_forward.  The tensor has the geometry    */
+/* of the fp32 input (border mp_backbone_input_border()) with records of that many bf16 elements per pixel.                            */
+int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32);
+int mp_backbone_forward_xrec(mp_backbone* bb, const void* d_xrec, int n_f32, int batch, int h, int w, float* d_out,
+                             float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
+                             mp_stream stream);
 /* algorithmic conv+fc FLOPs of one forward at this batch (2*MACs, real channels only)       */
 double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w);
 

@@ -108,9 +108,6 @@ SIGNATURES = {
     "mp_conv_pack_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
     "mp_conv2d_plan": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(C.c_int32)]),
-    "mp_conv_packed_split_bytes": (_sz, [_i, _i, _i, _i]),
-    "mp_conv_pack_weights_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mp_conv2d_nhwc_split": (_i, [C.POINTER(ConvDesc), _i, _vp]),
     "mp_conv2d_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
     "mp_conv_wino_packed_floats": (_sz, [_i, _i]),
     "mp_conv_wino_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -125,8 +122,7 @@ SIGNATURES = {
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
-    "mp_backbone_create_ex": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, _i, C.POINTER(_vp)]),
-    "mp_backbone_create_wide": (_i, [_i, _i, _i, _i, _i, C.POINTER(NamedTensor), _i, _i, C.POINTER(_vp)]),
+    "mp_backbone_create_wide": (_i, [_i, _i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
     "mp_backbone_destroy": (_i, [_vp]),
     "mp_backbone_input_channels_padded": (_i, [_vp]),
     "mp_backbone_input_border": (_i, [_vp]),
@@ -134,6 +130,8 @@ SIGNATURES = {
     "mp_backbone_workspace_reset": (_i, [_vp, _vp]),
     "mp_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_forward_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_backbone_xrec_elements": (_i, [_vp, _i]),
+    "mp_backbone_forward_xrec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_flops": (C.c_double, [_vp, _i, _i, _i]),
     "mp_normalize_T": (_i, [_vp, _i, _vp, _vp]),
     "mp_init_extents": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

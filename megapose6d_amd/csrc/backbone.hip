@@ -18,7 +18,7 @@ namespace mp {
 
 struct ConvLayer {
   int Cin, Cin_p, Cout, K, stride, pad;
-  float* d_w = nullptr;   // packed fp32 weights, or the bf16 split blob when the backbone runs in split mode
+  float* d_w = nullptr;   // packed fp32 weights
   float* d_u = nullptr;   // Winograd-transformed weights (conv_wino.hip) of an eligible 3x3 / stride-1 layer, native fp32 mode only
   float* d_b = nullptr;  // folded BN shift (may be null)
 };
@@ -42,13 +42,17 @@ struct mp_backbone {
   int kind, c_in, c_in_p, in_border, head_kind, n_out, n_feat;
   int width = 1;      // WideResNet width multiplier (`resnet34_width=N`, training/pose_models_cfg.py:114-116): stage widths 64N .. 512N
   int stageC[4] = {64, 128, 256, 512};
-  int precision = 0;  // 0 native fp32 MFMA, 9 / 6 bf16 split products
   bool wide;
   ConvLayer stem;
   std::vector<Block> blocks;
   std::vector<int> stage_of_block;  // 0..3
   float *d_fc_w = nullptr, *d_fc_b = nullptr, *d_head_w = nullptr, *d_head_b = nullptr;
   std::vector<void*> allocs;
+  // exact-piece bf16 stem (conv_stem.hip): the stem's OIHW weights + folded BN scale stay on the host so that the piece blob can be
+  // packed for the record layout (number of fp32-kind channels) the caller's rasteriser launch writes
+  std::vector<float> stem_w_host, stem_scale_host;
+  void* d_stem_pieces = nullptr;
+  int stem_pieces_nf32 = -1;
   // workspace bookkeeping: borders are zeroed once per (pointer, batch, h, w); several workspaces may be live at once
   // (one per HIP stream when half-batches are interleaved on two streams)
   struct WsKey { void* ptr; int batch, h, w; };
@@ -107,23 +111,20 @@ int make_conv(mp_backbone* bb, const StateMap& sm, const std::string& wkey, cons
     if (rc) return rc;
   }
   int rc;
-  if (bb->precision == 0) {
-    std::vector<float> packed(mp_conv_packed_floats(Cin_p, Cout, K, K));
-    rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
-    if (rc) return rc;
-    rc = upload(bb, packed, &L->d_w);
-    // 3x3 / stride-1 layers of the residual stages also get their Winograd F(2x2, 3x3) form (MP_CONV_WINO=0 keeps the direct kernel)
-    static const bool wino_on = !(getenv("MP_CONV_WINO") && atoi(getenv("MP_CONV_WINO")) == 0);
-    if (!rc && wino_on && K == 3 && stride == 1 && pad == 1 && Cin_p % 16 == 0 && Cout % 64 == 0) {
-      std::vector<float> u(mp_conv_wino_packed_floats(Cin_p, Cout));
-      rc = mp_conv_wino_pack_weights(w, Cout, Cin, Cin_p, bnkey.empty() ? nullptr : scale.data(), u.data());
-      if (!rc) rc = upload(bb, u, &L->d_u);
-    }
-  } else {
-    std::vector<float> packed((mp_conv_packed_split_bytes(Cin_p, Cout, K, K) + 3) / 4);
-    rc = mp_conv_pack_weights_split(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
-    if (rc) return rc;
-    rc = upload(bb, packed, &L->d_w);
+  if (L == &bb->stem) {
+    bb->stem_w_host.assign(w, w + (size_t)Cout * Cin * K * K);
+    bb->stem_scale_host = scale;
+  }
+  std::vector<float> packed(mp_conv_packed_floats(Cin_p, Cout, K, K));
+  rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
+  if (rc) return rc;
+  rc = upload(bb, packed, &L->d_w);
+  // 3x3 / stride-1 layers of the residual stages also get their Winograd F(2x2, 3x3) form (MP_CONV_WINO=0 keeps the direct kernel)
+  static const bool wino_on = !(getenv("MP_CONV_WINO") && atoi(getenv("MP_CONV_WINO")) == 0);
+  if (!rc && wino_on && K == 3 && stride == 1 && pad == 1 && Cin_p % 16 == 0 && Cout % 64 == 0) {
+    std::vector<float> u(mp_conv_wino_packed_floats(Cin_p, Cout));
+    rc = mp_conv_wino_pack_weights(w, Cout, Cin, Cin_p, bnkey.empty() ? nullptr : scale.data(), u.data());
+    if (!rc) rc = upload(bb, u, &L->d_u);
   }
   if (rc) return rc;
   if (!bnkey.empty()) {
@@ -156,7 +157,7 @@ int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, i
   if (y_act) { d.d_act_scale = act->d_scale; d.d_act_shift = act->d_shift; }
   d.d_splitk_ws = splitk_ws;
   d.splitk_ws_floats = splitk_ws ? (int64_t)SPLITK_WS_FLOATS : 0;
-  if (bb->precision == 0 && L.d_u && !x_f16) {
+  if (L.d_u && !x_f16) {
     static int n_cu = 0;
     if (!n_cu) {
       int dev = 0;
@@ -165,7 +166,7 @@ int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, i
     }
     if (mp_conv_wino_eligible(&d, n_cu)) return mp_conv3x3_wino_nhwc(&d, L.d_u, s);   // the workspace buffers carry the read slack it needs
   }
-  return bb->precision == 0 ? mp_conv2d_nhwc(&d, s) : mp_conv2d_nhwc_split(&d, bb->precision, s);
+  return mp_conv2d_nhwc(&d, s);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -195,18 +196,12 @@ Geometry geometry(const mp_backbone* bb, int h, int w) {
 
 extern "C" int mp_backbone_create(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
                                   mp_backbone** out) {
-  return mp_backbone_create_ex(kind, c_in, head_kind, n_head_out, st, n_tensors, 0, out);
-}
-
-extern "C" int mp_backbone_create_ex(int kind, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
-                                     int precision, mp_backbone** out) {
-  return mp_backbone_create_wide(kind, 1, c_in, head_kind, n_head_out, st, n_tensors, precision, out);
+  return mp_backbone_create_wide(kind, 1, c_in, head_kind, n_head_out, st, n_tensors, out);
 }
 
 extern "C" int mp_backbone_create_wide(int kind, int width, int c_in, int head_kind, int n_head_out, const mp_named_tensor* st, int n_tensors,
-                                       int precision, mp_backbone** out) {
+                                       mp_backbone** out) {
   MP_REQUIRE(out && st && n_tensors > 0, "mp_backbone_create: bad arguments");
-  MP_REQUIRE(precision == 0 || precision == 9 || precision == 6, "mp_backbone_create: precision must be 0, 9 or 6");
   MP_REQUIRE(kind >= 0 && kind <= 2, "mp_backbone_create: unknown backbone kind %d", kind);
   MP_REQUIRE(width >= 1 && width <= 8 && (width == 1 || kind != MP_BACKBONE_VANILLA_RESNET34),
              "mp_backbone_create: width multiplier %d (1..8, WideResNets only: training/pose_models_cfg.py:114-116)", width);
@@ -215,7 +210,6 @@ extern "C" int mp_backbone_create_wide(int kind, int width, int c_in, int head_k
   for (int i = 0; i < n_tensors; ++i) sm[st[i].name] = std::make_pair(st[i].h_data, st[i].numel);
   mp_backbone* bb = new mp_backbone();
   bb->kind = kind;
-  bb->precision = precision;
   bb->wide = kind != MP_BACKBONE_VANILLA_RESNET34;
   bb->c_in = c_in;
   bb->c_in_p = (c_in + 3) / 4 * 4;
@@ -308,10 +302,32 @@ extern "C" int mp_backbone_workspace_reset(mp_backbone* bb, const void* d_ws) {
   return MP_OK;
 }
 
-static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, int batch, int h, int w, float* d_out, float* d_sigmoid,
+// The piece blob of the stem for records with `n_f32` fp32-kind channels (packed and uploaded on first use); returns the record length
+// in bf16 elements, 0 if this backbone's stem has no exact-piece form (unsupported record sizes).
+extern "C" int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32) {
+  if (!bb || n_f32 < 0 || n_f32 > bb->c_in || bb->stem_w_host.empty()) return 0;
+  const int n_u8 = bb->c_in - n_f32;
+  if (!mp_conv_stem_supported(bb->stem.K, n_f32, n_u8) || bb->stem.Cout % 64 != 0) return 0;
+  if (bb->stem_pieces_nf32 != n_f32) {
+    std::vector<unsigned char> blob(mp_conv_stem_packed_bytes(bb->stem.K, n_f32, n_u8, bb->stem.Cout));
+    if (mp_conv_stem_pack_weights(bb->stem_w_host.data(), bb->stem.Cout, bb->c_in, bb->stem.K, n_f32,
+                                  bb->stem_scale_host.empty() ? nullptr : bb->stem_scale_host.data(), blob.data()) != MP_OK)
+      return 0;
+    void* d = nullptr;
+    if (hipMalloc(&d, blob.size()) != hipSuccess) return 0;
+    if (hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return 0; }
+    bb->allocs.push_back(d);   // (an older blob for another n_f32 stays allocated until destroy: in-flight launches may still read it)
+    bb->d_stem_pieces = d;
+    bb->stem_pieces_nf32 = n_f32;
+  }
+  return mp_xrec_elements(n_f32, n_u8);
+}
+
+// x_mode: 0 = fp32 padded NHWC, 1 = binary16 elements (MP_RASTER_F16), 2 = bf16 stem records with n_f32 fp32-kind channels (MP_RASTER_XREC)
+static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, int n_f32, int batch, int h, int w, float* d_out, float* d_sigmoid,
                                  float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  const bool x_f16 = x_mode == 1;
   MP_REQUIRE(bb && d_x && d_out && d_ws, "mp_backbone_forward: null pointer");
-  MP_REQUIRE(!x_f16 || bb->precision == 0, "mp_backbone_forward_f16: half-precision inputs need a native fp32 backbone (precision 0)");
   if (batch == 0) return MP_OK;
   const size_t need = mp_backbone_workspace_bytes(bb, batch, h, w);
   MP_REQUIRE(ws_bytes >= need, "mp_backbone_forward: workspace %zu < %zu bytes", ws_bytes, need);
@@ -340,7 +356,18 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, 
   float* SK = p;  // split-K scratch (SPLITK_WS_FLOATS)
   int rc;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
-  rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
+  if (x_mode == 2) {
+    MP_REQUIRE(mp_backbone_xrec_elements(bb, n_f32) > 0, "mp_backbone_forward_xrec: this backbone's stem has no exact-piece form for %d fp32 channels of %d",
+               n_f32, bb->c_in);
+    mp_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.d_x = d_x; d.N = batch; d.H = h; d.W = w; d.C = bb->stem.Cin_p; d.c_real = bb->c_in; d.in_border = bb->in_border;
+    d.d_bias = bb->stem.d_b; d.Cout = bb->stem.Cout; d.KH = bb->stem.K; d.KW = bb->stem.K; d.stride = 2; d.pad = bb->stem.pad;
+    d.d_y = S; d.out_border = 1; d.relu = 1;
+    rc = mp_conv_stem_xrec(&d, bb->d_stem_pieces, n_f32, s);
+  } else {
+    rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
+  }
   if (rc) return rc;
   const Block& b0 = bb->blocks[0];
   rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, bb->stageC[0], 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
@@ -386,12 +413,17 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, bool x_f16, 
 
 extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch, int h, int w, float* d_out, float* d_sigmoid,
                                    float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
-  return backbone_forward_impl(bb, d_x, false, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+  return backbone_forward_impl(bb, d_x, 0, 0, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+}
+
+extern "C" int mp_backbone_forward_xrec(mp_backbone* bb, const void* d_xrec, int n_f32, int batch, int h, int w, float* d_out, float* d_sigmoid,
+                                        float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  return backbone_forward_impl(bb, (const float*)d_xrec, 2, n_f32, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
 }
 
 extern "C" int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, int h, int w, float* d_out, float* d_sigmoid,
                                        float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
-  return backbone_forward_impl(bb, (const float*)d_x_half, true, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+  return backbone_forward_impl(bb, (const float*)d_x_half, 1, 0, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
 }
 
 extern "C" double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w) {

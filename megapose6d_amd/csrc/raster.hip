@@ -413,9 +413,14 @@ struct ViewHdr {   // what a wave needs to know about one view's lists for its t
   int begin, n_list, begin_l, n_large, overflow;
 };
 
-// F16 (MP_RASTER_F16, the "fp16 renders" mode of BASELINE.json configs[4]): `out` holds IEEE binary16 elements -- same element
+// OUT = OUT_F16 (MP_RASTER_F16, the "fp16 renders" mode of BASELINE.json configs[4]): `out` holds IEEE binary16 elements -- same element
 // strides, every written channel (renders and the fused crop) is rounded to nearest-even on its way out; nothing else changes.
-template <int NS, bool F16 = false, bool FULL = true>
+// OUT = OUT_XREC (MP_RASTER_XREC): `out` holds the bf16 pixel RECORDS the exact-piece stem convolution consumes (conv_stem.hip):
+// [x1,x2,x3 of every crop channel | the 8-bit integer k of every render channel | zero padding], stride_x = record length; the
+// record is staged in LDS in that form and leaves as 16-byte chunks.  Channel numbers (c_rgb, c_normals, stride_view, crop.c0) stay
+// logical channel numbers; stride_v / stride_y / stride_x count bf16 elements.
+constexpr int OUT_F32 = 0, OUT_F16 = 1, OUT_XREC = 2;
+template <int NS, int OUT = OUT_F32, bool FULL = true>
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(MP_RASTER_WAVES, MP_RASTER_WAVES))) void raster_tiles(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
@@ -434,6 +439,30 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   unsigned* tasks = (unsigned*)(mine + (size_t)64 * NS * sizeof(unsigned long long));
   float* stage = (float*)(mine + ZT_BYTES);
   float* my_stage = stage + (size_t)lane * run;
+  // OUT_XREC: the staging area holds the pixel records themselves, [64][stride_x] bf16 (never larger than [64][run] floats: the
+  // launcher checks); `put` files a channel value into the lane's pixel in whichever form the launch stages
+  const int xrec_nf = crop.C;   // (OUT_XREC) the crop's channels are the fp32-kind ones, 3 record slots each
+  unsigned short* my_rec = reinterpret_cast<unsigned short*>(stage) + (size_t)lane * (int)stride_x;
+  auto put = [&](int ch, float v) {   // ch = logical channel number
+    if constexpr (OUT == OUT_XREC) {
+      if (ch < xrec_nf) {   // exact truncation split x = x1 + x2 + x3 (three bf16 pieces)
+        const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(b1);
+        const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(b2);
+        my_rec[3 * ch] = (unsigned short)(b1 >> 16); my_rec[3 * ch + 1] = (unsigned short)(b2 >> 16);
+        my_rec[3 * ch + 2] = (unsigned short)(__float_as_uint(r2) >> 16);
+      } else {              // an integer 0..255: one bf16, exactly
+        my_rec[2 * xrec_nf + ch] = (unsigned short)(__float_as_uint(v) >> 16);
+      }
+    } else {
+      my_stage[ch - c_lo] = v;
+    }
+  };
+  if constexpr (OUT == OUT_XREC) {   // zero the whole record once (the padding slots are never written again)
+    uint4* z = reinterpret_cast<uint4*>(my_rec);
+    for (int q = 0; q < (int)stride_x / 8; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
   const int groups_x = (lay.tiles_x + TILE_WAVES - 1) / TILE_WAVES;
   int b = blockIdx.x;
   const int gx = b % groups_x; b /= groups_x;
@@ -536,9 +565,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const int n_total = vh.n_list + vh.n_large;
     const long long cv = (long long)r * stride_view;
     if (n_total == 0) {   // nothing of this view reaches the tile (most tiles of a crop): background
-      if (c_rgb >= 0) { my_stage[c_rgb + cv - c_lo] = 0.f; my_stage[c_rgb + cv + 1 - c_lo] = 0.f; my_stage[c_rgb + cv + 2 - c_lo] = 0.f; }
-      if (do_norm) { my_stage[c_normals + cv - c_lo] = 0.f; my_stage[c_normals + cv + 1 - c_lo] = 0.f; my_stage[c_normals + cv + 2 - c_lo] = 0.f; }
-      if (do_depth) my_stage[c_depth + cv - c_lo] = 0.f;
+      if (c_rgb >= 0) { put(c_rgb + (int)cv, 0.f); put(c_rgb + (int)cv + 1, 0.f); put(c_rgb + (int)cv + 2, 0.f); }
+      if (do_norm) { put(c_normals + (int)cv, 0.f); put(c_normals + (int)cv + 1, 0.f); put(c_normals + (int)cv + 2, 0.f); }
+      if (do_depth) put(c_depth + (int)cv, 0.f);
       PROF(0)
       continue;
     }
@@ -671,27 +700,36 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     if (c_rgb >= 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) my_stage[c_rgb + cv + c - c_lo] = rc::resolve_channel(acc[c], NS, false);
+      for (int c = 0; c < 3; ++c) put(c_rgb + (int)cv + c, OUT == OUT_XREC ? rc::resolve_k(acc[c], NS) : rc::resolve_channel(acc[c], NS, false));
     }
     if (do_norm) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) my_stage[c_normals + cv + c - c_lo] = rc::resolve_channel(acc[3 + c], NS, false);
+      for (int c = 0; c < 3; ++c) put(c_normals + (int)cv + c, OUT == OUT_XREC ? rc::resolve_k(acc[3 + c], NS) : rc::resolve_channel(acc[3 + c], NS, false));
     }
-    if (do_depth) my_stage[c_depth + cv - c_lo] = st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f;
+    if (do_depth) put(c_depth + (int)cv, st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f);
     wave_lds_fence();  // the z-buffer / task arrays are reused by the next view
     PROF(6)
   }
   if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
     const float4 cv4 = crop_lane(crop, item, h, w, px, py);
-    my_stage[crop.c0 - c_lo] = cv4.x; my_stage[crop.c0 + 1 - c_lo] = cv4.y; my_stage[crop.c0 + 2 - c_lo] = cv4.z;
-    if (crop.C == 4) my_stage[crop.c0 + 3 - c_lo] = cv4.w;
+    put(crop.c0, cv4.x); put(crop.c0 + 1, cv4.y); put(crop.c0 + 2, cv4.z);
+    if (crop.C == 4) put(crop.c0 + 3, cv4.w);
   }
   wave_lds_fence();
   PROF(7)
   // ---- store: each of the tile's 8 rows leaves as one contiguous run of 8 pixels x `run` channels (only written channels) -------
   const int cols = min(TILE, w - tile_x0), rows = min(TILE, h - tile_y0);
   const int per_row = cols * run;   // <= 256 floats
-  if constexpr (F16) {
+  if constexpr (OUT == OUT_XREC) {
+    // the tile's records sit in LDS as [8 rows][8 pixels][stride_x bf16]; a tile row = cols * stride_x / 8 contiguous 16-byte chunks
+    const int rowlen = cols * ((int)stride_x / 8);   // <= 40 chunks
+    unsigned short* out_item = reinterpret_cast<unsigned short*>(out) + (size_t)item * stride_v;
+    const uint4* recs = reinterpret_cast<const uint4*>(stage);
+    if (lane < rowlen)
+      for (int row = 0; row < rows; ++row)
+        *reinterpret_cast<uint4*>(out_item + (size_t)(tile_y0 + row) * stride_y + (size_t)tile_x0 * stride_x + (size_t)lane * 8) =
+            recs[row * 8 * ((int)stride_x / 8) + lane];
+  } else if constexpr (OUT == OUT_F16) {
     _Float16* out_item = reinterpret_cast<_Float16*>(out) + (size_t)item * stride_v + c_lo;
     for (int i = lane; i < per_row; i += 64) {
       const int x = i / run, c = i - x * run;
@@ -860,7 +898,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && h <= 1024 && views_per_item >= 1 && views_per_item <= 64,
              "mp_raster_render: bad size (h, w <= 1024; 1 <= views_per_item <= 64)");
   MP_REQUIRE(lights->n_point >= 0 && lights->n_point <= 8, "mp_raster_render: too many point lights");
-  MP_REQUIRE((flags & ~(MP_RASTER_NORMALS | MP_RASTER_DEPTH | MP_RASTER_NORMALS_GL | MP_RASTER_MSAA4 | MP_RASTER_F16)) == 0,
+  MP_REQUIRE((flags & ~(MP_RASTER_NORMALS | MP_RASTER_DEPTH | MP_RASTER_NORMALS_GL | MP_RASTER_MSAA4 | MP_RASTER_F16 | MP_RASTER_XREC)) == 0,
              "mp_raster_render: unknown flag bits 0x%x", flags);
   if (n_views == 0) return MP_OK;
   MP_REQUIRE(ws_bytes >= mp_raster_workspace_bytes(db, n_views, h, w), "mp_raster_render: workspace too small");
@@ -914,27 +952,40 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
-  const bool f16 = (flags & MP_RASTER_F16) != 0;
+  const bool f16 = (flags & MP_RASTER_F16) != 0, xrec = (flags & MP_RASTER_XREC) != 0;
+  if (xrec) {   // stem records: ONE launch writes the whole record of every pixel
+    MP_REQUIRE(!f16 && !do_depth && crop.images && crop.c0 == 0 && c_lo == 0 && mask == (run >= 32 ? 0xFFFFFFFFu : (1u << run) - 1u),
+               "mp_raster_render: MP_RASTER_XREC needs the fused crop at channel 0, no depth channel, and every channel of the record written "
+               "by this launch");
+    MP_REQUIRE(stride_x == mp_xrec_elements(crop.C, run - crop.C) && stride_x <= 2 * run && stride_x <= 40,
+               "mp_raster_render: MP_RASTER_XREC: stride_x (%lld) must be the record length mp_xrec_elements(%d, %d)", (long long)stride_x, crop.C,
+               run - crop.C);
+  }
   const double out_es = f16 ? 2.0 : 4.0;   // bytes per output element
-  ProfScope prof(f16 ? "raster_tiles/f16" : "raster_tiles", 0.0,
+  ProfScope prof(f16 ? "raster_tiles/f16" : xrec ? "raster_tiles/xrec" : "raster_tiles", 0.0,
+                 xrec ? (double)n_views * (32.0 * db->max_verts + 12.0 * db->max_faces) + (double)n_items * (2.0 * stride_x + 4.0 * crop.C) * h * w :
                  (double)n_views * ((double)n_ch * out_es * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) +
                      (crop.images ? (double)n_items * crop.C * (out_es + 4.0) * h * w : 0.0), s);   // crop: C channels written + <= the same-sized fp32 source window read
   // FULL = texture + point-light code compiled in; the pose networks' renders (vertex colours, ambient light) take the lean instance
   const bool full = db->any_texture || L.n_point > 0;
-#define MP_LAUNCH_TILES(NSV, F16V, FULLV)                                                                                              \
-  hipLaunchKernelGGL((raster_tiles<NSV, F16V, FULLV>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,    \
+#define MP_LAUNCH_TILES(NSV, OUTV, FULLV)                                                                                              \
+  hipLaunchKernelGGL((raster_tiles<NSV, OUTV, FULLV>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,    \
                      d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,  \
                      (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop)
-  const int sel = (ns == 4 ? 4 : 0) | (f16 ? 2 : 0) | (full ? 1 : 0);
+  const int sel = (ns == 4 ? 8 : 0) | (xrec ? 4 : f16 ? 2 : 0) | (full ? 1 : 0);
   switch (sel) {
-    case 0: MP_LAUNCH_TILES(1, false, false); break;
-    case 1: MP_LAUNCH_TILES(1, false, true); break;
-    case 2: MP_LAUNCH_TILES(1, true, false); break;
-    case 3: MP_LAUNCH_TILES(1, true, true); break;
-    case 4: MP_LAUNCH_TILES(4, false, false); break;
-    case 5: MP_LAUNCH_TILES(4, false, true); break;
-    case 6: MP_LAUNCH_TILES(4, true, false); break;
-    default: MP_LAUNCH_TILES(4, true, true); break;
+    case 0: MP_LAUNCH_TILES(1, OUT_F32, false); break;
+    case 1: MP_LAUNCH_TILES(1, OUT_F32, true); break;
+    case 2: MP_LAUNCH_TILES(1, OUT_F16, false); break;
+    case 3: MP_LAUNCH_TILES(1, OUT_F16, true); break;
+    case 4: MP_LAUNCH_TILES(1, OUT_XREC, false); break;
+    case 5: MP_LAUNCH_TILES(1, OUT_XREC, true); break;
+    case 8: MP_LAUNCH_TILES(4, OUT_F32, false); break;
+    case 9: MP_LAUNCH_TILES(4, OUT_F32, true); break;
+    case 10: MP_LAUNCH_TILES(4, OUT_F16, false); break;
+    case 11: MP_LAUNCH_TILES(4, OUT_F16, true); break;
+    case 12: MP_LAUNCH_TILES(4, OUT_XREC, false); break;
+    default: MP_LAUNCH_TILES(4, OUT_XREC, true); break;
   }
 #undef MP_LAUNCH_TILES
   MP_CHECK_HIP(hipGetLastError());

@@ -732,6 +732,9 @@ MP_HD float resolve_channel(float acc, int ns, bool no_quant) {
   return no_quant ? (acc * inv_ns) / 255.0f : floorf(fmaf(acc, inv_ns, 0.5f)) / 255.0f;
 }
 
+// the resolved 8-bit value itself (what resolve_channel divides by 255): the integer the stem-record output stores
+MP_HD float resolve_k(float acc, int ns) { return floorf(fmaf(acc, 1.0f / (float)ns, 0.5f)); }
+
 MP_HD bool view_finite(const float* T, const float* K) {
   bool ok = true;
   for (int i = 0; i < 16; ++i) ok = ok && isfinite(T[i]);

@@ -20,6 +20,7 @@ RASTER_DEPTH = 2
 RASTER_NORMALS_GL = 4
 RASTER_MSAA4 = 16   # 4x multisampling = the reference renderer's configuration (panda3d_scene_renderer.py:73-74)
 RASTER_F16 = 32     # "fp16 renders": the output tensor holds binary16 elements (set from `out.dtype`, never by hand)
+RASTER_XREC = 64
 
 BACKBONE_KINDS = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2}
 
@@ -203,9 +204,11 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
     mesh_ids = _dev_i32(mesh_ids)
     TCO = _dev_f32(TCO)
     K = _dev_f32(K)
-    assert out.dtype in (torch.float32, torch.float16) and out.is_cuda
+    assert out.dtype in (torch.float32, torch.float16, torch.bfloat16) and out.is_cuda
     es = out.element_size()
     flags = (flags | RASTER_F16) if out.dtype == torch.float16 else (flags & ~RASTER_F16)
+    # a bfloat16 `out` = the stem RECORDS of the exact-piece stem convolution (MP_RASTER_XREC; strides / offset in bf16 elements)
+    flags = (flags | RASTER_XREC) if out.dtype == torch.bfloat16 else (flags & ~RASTER_XREC)
     ws = db.workspace(n, h, w, out.device, slot)
     if crop is not None:
         images, im_ids, boxes, c0 = crop
@@ -279,7 +282,7 @@ def conv_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray
 def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int, w_packed: torch.Tensor,
                 bias: Optional[torch.Tensor], Cout: int, K: int, stride: int, pad: int, y: Optional[torch.Tensor], out_border: int,
                 residual: Optional[torch.Tensor] = None, relu: bool = False, y_act: Optional[torch.Tensor] = None,
-                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None, split_products: int = 0,
+                act_scale: Optional[torch.Tensor] = None, act_shift: Optional[torch.Tensor] = None,
                 splitk_ws: Optional[torch.Tensor] = None) -> None:
     """`splitk_ws` (fp32 scratch): lets launches whose tile grid cannot fill the chip split the K loop (deterministic two-pass).
     A float16 `x` (same padded-NHWC geometry) selects the half-precision input path (mp_conv_desc.x_f16; Cout <= 64 only)."""
@@ -294,10 +297,7 @@ def conv2d_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_border: int
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, stride, pad
     d.d_y, d.out_border, d.d_residual, d.relu = _ptr(y), out_border, _ptr(residual), int(relu)
     d.d_y_act, d.d_act_scale, d.d_act_shift = _ptr(y_act), _ptr(act_scale), _ptr(act_shift)
-    if split_products:
-        check(lib.mp_conv2d_nhwc_split(C.byref(d), split_products, _stream()))
-    else:
-        check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
+    check(lib.mp_conv2d_nhwc(C.byref(d), _stream()))
 
 
 def conv_wino_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
@@ -327,6 +327,35 @@ def conv3x3_wino_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_borde
     check(_lib.load().mp_conv3x3_wino_nhwc(C.byref(d), u_packed.data_ptr(), _stream()))
 
 
+def conv_stem_pack_weights(w_oihw: np.ndarray, n_f32: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
+    """three exact bf16 pieces of every stem weight (BN scale and, for the integer channels, 1/255 folded in) in MFMA fragment order
+    (mp_conv_stem_pack_weights); the first `n_f32` input channels are fp32-kind, the others 8-bit integers.  Returns a uint8 blob."""
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin, KH, KW = w.shape
+    assert KH == KW
+    out = np.empty(lib.mp_conv_stem_packed_bytes(KH, n_f32, Cin - n_f32, Cout), dtype=np.uint8)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    check(lib.mp_conv_stem_pack_weights(w.ctypes.data, Cout, Cin, KH, n_f32, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    return out
+
+
+def xrec_elements(n_f32: int, n_u8: int) -> int:
+    return int(_lib.load().mp_xrec_elements(n_f32, n_u8))
+
+
+def conv_stem_xrec(xrec: torch.Tensor, N: int, H: int, W: int, c_real: int, n_f32: int, in_border: int, w_pieces: torch.Tensor,
+                   bias: Optional[torch.Tensor], Cout: int, K: int, pad: int, y: torch.Tensor, out_border: int, relu: bool = False) -> None:
+    """stride-2 stem convolution of a bfloat16 record tensor (mp_conv_stem_xrec)"""
+    assert xrec.dtype == torch.bfloat16 and w_pieces.dtype == torch.uint8
+    d = ConvDesc()
+    d.d_x, d.N, d.H, d.W, d.C, d.c_real, d.in_border = xrec.data_ptr(), N, H, W, (c_real + 3) // 4 * 4, c_real, in_border
+    d.d_bias = _ptr(bias)
+    d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, 2, pad
+    d.d_y, d.out_border, d.relu = y.data_ptr(), out_border, int(relu)
+    check(_lib.load().mp_conv_stem_xrec(C.byref(d), w_pieces.data_ptr(), n_f32, _stream()))
+
+
 def conv2d_plan(N: int, H: int, W: int, Cp: int, in_border: int, Cout: int, K: int, stride: int, pad: int, n_cu: int,
                 ws_floats: int = 0, x_f16: bool = False) -> Dict[str, int]:
     """How mp_conv2d_nhwc would lay this launch out on `n_cu` CUs (host-only, no GPU work): mode 0 single pass, 1 every tile
@@ -344,17 +373,6 @@ def conv2d_plan(N: int, H: int, W: int, Cp: int, in_border: int, Cout: int, K: i
     return dict(zip(("mode", "k_split", "chunks_per_split", "n_main", "m_begin"), out))
 
 
-def conv_pack_weights_split(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
-    """bf16 (hi, mid, lo) pieces for the split-precision conv; returns a uint8 blob"""
-    lib = _lib.load()
-    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
-    Cout, Cin, KH, KW = w.shape
-    out = np.empty(lib.mp_conv_packed_split_bytes(cin_p, Cout, KH, KW), dtype=np.uint8)
-    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
-    check(lib.mp_conv_pack_weights_split(w.ctypes.data, Cout, Cin, KH, KW, cin_p, None if sc is None else sc.ctypes.data, out.ctypes.data))
-    return out
-
-
 def maxpool3x3s2(x, N, H, W, Cc, in_border, y, out_border, y_act=None, sc=None, sh=None) -> None:
     check(_lib.load().mp_maxpool3x3s2(x.data_ptr(), N, H, W, Cc, in_border, _ptr(y), out_border, _ptr(y_act), _ptr(sc), _ptr(sh),
                                       _stream()))
@@ -368,7 +386,7 @@ def pool_fc_heads(x, N, H, W, Cc, in_border, fc_w, fc_b, n_feat, head_w, head_b,
 class Backbone:
     """mp_backbone: whole CNN + head resident on the device, one call per forward."""
 
-    def __init__(self, kind: str, c_in: int, head: str, n_out: int, state_dict: Dict[str, torch.Tensor], precision: int = 0):
+    def __init__(self, kind: str, c_in: int, head: str, n_out: int, state_dict: Dict[str, torch.Tensor]):
         lib = _lib.load()
         width = 1
         if kind.startswith("resnet34_width="):   # training/pose_models_cfg.py:114-116: WideResNet34(width=int(...))
@@ -388,8 +406,7 @@ class Backbone:
         for i, (k, a) in enumerate(items):
             arr[i] = NamedTensor(k, a.ctypes.data, a.size)
         h = C.c_void_p()
-        check(lib.mp_backbone_create_wide(BACKBONE_KINDS[kind], width, c_in, 0 if head == "pose" else 1, n_out, arr, len(items), precision, C.byref(h)))
-        self.precision = precision
+        check(lib.mp_backbone_create_wide(BACKBONE_KINDS[kind], width, c_in, 0 if head == "pose" else 1, n_out, arr, len(items), C.byref(h)))
         self.handle = h
         self.kind, self.c_in, self.n_out = kind, c_in, n_out
         self.c_in_p = lib.mp_backbone_input_channels_padded(h)
@@ -409,11 +426,23 @@ class Backbone:
     def flops(self, batch: int, h: int, w: int) -> float:
         return _lib.load().mp_backbone_flops(self.handle, batch, h, w)
 
+    def xrec_elements(self, n_f32: int) -> int:
+        """Record length (bf16 elements per pixel) of the exact-piece stem input for `n_f32` leading fp32-kind channels (the observation
+        crop), all other input channels being 8-bit integers (renders); 0 = this stem has no such form (mp_backbone_xrec_elements)."""
+        return int(_lib.load().mp_backbone_xrec_elements(self.handle, int(n_f32)))
+
     def forward(self, x: torch.Tensor, batch: int, h: int, w: int, out: torch.Tensor, sigmoid: Optional[torch.Tensor] = None,
-                feat: Optional[torch.Tensor] = None, slot: int = 0) -> None:
+                feat: Optional[torch.Tensor] = None, slot: int = 0, n_f32: int = 3) -> None:
+        """x: fp32 padded NHWC | float16 (same geometry, mp_backbone_forward_f16) | bfloat16 stem records with `n_f32` fp32-kind
+        channels (what the rasteriser writes with MP_RASTER_XREC; mp_backbone_forward_xrec)."""
         ws = self.workspace(batch, h, w, x.device, slot)
-        assert x.dtype in (torch.float32, torch.float16)
-        fn = _lib.load().mp_backbone_forward_f16 if x.dtype == torch.float16 else _lib.load().mp_backbone_forward
+        assert x.dtype in (torch.float32, torch.float16, torch.bfloat16)
+        lib = _lib.load()
+        if x.dtype == torch.bfloat16:
+            check(lib.mp_backbone_forward_xrec(self.handle, x.data_ptr(), int(n_f32), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat),
+                                               ws.data_ptr(), ws.numel(), _stream()))
+            return
+        fn = lib.mp_backbone_forward_f16 if x.dtype == torch.float16 else lib.mp_backbone_forward
         check(fn(self.handle, x.data_ptr(), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()))
 
     def close(self):

@@ -103,7 +103,12 @@ class _RefinerGraph:
         self.pack = torch.zeros(n_iterations, rows, width, dtype=torch.float32, device=device)
         self.graph = torch.cuda.CUDAGraph()
         self._fill = None
-        self._model, self._n_iterations, self._slot = model, n_iterations, slot
+        # A captured call holds raw device addresses of the CNN-input buffer, the backbone workspace and the rasteriser workspace.  The
+        # eager path's per-slot buffers are grow-only (a later, larger eager call on the same slot reallocates them and the old storage
+        # goes back to the allocator), so every graph works on PRIVATE buffers under its own slot key: sized once for `rows`, never
+        # touched by any other call, released by PosePredictor._drop_graph.
+        self.slot_key = ("graph", rows, n_iterations, slot, id(self))
+        self._model, self._n_iterations, self._slot = model, n_iterations, self.slot_key
 
     def _body(self):
         m = self._model
@@ -217,8 +222,15 @@ class PosePredictor(nn.Module):
         # (renders + observation crop) as binary16 and the stem convolution widens it on its way into LDS; half the bytes of the
         # largest tensor of a step.  Narrower than the reference (fp32 inputs, models/pose_rigid.py:567): off by default.
         self.render_dtype: torch.dtype = torch.float32
+        # Stem records (default ON where they apply: RGB models, <= 32 input channels): the rasteriser launch stores every pixel of the
+        # CNN input as a bf16 RECORD -- the 8-bit integer k of each render channel (the reference's renders ARE k / 255,
+        # panda3d_batch_renderer.py:261-274) and three exact bf16 pieces of each fp32 crop channel -- and the stem convolution runs on
+        # the bf16 MFMA with the weights split into three exact pieces (csrc/conv_stem.hip): every product is exact, the sum is fp32,
+        # only the order of the fp32 additions differs from the fp32-MFMA stem.  MP_STEM_RECORDS=0 / stem_records=False: fp32 tensor.
+        self.stem_records: bool = os.environ.get("MP_STEM_RECORDS", "1") != "0"
         self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
         self._x_rows: Dict[int, int] = {}
+        self._x_cp: Dict[int, int] = {}
         self._label_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         # hipGraph capture of small refiner calls (n_iterations x ~45 launches for a handful of rows): calls of at most `graph_rows`
         # rows are captured once per (rows, frame shape, n_iterations, slot) and replayed.  OFF by default (0): measured on the MI355X
@@ -230,43 +242,68 @@ class PosePredictor(nn.Module):
 
     # -- engine plumbing -----------------------------------------------------------------------------------------
     def load_state_dict(self, *args, **kwargs):
-        self._engine_bb = None
         self.invalidate_graphs()   # captured refiner calls hold the old engine's device pointers
+        self._engine_bb = None
         return super().load_state_dict(*args, **kwargs)
 
     def invalidate_graphs(self) -> None:
         """Drop the captured refiner calls (`graph_rows` > 0): needed whenever the engine backbone, the renderer's mesh database or a
-        mode such as `conv_precision` changes after a capture; `load_state_dict` does it itself."""
-        self._graphs.clear()
+        mode such as `stem_records` / `render_dtype` changes after a capture; `load_state_dict` does it itself."""
+        for key in list(self._graphs):
+            self._drop_graph(key)
         self._graph_seen.clear()
+
+    def _drop_graph(self, key) -> None:
+        """forget one captured call and release the private buffers it ran on (CNN input, backbone / rasteriser workspaces)"""
+        g = self._graphs.pop(key, None)
+        if g is None:
+            return
+        sk = g.slot_key
+        self._x.pop(sk, None); self._x_rows.pop(sk, None); self._x_cp.pop(sk, None)
+        if self._engine_bb is not None:
+            self._engine_bb._ws.pop(sk, None)
+        db = getattr(self.renderer, "_mesh_db", None)
+        if db is not None:
+            db._ws.pop(sk, None)
 
     def _backbone_engine(self) -> eng.Backbone:
         if self._engine_bb is None:
             head, n_out = ("pose", 9) if self.predict_pose_update else ("logits", self.n_rendered_views)
-            # conv_precision: 0 = native fp32 MFMA (default); 9 / 6 = optional bf16 split modes (csrc/conv_split.hip)
-            self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict(),
-                                           precision=int(getattr(self, "conv_precision", 0)))
+            self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict())
         return self._engine_bb
+
+    def _record_len(self) -> int:
+        """bf16 elements per pixel if this model's CNN input is staged as stem records (see `stem_records`), else 0."""
+        if (not self.stem_records or self.render_dtype != torch.float32 or self.input_depth or self.render_depth
+                or self.backbone.n_inputs > 32):   # (one rasteriser launch must write the whole record: <= 32 channels)
+            return 0
+        return self._backbone_engine().xrec_elements(self._n_input_channels)
+
+    def _x_layout(self) -> Tuple[torch.dtype, int]:
+        """(element type, elements per pixel) of the CNN input tensor"""
+        R = self._record_len()
+        return (torch.bfloat16, R) if R else (self.render_dtype, self._backbone_engine().c_in_p)
 
     def _x_buffer(self, rows: int, device, slot: int = 0) -> torch.Tensor:
         bb = self._backbone_engine()
         h, w = self.render_size
         if self.render_dtype not in (torch.float32, torch.float16):
             raise ValueError(f"render_dtype must be torch.float32 or torch.float16, got {self.render_dtype}")
-        if self.render_dtype == torch.float16 and int(getattr(self, "conv_precision", 0)) != 0:
-            raise NotImplementedError("render_dtype=float16 needs the native fp32 backbone (conv_precision 0)")
+        dtype, Cp = self._x_layout()
         x = self._x.get(slot)
-        if x is None or self._x_rows[slot] < rows or x.device != device or x.dtype != self.render_dtype:
+        if x is None or self._x_rows[slot] < rows or x.device != device or x.dtype != dtype or self._x_cp.get(slot) != Cp:
             self._x.pop(slot, None)
-            self._x[slot] = x = eng.padded_nhwc(rows, h, w, bb.c_in_p, bb.in_border, device, dtype=self.render_dtype)
+            self._x[slot] = x = eng.padded_nhwc(rows, h, w, Cp, bb.in_border, device, dtype=dtype)
             self._x_rows[slot] = rows
+            self._x_cp[slot] = Cp
         return x
 
     def _x_geometry(self):
         bb = self._backbone_engine()
         h, w = self.render_size
-        Wp, Hp, Cp, B = w + 2 * bb.in_border, h + 2 * bb.in_border, bb.c_in_p, bb.in_border
-        return Hp * Wp * Cp, Wp * Cp, Cp, (B * Wp + B) * Cp  # stride_row, stride_y, stride_x, interior offset
+        Cp = self._x_layout()[1]
+        Wp, Hp, B = w + 2 * bb.in_border, h + 2 * bb.in_border, bb.in_border
+        return Hp * Wp * Cp, Wp * Cp, Cp, (B * Wp + B) * Cp  # stride_row, stride_y, stride_x, interior offset (in elements)
 
     def _ids(self, labels: Sequence[str], device) -> Tuple[torch.Tensor, torch.Tensor]:
         key = (tuple(labels), str(device))
@@ -287,7 +324,17 @@ class PosePredictor(nn.Module):
     def _nchw_view(self, rows: int, c0: int, c1: int, slot: int = 0) -> torch.Tensor:
         bb = self._backbone_engine()
         h, w = self.render_size
-        v = eng.padded_view(self._x[slot], self._x_rows[slot], h, w, bb.c_in_p, bb.in_border)[:rows, :, :, c0:c1].permute(0, 3, 1, 2)
+        x = self._x[slot]
+        Cp = self._x_cp[slot]
+        v = eng.padded_view(x, self._x_rows[slot], h, w, Cp, bb.in_border)[:rows]
+        if x.dtype == torch.bfloat16:   # stem records -> the fp32 channels they stand for: x1 + x2 + x3 (exact), k / 255
+            nf = self._n_input_channels
+            pieces = v[..., : 3 * nf].float().reshape(rows, h, w, nf, 3)
+            crop = (pieces[..., 0] + pieces[..., 1]) + pieces[..., 2]
+            # (a tensor divisor: torch's GPU division by a Python scalar multiplies by the reciprocal, which is not k / 255 rounded once)
+            rend = v[..., 3 * nf : 3 * nf + (self.backbone.n_inputs - nf)].float() / torch.full((), 255.0, device=x.device)
+            return torch.cat([crop, rend], dim=-1)[..., c0:c1].permute(0, 3, 1, 2)
+        v = v[:, :, :, c0:c1].permute(0, 3, 1, 2)
         return v if v.dtype == torch.float32 else v.float()   # (fp16 renders mode: callers always see fp32 crops / renders)
 
     def _packed(self, images: torch.Tensor) -> "eng.PackedObservation":
@@ -358,12 +405,12 @@ class PosePredictor(nn.Module):
         if self.render_depth:
             d0 = nin + (6 if self.render_normals else 3)
             depth_ch += [d0 + nper * v for v in range(V)]
-        if depth_ch and mode:
+        if depth_ch and mode:   # (depth models never stage records: _record_len)
             eng.normalize_depth(x, b, h, w, bb.in_border, bb.c_in_p, depth_ch, tCR, mode)
         n_out = bb.n_out
         out = torch.empty(b, n_out, dtype=torch.float32, device=device)
         sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
-        bb.forward(x, b, h, w, out, sig, slot=slot)
+        bb.forward(x, b, h, w, out, sig, slot=slot, n_f32=nin)
         if ev is not None:
             ev[2].record()
         return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, K_crop=K_main, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,
@@ -453,7 +500,8 @@ class PosePredictor(nn.Module):
             if seen == 0:
                 return None
             if len(self._graphs) >= 32:
-                self._graphs.clear()
+                for old in list(self._graphs):
+                    self._drop_graph(old)
             g = self._graphs[key] = _RefinerGraph(self, b, n_iterations, slot, packed, device)
         res = g.run(TCO, K, im_ids, ids, packed)
         V = self.n_rendered_views

@@ -20,7 +20,7 @@ from . import synthetic as syn
 
 
 def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
-                    seeds=(11, 12), precision: int = 0, pose_head_scale: float = syn.POSE_HEAD_SCALE, **est_kwargs) -> PoseEstimator:
+                    seeds=(11, 12), pose_head_scale: float = syn.POSE_HEAD_SCALE, **est_kwargs) -> PoseEstimator:
     """Seeded random-weight coarse + refiner models in the released recipes' structure, on the HIP engine."""
     renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
     mesh_db = MeshDataBase.from_object_ds(object_dataset).batched().cuda()
@@ -30,7 +30,6 @@ def build_estimator(object_dataset, backbone: str = "vanilla_resnet34", rgbd: bo
         head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
         sd = syn.make_state_dict(backbone, syn.n_inputs_for(cfg), head, n_out, seed=seed, pose_head_scale=pose_head_scale)
         models[role] = build_pose_model(cfg, sd, renderer, mesh_db)
-        models[role].conv_precision = precision
     return PoseEstimator(refiner_model=models["refiner"], coarse_model=models["coarse"], SO3_grid_size=SO3_grid_size, **est_kwargs)
 
 
@@ -67,11 +66,11 @@ def render_observation(renderer: Panda3dBatchRenderer, labels: List[str], poses:
 
 
 def make_scene(n_objects: int = 1, seed: int = 0, backbone: str = "vanilla_resnet34", rgbd: bool = False, SO3_grid_size: int = 576,
-               tmp_dir: Optional[str] = None, precision: int = 0, **est_kwargs):
+               tmp_dir: Optional[str] = None, **est_kwargs):
     """-> (estimator, observation, detections, gt_poses)"""
     tmp = Path(tmp_dir or tempfile.mkdtemp(prefix="mp_scene_"))
     ds = syn.make_object_dataset(tmp, n_objects=n_objects, seed=seed)
-    est = build_estimator(ds, backbone, rgbd, SO3_grid_size, precision=precision, **est_kwargs)
+    est = build_estimator(ds, backbone, rgbd, SO3_grid_size, **est_kwargs)
     rng = np.random.RandomState(seed + 100)
     labels = [o.label for o in ds.list_objects]
     poses = np.stack([syn.random_pose(rng, z_range=(0.45, 0.7), xy_frac=0.12 if n_objects == 1 else 0.3) for _ in labels])

@@ -491,53 +491,6 @@ def test_pose_ops_vs_oracle(eng, engine_meshes):
     assert (got - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_CASES[5], CONV_CASES[7]])
-@pytest.mark.parametrize("nprod", [9, 6])
-def test_conv_bf16_split_modes_match_torch_fp32(eng, case, nprod):
-    """optional fast mode (csrc/conv_split.hip): exact 3-way bf16 operand split; bf16x9 must sit in the same fp32 error class as
-    the native fp32-MFMA path (same 2e-4 bound), bf16x6 drops pairs weighing <= 2^-24 (same bound)."""
-    N, Cin, H, W, Cout, K, s, p, ib = case
-    g = torch.Generator().manual_seed(hash(case) % 1000 + nprod)
-    x = torch.randn(N, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5
-    scale = torch.rand(Cout, generator=g) + 0.5
-    bias = torch.randn(Cout, generator=g) * 0.1
-    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
-    res = torch.randn(N, Cout, Ho, Wo, generator=g)
-    cp = (Cin + 3) // 4 * 4
-    xb = _to_padded(eng, x, cp, ib)
-    wp = torch.from_numpy(eng.conv_pack_weights_split(w.numpy(), cp, scale.numpy())).cuda()
-    yb = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda")
-    eng.conv2d_nhwc(xb, N, H, W, cp, ib, wp, bias.cuda(), Cout, K, s, p, yb, 1, residual=_to_padded(eng, res, Cout, 1), relu=True,
-                    split_products=nprod)
-    torch.cuda.synchronize()
-    ref64 = F.relu(F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride=s, padding=p) + res.double())
-    ref32 = F.relu(F.conv2d(x, w * scale.view(-1, 1, 1, 1), bias, stride=s, padding=p) + res)
-    got = _from_padded(eng, yb, N, Ho, Wo, Cout, 1)
-    err_split = (got.double() - ref64).abs().max().item()
-    err_fp32 = (ref32.double() - ref64).abs().max().item()  # what plain fp32 (torch CPU) loses against fp64
-    assert err_split < 2e-4 * max(1.0, ref64.abs().max().item())
-    assert err_split < 8 * err_fp32 + 1e-6, (err_split, err_fp32)  # same error class as fp32 arithmetic
-
-
-def test_backbone_bf16x9_matches_oracle(eng):
-    from tests.support import synthetic as syn
-    from oracle import backbones as ob
-
-    sd = syn.make_state_dict("vanilla_resnet34", 27, "pose", 9, seed=1)
-    bb = eng.Backbone("vanilla_resnet34", 27, "pose", 9, sd, precision=9)
-    b, h, w = 2, 240, 320
-    x = torch.rand(b, 27, h, w, generator=torch.Generator().manual_seed(0))
-    xb = _to_padded(eng, x, bb.c_in_p, bb.in_border)
-    out = torch.empty(b, 9, device="cuda")
-    feat = torch.empty(b, 512 * getattr(bb, "width", 1), device="cuda")
-    bb.forward(xb, b, h, w, out, None, feat)
-    torch.cuda.synchronize()
-    ref = ob.net_forward(sd, "vanilla_resnet34", x)
-    assert (feat.cpu() - ref["features"]).abs().max().item() < 2e-4 * max(1.0, ref["features"].abs().max().item())
-    assert (out.cpu() - ref["pose"]).abs().max().item() < 2e-4
-
-
 @pytest.mark.parametrize("shape", [(64, 64, 60, 80), (128, 128, 30, 40), (256, 256, 15, 20), (128, 256, 15, 20)])
 def test_conv_full_rounds_plus_splitk_tail(eng, shape):
     """a grid of ~600 tiles on 512 resident workgroups: the first 512 tiles run single-pass, the ~88 tail tiles split K and are

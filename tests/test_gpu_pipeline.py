@@ -252,28 +252,6 @@ def test_row_sharded_pipeline_two_ranks_matches_single_rank(backend):
     assert np.array_equal(res[0][1], res[1][1])  # every rank returns the identical full result
 
 
-@pytest.mark.parametrize("precision", [9, 6])
-def test_pipeline_split_precision_modes_match_reference_golden(precision):
-    """the optional bf16x9 / bf16x6 conv modes must meet the SAME end-to-end bounds against the reference's golden outputs"""
-    from tests.support import synthetic as syn
-    from tests.support.scene import build_estimator
-
-    ds = syn.make_object_dataset(tempfile.mkdtemp(prefix="mp_sp_"), n_objects=1, seed=0)
-    est = build_estimator(ds, SO3_grid_size=72, precision=precision)
-    g, obs, det = _golden_inputs()
-    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=3, n_pose_hypotheses=2)
-    scale = max(1.0, float(np.abs(g["coarse_logits"]).max()))
-    lg = extra["coarse"]["data"]["logits"].cpu().numpy().flatten()
-    assert_logits_close(lg, g["coarse_logits"], scale)
-    hyp = extra["coarse_filter"]["preds"].infos["hypothesis_id"].tolist()
-    assert sorted(hyp) == sorted(g["filtered_hyp_ids"].tolist())
-    order = [hyp.index(h) for h in g["filtered_hyp_ids"].tolist()]
-    for n in range(1, 4):
-        p = extra["refiner_all_hypotheses"]["preds"][f"iteration={n}"]
-        assert np.abs(p.poses.cpu().numpy()[order] - g[f"refiner_poses_{n}"]).max() < 1e-4, n
-    assert np.abs(final.poses.cpu().numpy() - g["final_TCO"]).max() < 1e-4
-
-
 def test_bench_self_launches_two_ranks_over_rccl():
     """`python bench.py --gpus 2` outside torchrun must spawn its own ranks (torch.distributed.run, backend nccl) and print ONE line
     with n_gpus = 2 and the RCCL world size; skipped on a 1-GPU box"""

@@ -66,6 +66,38 @@ def test_graph_replay_is_bit_identical_to_the_eager_launches(object_dataset, row
     _same(runs[1][1], ref2, n_it)
 
 
+def test_replays_survive_larger_eager_calls_and_other_row_counts_in_between(object_dataset):
+    """A captured call holds raw device addresses.  The eager path's per-slot buffers are grow-only, so a larger eager call (or the warm-up
+    of another row count) on the same slot reallocates them: the captured calls therefore run on private buffers, and a replay after such
+    calls must still equal the eager result bit for bit."""
+    model = _model(object_dataset)
+    model.graph_rows = 8
+    n_it = 2
+
+    def call(rows, seed):
+        images, K, labels, T0, im_ids = _inputs(object_dataset, rows, seed)
+        return model(images=images, K=K, labels=labels, TCO=T0, n_iterations=n_it, im_ids=im_ids, materialize=False)
+
+    call(2, 1); call(2, 2)               # warm-up + capture of the 2-row call
+    assert len(model._graphs) == 1
+    model.graph_rows = 0
+    call(40, 3)                          # a larger eager call on the same slot: the slot's CNN-input / workspaces are reallocated
+    torch.cuda.empty_cache()             # ... and the old storage really leaves the process
+    model.graph_rows = 8
+    call(5, 4); call(5, 5)               # warm-up + capture of a second row count
+    assert len(model._graphs) == 2
+    got2, got5 = call(2, 6), call(5, 7)  # replays of both graphs
+    junk = torch.full((64 << 20,), float("nan"), device="cuda")   # whatever memory was freed above is now NaN
+    got2b = call(2, 6)
+    del junk
+    model.graph_rows = 0
+    _same(got2, call(2, 6), n_it)
+    _same(got2b, call(2, 6), n_it)
+    _same(got5, call(5, 7), n_it)
+    model.invalidate_graphs()
+    assert not model._graphs and not any(isinstance(k, tuple) for k in model._x)   # the private buffers are released with the graphs
+
+
 def test_graph_replay_timing_for_one_row(object_dataset):
     """Why the capture is off by default: the replay is not faster than the eager launches (measured 5.98 vs 5.96 ms) -- the call is
     bound by the device time of its dependent small-grid kernels.  The test reports both and only guards against a regression."""

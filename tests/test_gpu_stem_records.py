@@ -1,0 +1,173 @@
+"""-m gpu: the exact-piece bf16 stem path (csrc/conv_stem.hip + MP_RASTER_XREC + mp_backbone_forward_xrec).
+
+What it replaces: the first convolution behind `self.backbone(x)` (reference src/megapose/models/torchvision_resnet.py:213-216,
+models/wide_resnet.py:65-67) fed by the renders `uint8 / 255` of panda3d_batch_renderer.py:261-274.  Statements checked here:
+  * the rasteriser's record output holds EXACTLY the values of its fp32 output (k with k / 255 == the fp32 value, x1 + x2 + x3 == the
+    fp32 crop value): bit-exact decode;
+  * the stem convolution on records equals torch's fp32 conv2d on the decoded tensor to fp32 round-off (1e-5 of the output scale: the
+    products are exact, only the order of the fp32 additions differs), for 7x7 and 5x5 stems, ragged tiles, every record length;
+  * a whole backbone forward / a whole pose step on records equals the fp32-tensor path to 1e-5 of the feature scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from megapose6d_amd import engine
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return engine
+
+
+def split3(v: torch.Tensor):
+    """exact truncation split of fp32 values into three bf16-representable fp32 pieces"""
+    def trunc(t):
+        return (t.view(torch.int32) & -65536).view(torch.float32)
+    h = trunc(v)
+    r = v - h
+    m = trunc(r)
+    lo = r - m
+    assert torch.equal((h + m) + lo, v)
+    return h, m, lo
+
+
+def to_records(eng, x_nchw: torch.Tensor, n_f32: int, border: int) -> torch.Tensor:
+    """fp32 [n, c, h, w] whose channels >= n_f32 are k / 255 -> bf16 record tensor (padded NHWC)"""
+    n, c, h, w = x_nchw.shape
+    R = eng.xrec_elements(n_f32, c - n_f32)
+    buf = eng.padded_nhwc(n, h, w, R, border, "cuda", dtype=torch.bfloat16)
+    v = eng.padded_view(buf, n, h, w, R, border)
+    xl = x_nchw.permute(0, 2, 3, 1).cpu()
+    k = torch.round(xl[..., n_f32:] * 255.0)
+    assert torch.equal(k / 255.0, xl[..., n_f32:])   # (on the CPU: torch's GPU division by a scalar multiplies by the reciprocal)
+    xl, k = xl.cuda(), k.cuda()
+    pieces = torch.stack(split3(xl[..., :n_f32].contiguous()), dim=-1).reshape(n, h, w, 3 * n_f32)
+    v[..., : 3 * n_f32] = pieces.to(torch.bfloat16)
+    v[..., 3 * n_f32 : 3 * n_f32 + (c - n_f32)] = k.to(torch.bfloat16)
+    assert torch.equal(v[..., : 3 * n_f32].float(), pieces)   # the pieces really are bf16 values
+    return buf
+
+
+STEM_CASES = [
+    # N, n_f32, n_u8, H, W, K, Cout
+    (2, 3, 6, 32, 48, 7, 64),      # coarse stem, record of 16
+    (3, 3, 24, 30, 44, 7, 64),     # refiner stem, record of 40, ragged tiles (15 x 22 outputs)
+    (2, 3, 24, 26, 38, 5, 128),    # WideResNet stem, two channel blocks
+    (1, 3, 12, 24, 40, 7, 64),     # 2 views: record of 24
+    (2, 3, 18, 18, 34, 5, 64),     # 3 views: record of 32
+    (1, 4, 21, 17, 33, 7, 64),     # four fp32 channels (an RGBD-style crop without depth renders): record of 40
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_stem_conv_on_records_matches_torch_fp32(eng, case, relu):
+    N, nf, nu, H, W, K, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.cat([torch.randn(N, nf, H, W, generator=g) * 0.3 + 0.5,
+                   torch.randint(0, 256, (N, nu, H, W), generator=g).float() / 255.0], dim=1)
+    x[:, nf:, : H // 3] = 0.0   # background
+    w = torch.randn(Cout, nf + nu, K, K, generator=g) * (2.0 / ((nf + nu) * K * K)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    pad = K // 2
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    rec = to_records(eng, x, nf, pad)
+    wp = torch.from_numpy(eng.conv_stem_pack_weights(w.numpy(), nf, scale.numpy())).cuda()
+    yb = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda")
+    eng.padded_view(yb, N, Ho, Wo, Cout, 1)[:] = 7.0   # poison: the interior must be fully overwritten, the border untouched
+    eng.conv_stem_xrec(rec, N, H, W, nf + nu, nf, pad, wp, bias.cuda(), Cout, K, pad, yb, 1, relu=relu)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride=2, padding=pad)
+    if relu:
+        ref = F.relu(ref)
+    got = eng.padded_view(yb, N, Ho, Wo, Cout, 1).permute(0, 3, 1, 2).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+    full = yb[: N * (Ho + 2) * (Wo + 2) * Cout].view(N, Ho + 2, Wo + 2, Cout)
+    assert full[:, 0].abs().max() == 0 and full[:, -1].abs().max() == 0 and full[:, :, 0].abs().max() == 0 and full[:, :, -1].abs().max() == 0
+
+
+@pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 27)])
+def test_backbone_forward_on_records_matches_the_fp32_tensor_path(eng, kind, c_in):
+    from tests.support import synthetic as syn
+
+    sd = syn.make_state_dict(kind, c_in, "pose", 9, seed=4)
+    bb = eng.Backbone(kind, c_in, "pose", 9, sd)
+    R = bb.xrec_elements(3)
+    assert R == eng.xrec_elements(3, c_in - 3) and R in (16, 40)
+    b, h, w = 3, 240, 320
+    g = torch.Generator().manual_seed(c_in)
+    x = torch.cat([torch.rand(b, 3, h, w, generator=g), torch.randint(0, 256, (b, c_in - 3, h, w), generator=g).float() / 255.0], dim=1)
+    xb = eng.padded_nhwc(b, h, w, bb.c_in_p, bb.in_border, "cuda")
+    eng.padded_view(xb, b, h, w, bb.c_in_p, bb.in_border)[..., :c_in] = x.permute(0, 2, 3, 1).cuda()
+    rec = to_records(eng, x, 3, bb.in_border)
+    nf = 512
+    out0, out1 = torch.empty(b, 9, device="cuda"), torch.empty(b, 9, device="cuda")
+    f0, f1 = torch.empty(b, nf, device="cuda"), torch.empty(b, nf, device="cuda")
+    bb.forward(xb, b, h, w, out0, None, f0)
+    bb.forward(rec, b, h, w, out1, None, f1, n_f32=3)
+    torch.cuda.synchronize()
+    fs = max(1.0, f0.abs().max().item())
+    assert (f0 - f1).abs().max().item() < 1e-5 * fs, ((f0 - f1).abs().max().item(), fs)
+    assert (out0 - out1).abs().max().item() < 1e-5 * max(1.0, out0.abs().max().item())
+
+
+def test_rasteriser_record_output_holds_exactly_the_fp32_values(object_dataset):
+    """one refiner step (4 views + the fused crop) staged as records vs as the fp32 tensor: decoding the records gives the fp32 CNN
+    input bit for bit, and the network output agrees to fp32 round-off"""
+    from megapose6d_amd.load_model import build_pose_model
+    from megapose6d_amd.mesh_db import MeshDataBase
+    from megapose6d_amd.renderer import Panda3dBatchRenderer
+    from tests.support import synthetic as syn
+
+    for role in ("refiner", "coarse"):
+        cfg = syn.make_cfg(role)
+        head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
+        sd = syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), head, n_out, seed=5)
+        renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
+        model = build_pose_model(cfg, sd, renderer, MeshDataBase.from_object_ds(object_dataset).batched().cuda())
+        rng = np.random.RandomState(3)
+        rows = 5
+        labels = [object_dataset[int(i)].label for i in rng.randint(0, len(object_dataset.list_objects), rows)]
+        T0 = torch.from_numpy(np.stack([syn.random_pose(rng, (0.45, 0.6), 0.1) for _ in labels])).cuda()
+        K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None], rows, 0)).float().cuda()
+        images = (torch.round(torch.rand(rows, 3, 480, 640, generator=torch.Generator().manual_seed(1)) * 255) / 255).cuda()
+        res = {}
+        for records in (True, False):
+            model.stem_records = records
+            model._x.clear()
+            if role == "refiner":
+                out = model(images=images, K=K, labels=labels, TCO=T0, n_iterations=1)["iteration=1"]
+                net = out.network_outputs["pose"]
+            else:
+                out = model.forward_coarse(images=images, K=K, labels=labels, TCO_input=T0, return_debug_data=True)
+                net = out["logits"]
+            assert (model._x[0].dtype == torch.bfloat16) == records
+            n_in = syn.n_inputs_for(cfg)
+            res[records] = (model._nchw_view(rows, 0, n_in).clone(), net.clone())
+        assert torch.equal(res[True][0], res[False][0])
+        assert res[False][0][:, 3:].abs().max() > 0.1   # the renders are not empty
+        s = max(1.0, res[False][1].abs().max().item())
+        assert (res[True][1] - res[False][1]).abs().max().item() < 1e-5 * s
+
+
+def test_record_mode_is_refused_where_it_does_not_apply(eng):
+    """depth models / records outside 16..40 elements keep the fp32 tensor; the C entry point refuses what it cannot do"""
+    from megapose6d_amd._lib import EngineError
+    from tests.support import synthetic as syn
+
+    assert eng.xrec_elements(3, 24) == 40 and eng.xrec_elements(3, 6) == 16 and eng.xrec_elements(4, 28) == 40
+    sd = syn.make_state_dict("resnet34", 32, "pose", 9, seed=1)
+    bb = eng.Backbone("resnet34", 32, "pose", 9, sd)
+    assert bb.xrec_elements(3) == 40  # 3 * 3 + 29 = 38 -> 40 (the library could; PosePredictor never asks for a depth model)
+    assert bb.xrec_elements(32) == 0  # 96 elements: no
+    rec = eng.padded_nhwc(1, 240, 320, 40, 2, "cuda", dtype=torch.bfloat16)
+    out = torch.empty(1, 9, device="cuda")
+    with pytest.raises(EngineError):
+        bb.forward(rec, 1, 240, 320, out, None, None, n_f32=32)

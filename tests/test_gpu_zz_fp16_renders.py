@@ -137,11 +137,6 @@ def test_half_input_is_refused_where_it_is_not_implemented(eng):
     y = eng.padded_nhwc(1, 8, 8, 128, 1, "cuda")
     with pytest.raises(EngineError):   # Cout > 64
         eng.conv2d_nhwc(x, 1, 8, 8, 64, 1, torch.from_numpy(eng.conv_pack_weights(w, 64)).cuda(), None, 128, 3, 1, 1, y, 1)
-    w64 = np.zeros((64, 64, 3, 3), np.float32)
-    y64 = eng.padded_nhwc(1, 8, 8, 64, 1, "cuda")
-    with pytest.raises(EngineError):   # bf16 split modes
-        eng.conv2d_nhwc(x, 1, 8, 8, 64, 1, torch.from_numpy(eng.conv_pack_weights_split(w64, 64)).cuda(), None, 64, 3, 1, 1, y64, 1,
-                        split_products=9)
 
 
 @pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 32)])
