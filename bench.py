@@ -241,11 +241,10 @@ def extras(est, obs, det, steps: int) -> dict:
 
         tmp2 = tempfile.mkdtemp(prefix="mp_bench_extra_")
         try:
-            est2, obs2, det2, _, desc2, n_obj2, run2 = build_workload(cfg_id, 1, backbone, tmp2, 0, k_hyp)
+            est2, obs2, det2, _, desc2, n_obj2, run2 = build_workload(cfg_id, 1, backbone, tmp2, k_hyp)
             est2.run_inference_pipeline(obs2, detections=det2, **run2)
             torch.cuda.synchronize()
             eng_.profile_begin()
-            eng_.conv_wino_stats(reset=True)
             n_t = 2
             t0 = time.perf_counter()
             for _ in range(n_t):
@@ -253,14 +252,14 @@ def extras(est, obs, det, steps: int) -> dict:
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n_t
             prof2 = eng_.profile_end()
-            wd, we = eng_.conv_wino_stats(reset=True)
-            conv2 = {k: v for k, v in prof2.items() if k.startswith("conv_nhwc_f32") or k.startswith("conv3x3_wino")}
+            conv2 = {k: v for k, v in prof2.items() if k.startswith("conv") and k != "conv_splitk_reduce"}
             dom = max(conv2, key=lambda k: conv2[k]["ms"])
             rast = sum(v["ms"] for k, v in prof2.items() if k.startswith("raster_")) / n_t
             line = {"workload": desc2, "ms_per_call": dt * 1e3, "pose_hypotheses_per_s": n_obj2 * N_HYP / dt, "dominant_conv_kernel": dom,
                     "dominant_conv_tflops_algorithmic": conv2[dom]["flops"] / (conv2[dom]["ms"] * 1e-3) / 1e12,
+                    "dominant_conv_mfma_utilisation": conv2[dom]["executed"] / (conv2[dom]["ms"] * 1e-3) / 1e12 / conv2[dom]["peak_tflops"],
                     "all_conv_kernels_tflops_algorithmic": sum(v["flops"] for v in conv2.values()) / (sum(v["ms"] for v in conv2.values()) * 1e-3) / 1e12,
-                    "winograd_executed_over_algorithmic": (we / wd) if wd else None, "raster_ms_per_call": rast, "note": note}
+                    "raster_ms_per_call": rast, "note": note}
             del est2, obs2, det2
             torch.cuda.empty_cache()
             return line
@@ -393,7 +392,7 @@ def main():
     fence()
     mpd.stats.reset()
     eng.conv_clock(reset=True)
-    eng.conv_wino_stats(reset=True)
+    eng.conv_wino_bf16_clock(reset=True)
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -401,8 +400,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
-    wino_direct, wino_exec = eng.conv_wino_stats(reset=True)   # algorithmic vs executed FLOPs of the Winograd launches of the timed steps
-    conv_mhz = eng.conv_clock(reset=True)   # shader clock INSIDE the (direct) conv kernels of the timed steps
+    conv_mhz = eng.conv_clock(reset=True)   # shader clock INSIDE the (direct fp32) conv kernels of the timed steps
+    wb_mhz, wb_cps = eng.conv_wino_bf16_clock(reset=True)   # ... and inside the K loops of the bf16x9 Winograd launches (+ cycles per step)
     gather_ms = mpd.stats.ms() if world > 1 else 0.0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -416,62 +415,67 @@ def main():
 
     rc = 0
     if rank == 0:
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_nhwc_f32") or k.startswith("conv3x3_wino")}
+        conv = {k: v for k, v in prof.items() if k.startswith("conv")}
+        conv.pop("conv_splitk_reduce", None)
         dom_name = max(conv, key=lambda k: conv[k]["ms"])
         dom = conv[dom_name]
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # The Winograd kernel EXECUTES 16/36 of the algorithmic (direct-convolution) FLOPs its profiler row carries (SURVEY.md 8d counts
-        # 2 * MACs of the convolution), so its algorithmic rate may exceed the matrix peak; its MFMA utilisation is the executed rate.
-        wino = None
-        if wino_direct > 0:
-            wk = next(v for k, v in conv.items() if k.startswith("conv3x3_wino"))
-            wino = {"kernel": next(k for k in conv if k.startswith("conv3x3_wino")), "algorithm": "Winograd F(2x2,3x3), fp32 MFMA",
-                    "ms_per_step": wk["ms"] / a.steps, "algorithmic_tflops": wk["flops"] / (wk["ms"] * 1e-3) / 1e12,
-                    "executed_tflops": wk["flops"] * (wino_exec / wino_direct) / (wk["ms"] * 1e-3) / 1e12,
-                    "executed_over_algorithmic_flops": wino_exec / wino_direct}
-            wino["mfma_utilisation"] = wino["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS
+        # `frac` = the rate the dominant kernel EXECUTES on its matrix pipe / that pipe's dense peak (<= 1 by construction).  The algorithmic
+        # (direct-convolution) rate sits next to it: Winograd executes 16/36 of the algorithmic multiplications, the
+        # exact-piece kernels execute 9 (stem: 3 | 9) bf16 products per fp32 multiplication on the 16x faster bf16 pipe.
+        achieved = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
+        alg_rate = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        per_kernel = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "algorithmic_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                          "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2), "peak_tflops": v["peak_tflops"],
+                          "mfma_utilisation": round(v["executed"] / (v["ms"] * 1e-3) / 1e12 / v["peak_tflops"], 4)}
+                      for k, v in sorted(conv.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
         all_conv_tf = sum(v["flops"] for v in conv.values()) / (sum(v["ms"] for v in conv.values()) * 1e-3) / 1e12
-        conv_tf = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in conv.items() if v["ms"] > 0}
         kernel_ms = {k: round(v["ms"] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         rb = next((v for k, v in prof.items() if k.startswith("raster_")
                    and v["ms"] == max(vv["ms"] for kk, vv in prof.items() if kk.startswith("raster_"))), None)
         rb_name = next((k for k, v in prof.items() if v is rb), None)
         traffic, traffic_src, r_traffic = None, None, None
-        tfile = next((f for f in (ROOT / "profiles" / "r03_traffic.json", ROOT / "profiles" / "r02_traffic.json") if f.is_file()), None)
+        tfile = next((f for f in (ROOT / "profiles" / "r04_traffic.json", ROOT / "profiles" / "r03_traffic.json") if f.is_file()), None)
         if tfile is not None:  # PMC cannot be sampled from inside the process: committed rocprofv3 --pmc summary of the same command
             tj = json.loads(tfile.read_text())
             k = tj["kernels"].get(dom_name.replace(" ", ""))
             if k:
                 traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], tj["source"]
-            k = tj["kernels"].get(rb_name or "")
+            k = tj["kernels"].get((rb_name or "").replace(" ", ""))
             if k:
                 r_traffic = k["hbm_bytes_per_launch_corrected"]
+        bf16 = dom["peak_tflops"] > 1000.0
+        dom_mhz = wb_mhz if dom_name.startswith("conv3x3_wino_bf16") and wb_mhz > 0 else conv_mhz
         rows_per_obj = N_HYP + k_hyp * N_ITERS + k_hyp
         views_per_obj = N_HYP + 4 * k_hyp * N_ITERS + k_hyp
         sd = {s: extra_t[s]["data"] for s in ("coarse", "refiner", "scoring")}
         out = {
             "metric": METRIC, "value": n_obj * N_HYP * a.steps / dt, "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (results of fp32 arithmetic; the convolutions' multiplications run on the bf16 MFMA as EXACT piece products of the fp32 operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": desc, "baseline_config": a.config, "objects": n_obj, "n_pose_hypotheses": k_hyp,
                        "rows_per_step": n_obj * rows_per_obj, "evals_per_s": n_obj * rows_per_obj * a.steps / dt,
                        "views_per_step": n_obj * views_per_obj,
                        "parallelism": f"rows sharded rank::world over {world} GPU(s)", "arch": arch, "cus": n_cu},
-            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": dom["peak_tflops"], "unit": "TFLOP/s",
+                         "frac": achieved / dom["peak_tflops"],
+                         "executed_arithmetic": ("bf16 MFMA on exact pieces of the fp32 operands (each fp32 value = three bf16 pieces, all nine piece "
+                                                 "products, fp32 accumulate): every product exact" if bf16 else "fp32 MFMA"),
+                         "algorithmic_equiv": {"tflops": alg_rate, "over_fp32_mfma_peak": alg_rate / PEAK_FP32_MFMA_TFLOPS,
+                                               "note": "2 x MACs of the direct convolution (SURVEY.md 8d) / the same HIP-event time; may exceed the "
+                                                       "fp32 matrix peak because the kernel does not execute those FLOPs"},
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": dom["bytes"] / dom["launches"], "launches": dom["launches"],
-                         "avg_launch_ms": dom["ms"] / dom["launches"], "avg_launch_gflop": dom["flops"] / dom["launches"] / 1e9,
-                         "all_conv_kernels_tflops": all_conv_tf, "per_kernel_tflops": conv_tf, "winograd": wino,
-                         "note": ("`achieved` = algorithmic FLOPs (2 x MACs of the direct convolution, SURVEY.md 8d) / HIP-event time of the dominant "
-                                  "kernel, as the contract defines it.  Where that kernel is the Winograd one, `frac` can exceed 1: the kernel executes "
-                                  "16/36 of those FLOPs -- `winograd.mfma_utilisation` is its executed rate / peak (<= 1)") if wino else None,
-                         "shader_clock_mhz": conv_mhz,
-                         "frac_at_measured_clock": achieved / (PEAK_FP32_MFMA_TFLOPS * conv_mhz / 2400.0) if conv_mhz > 0 else None,
-                         "probe_clock_mhz": clk["shader_mhz"], "mfma_probe_tflops": clk["mfma_tflops"],
-                         "clock_note": "shader_clock_mhz = s_memtime / s_memrealtime accumulated INSIDE the conv kernels of the timed steps "
-                                       "(mp_conv_clock_read): real operands throttle this part to ~2.15 GHz, all-zero operands run at 2.38; "
-                                       "probe_* = a register-only MFMA loop right after the timed region (mp_clock_probe). `peak` is the 2400 MHz "
-                                       "figure and `frac` = achieved / peak as the contract defines it"},
+                         "avg_launch_ms": dom["ms"] / dom["launches"], "avg_launch_gflop_algorithmic": dom["flops"] / dom["launches"] / 1e9,
+                         "avg_launch_gflop_executed": dom["executed"] / dom["launches"] / 1e9,
+                         "all_conv_kernels_algorithmic_tflops": all_conv_tf, "per_kernel": per_kernel,
+                         "shader_clock_mhz": dom_mhz,
+                         "frac_at_measured_clock": achieved / (dom["peak_tflops"] * dom_mhz / 2400.0) if dom_mhz > 0 else None,
+                         "k_loop_cycles_per_16_channel_step": wb_cps if dom_name.startswith("conv3x3_wino_bf16") else None,
+                         "clock": {"bf16_winograd_k_loops_mhz": wb_mhz, "fp32_direct_kernels_mhz": conv_mhz, "probe_fp32_mfma_mhz": clk["shader_mhz"],
+                                   "probe_fp32_mfma_tflops": clk["mfma_tflops"],
+                                   "note": "s_memtime / s_memrealtime accumulated INSIDE the kernels of the timed steps (every 64th workgroup): the chip "
+                                           "clocks to its power budget, and bf16 MFMA work on real operands runs well below the 2400 MHz `peak` is "
+                                           "priced at; probe_* = a register-only fp32 MFMA loop right after the timed region (mp_clock_probe)"}},
             "raster": None if rb is None else {"bound": "hbm", "kernel": rb_name, "achieved": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9,
                                                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                                "traffic": r_traffic, "alg_bytes_per_launch": rb["bytes"] / rb["launches"],

@@ -42,6 +42,11 @@ int mp_profile_begin(void);
 int mp_profile_end(void);
 int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
                      double* total_bytes);
+/* the same + the FLOPs the launches EXECUTED on the matrix pipe (= the algorithmic figure for the direct kernels; 16/36 of it for the
+ * fp32 Winograd kernel; 9 bf16 piece products per Winograd multiplication / 3 or 9 per stem multiplication for the exact-piece kernels)
+ * and the dense peak (TFLOP/s) of the pipe they run on (157.3 fp32 MFMA, 2500 bf16 MFMA): executed / time / peak = MFMA utilisation */
+int mp_profile_query_ex(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
+                        double* total_bytes, double* total_executed_flops, double* peak_tflops);
 
 /* Shader clock under fp32-MFMA load: runs a register-only v_mfma_f32_32x32x2_f32 loop on every CU for `ms_target` milliseconds
  * (two workgroups of four waves per CU, operands rotating every instruction), synchronises, and returns the effective shader clock
@@ -235,6 +240,20 @@ int mp_conv_wino_eligible(const mp_conv_desc* desc, int n_cu);
 int mp_conv3x3_wino_nhwc(const mp_conv_desc* desc, const float* d_u, mp_stream stream);
 /* totals over the Winograd launches since the last reset: algorithmic (direct-convolution) FLOPs and the FLOPs actually executed */
 int mp_conv_wino_stats(double* direct_flops, double* executed_flops, int reset);
+
+/* The same fused Winograd convolution with its multiplications on the bf16 MFMA through EXACT operand pieces (csrc/conv_wino_bf16.hip):
+ * U = G g G^T and every fp32 fragment of V = B^T d B are split by truncation into three bf16 pieces (24 = 3 x 8 mantissa bits) and ALL
+ * nine piece products are accumulated in fp32 -- every product is exact, the result differs from mp_conv3x3_wino_nhwc only in the order
+ * of the fp32 additions -- at 9/16 of the fp32-MFMA matrix time.  Same descriptor, eligibility (mp_conv_wino_eligible) and read-slack
+ * contract; d_u_pieces = the blob of mp_conv_wino_bf16_pack_weights.  mp_conv_wino_bf16_stats: algorithmic (direct-convolution) FLOPs
+ * and executed bf16 FLOPs (9 x 16 per 2x2 tile and channel pair) since the last reset. */
+size_t mp_conv_wino_bf16_packed_bytes(int Cin_p, int Cout);
+int mp_conv_wino_bf16_pack_weights(const float* h_w_oi33, int Cout, int Cin, int Cin_p, const float* h_scale /*[Cout] or NULL*/, void* h_packed);
+int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* desc, const void* d_u_pieces, mp_stream stream);
+int mp_conv_wino_bf16_stats(double* direct_flops, double* executed_bf16_flops, int reset);
+/* effective shader clock (MHz) inside the K loops of the bf16 Winograd launches since the last reset and their shader cycles per
+ * 16-channel step (every 64th workgroup samples s_memtime / s_memrealtime); synchronises the device; 0.0 if none ran */
+int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int reset);
 
 /* Stem convolution on the bf16 MFMA through EXACT operand pieces (csrc/conv_stem.hip; same call site as mp_conv2d_nhwc for the first
  * layer: models/torchvision_resnet.py:213-216, models/wide_resnet.py:65-67).  The render channels of the CNN input are 8-bit integers

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mp_profile_begin": (_i, []),
     "mp_profile_end": (_i, []),
     "mp_profile_query": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mp_profile_query_ex": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mp_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "mp_mesh_db_create": (_i, [C.POINTER(MeshDesc), _i, C.POINTER(_vp)]),
     "mp_mesh_db_set_texture": (_i, [_vp, _i, _vp, _vp, _i, _i, _i]),
@@ -114,6 +116,11 @@ SIGNATURES = {
     "mp_conv_wino_eligible": (_i, [C.POINTER(ConvDesc), _i]),
     "mp_conv3x3_wino_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _vp]),
     "mp_conv_wino_stats": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
+    "mp_conv_wino_bf16_packed_bytes": (_sz, [_i, _i]),
+    "mp_conv_wino_bf16_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mp_conv3x3_wino_bf16_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _vp]),
+    "mp_conv_wino_bf16_stats": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
+    "mp_conv_wino_bf16_clock": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
     "mp_xrec_elements": (_i, [_i, _i]),
     "mp_conv_stem_supported": (_i, [_i, _i, _i]),
     "mp_conv_stem_packed_bytes": (_sz, [_i, _i, _i, _i]),

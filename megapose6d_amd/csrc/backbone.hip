@@ -19,7 +19,8 @@ namespace mp {
 struct ConvLayer {
   int Cin, Cin_p, Cout, K, stride, pad;
   float* d_w = nullptr;   // packed fp32 weights
-  float* d_u = nullptr;   // Winograd-transformed weights (conv_wino.hip) of an eligible 3x3 / stride-1 layer, native fp32 mode only
+  float* d_u = nullptr;   // Winograd-transformed weights of an eligible 3x3 / stride-1 layer: fp32 (conv_wino.hip, MP_CONV_WINO=1) ...
+  void* d_ub = nullptr;   // ... or split into three exact bf16 pieces (conv_wino_bf16.hip, the default)
   float* d_b = nullptr;  // folded BN shift (may be null)
 };
 
@@ -119,12 +120,21 @@ int make_conv(mp_backbone* bb, const StateMap& sm, const std::string& wkey, cons
   rc = mp_conv_pack_weights(w, Cout, Cin, K, K, Cin_p, bnkey.empty() ? nullptr : scale.data(), packed.data());
   if (rc) return rc;
   rc = upload(bb, packed, &L->d_w);
-  // 3x3 / stride-1 layers of the residual stages also get their Winograd F(2x2, 3x3) form (MP_CONV_WINO=0 keeps the direct kernel)
-  static const bool wino_on = !(getenv("MP_CONV_WINO") && atoi(getenv("MP_CONV_WINO")) == 0);
-  if (!rc && wino_on && K == 3 && stride == 1 && pad == 1 && Cin_p % 16 == 0 && Cout % 64 == 0) {
-    std::vector<float> u(mp_conv_wino_packed_floats(Cin_p, Cout));
-    rc = mp_conv_wino_pack_weights(w, Cout, Cin, Cin_p, bnkey.empty() ? nullptr : scale.data(), u.data());
-    if (!rc) rc = upload(bb, u, &L->d_u);
+  // 3x3 / stride-1 layers of the residual stages also get their Winograd F(2x2, 3x3) form.  MP_CONV_WINO: 2 (default) = the bf16x9
+  // exact-piece kernel, 1 = the fp32-MFMA kernel, 0 = keep the direct kernel
+  static const int wino_mode = getenv("MP_CONV_WINO") ? atoi(getenv("MP_CONV_WINO")) : 2;
+  if (!rc && wino_mode != 0 && K == 3 && stride == 1 && pad == 1 && Cin_p % 16 == 0 && Cout % 64 == 0) {
+    if (wino_mode == 1) {
+      std::vector<float> u(mp_conv_wino_packed_floats(Cin_p, Cout));
+      rc = mp_conv_wino_pack_weights(w, Cout, Cin, Cin_p, bnkey.empty() ? nullptr : scale.data(), u.data());
+      if (!rc) rc = upload(bb, u, &L->d_u);
+    } else {
+      std::vector<float> u((mp_conv_wino_bf16_packed_bytes(Cin_p, Cout) + 3) / 4);
+      rc = mp_conv_wino_bf16_pack_weights(w, Cout, Cin, Cin_p, bnkey.empty() ? nullptr : scale.data(), u.data());
+      float* d = nullptr;
+      if (!rc) rc = upload(bb, u, &d);
+      L->d_ub = d;
+    }
   }
   if (rc) return rc;
   if (!bnkey.empty()) {
@@ -157,14 +167,16 @@ int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, i
   if (y_act) { d.d_act_scale = act->d_scale; d.d_act_shift = act->d_shift; }
   d.d_splitk_ws = splitk_ws;
   d.splitk_ws_floats = splitk_ws ? (int64_t)SPLITK_WS_FLOATS : 0;
-  if (L.d_u && !x_f16) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
+  if ((L.d_u || L.d_ub) && !x_f16) {
+    static int n_cu = 0, n_cu_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (n_cu_dev != dev) {
       if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+      n_cu_dev = dev;
     }
-    if (mp_conv_wino_eligible(&d, n_cu)) return mp_conv3x3_wino_nhwc(&d, L.d_u, s);   // the workspace buffers carry the read slack it needs
+    if (mp_conv_wino_eligible(&d, n_cu))   // (the workspace buffers carry the read slack the Winograd kernels need)
+      return L.d_ub ? mp_conv3x3_wino_bf16_nhwc(&d, L.d_ub, s) : mp_conv3x3_wino_nhwc(&d, L.d_u, s);
   }
   return mp_conv2d_nhwc(&d, s);
 }

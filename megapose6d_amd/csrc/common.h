@@ -32,7 +32,9 @@ void set_error(const char* fmt, ...);
 // Optional per-launch HIP-event profiler (mp_profile_begin/end/query): events are recorded on the launch stream around
 // each instrumented kernel; aggregation happens at query time.  Disabled = zero overhead.
 struct ProfScope {
-  ProfScope(const char* name, double flops, double bytes, hipStream_t s);
+  // flops = ALGORITHMIC work (2 * MACs of the convolution); executed = the FLOPs the kernel really issues on the matrix
+  // pipe whose dense peak is peak_tflops (Winograd executes fewer fp32 FLOPs, the exact-piece kernels more bf16 ones); < 0 = flops
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s, double executed = -1.0, double peak_tflops = 157.3);
   ~ProfScope();
   int slot;
   hipStream_t stream;

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int KS, int Q>
 int launch(const Params& p, hipStream_t s, double flops, double bytes, const char* name) {
+  // executed on the bf16 pipe: every 16x16x32 MFMA of every step, three weight pieces (this counts the record padding, the step padding
+  // and the nine products of the fp32-kind channels as what they cost)
+  const double executed = 2.0 * (double)p.N * p.tiles_y * p.tiles_x * (TH * TW) * p.Cout * (double)p.n_steps * 32.0 * 3.0;
   using G = Geo<KS, Q>;
   static int attr_dev = -1;
   int dev = 0;
@@ -216,7 +219,7 @@ int launch(const Params& p, hipStream_t s, double flops, double bytes, const cha
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_bf16x3<KS, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
     attr_dev = dev;
   }
-  ProfScope prof(name, flops, bytes, s);
+  ProfScope prof(name, flops, bytes, s, executed, 2500.0);
   hipLaunchKernelGGL((conv_stem_bf16x3<KS, Q>), dim3((unsigned)((long)p.N * p.tiles_y * p.tiles_x * p.n_cb)), dim3(256), G::LDS, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;

@@ -22,51 +22,15 @@
 // Numerics: fp32 throughout; F(2x2, 3x3) in fp32 is ~2x the rounding error of the direct sum (3-6e-7 of the activation scale
 // on ResNet-shaped data) -- far inside the 1e-4 parity tolerance; results are deterministic.
 // Roofline: MFMA-bound; it EXECUTES 16/36 of the direct algorithm's FLOPs, so its algorithmic (direct-equivalent) rate can exceed
-// the matrix peak -- the profiler rows carry the executed FLOPs (`frac` <= 1 by construction) and bench.py reports both.
+// the matrix peak -- the profiler rows carry BOTH figures (mp_profile_query_ex): bench.py's `roofline.frac` is the executed rate / peak
+// (<= 1 by construction), the direct-equivalent rate sits next to it.
 #include <cstdlib>
 #include <vector>
 
-#include "common.h"
+#include "wino_common.h"
 
 namespace mp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int WT = 64;        // tiles per workgroup
-constexpr int WCK = 16;       // input channels per K step (two 8-channel MFMA half-steps)
-constexpr int WCOUT = 64;     // output channels per workgroup
-
-struct WinoParams {
-  const float* __restrict__ x;
-  const float* __restrict__ u;
-  const float* __restrict__ bias;
-  const float* __restrict__ residual;
-  const float* __restrict__ act_scale;
-  const float* __restrict__ act_shift;
-  float* __restrict__ y;
-  float* __restrict__ y_act;
-  int N, Ho, Wo;
-  int Hp, Wp, C;        // padded input geometry
-  int in_off;           // in_border - 1
-  int Cout;
-  int Hop, Wop, out_border;
-  int tiles_x, tiles_y, n_tiles;
-  int n_chunks;         // C / 8: 8-channel half-steps (the unit of the packed weights)
-  int n_steps;          // C / 16
-  int relu;
-  int n_cblocks;        // Cout / 64
-  int out_bytes;        // size of the output tensor (range check of the epilogue's buffer accesses)
-};
-
-__device__ __forceinline__ float4 buf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-// LDS: V[2][16][64][16] floats (128 KB) during the K loop; S[4][2][64][64] floats (128 KB) in the epilogue; + the tile table.
-constexpr int WV_STAGE = 16 * WT * WCK;                          // floats per V stage (64 KB)
-constexpr size_t WINO_LDS_BYTES = (size_t)4 * 2 * WT * WCOUT * sizeof(float) + (size_t)WT * 2 * sizeof(int);
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_f32(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -359,6 +323,11 @@ extern "C" int mp_conv_wino_eligible(const mp_conv_desc* d, int n_cu) {
   if (d->C % WCK != 0 || d->Cout % WCOUT != 0 || d->in_border < 1) return 0;   // 16 input channels per step, 64 output channels per workgroup
   const long tiles = (long)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
   const long wgs = ((tiles + WT - 1) / WT) * (d->Cout / WCOUT);
+  // the kernels address with 32-bit byte offsets: larger tensors (wide backbones at full batch) stay on the direct kernel
+  const long Hp = d->H + 2 * d->in_border, Wp = d->W + 2 * d->in_border;
+  const long in_bytes = ((long)d->N * Hp + 2) * Wp * d->C * 4;
+  const long out_elems = (long)d->N * (d->H + 2 * d->out_border) * (d->W + 2 * d->out_border) * d->Cout;
+  if (tiles >= (1L << 30) || in_bytes >= (1L << 31) || out_elems >= (1L << 29)) return 0;
   return wgs >= (long)n_cu ? 1 : 0;
 }
 
@@ -422,10 +391,12 @@ extern "C" int mp_conv3x3_wino_nhwc(const mp_conv_desc* d, const float* d_u, mp_
   p.n_steps = d->C / WCK;
   p.relu = d->relu;
   p.n_cblocks = d->Cout / WCOUT;
-  static bool attr_set = false;
-  if (!attr_set) {
+  int dev = 0;
+  MP_CHECK_HIP(hipGetDevice(&dev));
+  static int attr_dev = -1;
+  if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
-    attr_set = true;
+    attr_dev = dev;
   }
   const long n_wg = ((n_tiles + WT - 1) / WT) * p.n_cblocks;
   hipStream_t s = (hipStream_t)stream;
@@ -437,7 +408,7 @@ extern "C" int mp_conv3x3_wino_nhwc(const mp_conv_desc* d, const float* d_u, mp_
   const double direct = 2.0 * 9.0 * (double)d->N * d->H * d->W * c_real * d->Cout, executed = 2.0 * 16.0 * (double)n_tiles * c_real * d->Cout;
   g_wino_direct += direct;
   g_wino_executed += executed;
-  ProfScope prof("conv3x3_wino_f32<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout) + 16.0 * d->C * d->Cout), s);
+  ProfScope prof("conv3x3_wino_f32<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout) + 16.0 * d->C * d->Cout), s, executed, 157.3);
   hipLaunchKernelGGL(conv3x3_wino_f32, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;

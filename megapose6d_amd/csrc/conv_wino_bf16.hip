@@ -1,0 +1,527 @@
+// conv_wino_bf16.hip -- the fused Winograd F(2x2, 3x3) convolution with its 16 frequency-plane GEMMs on the bf16 MFMA through EXACT
+// operand pieces (v_mfma_f32_32x32x16_bf16), gfx950.
+//
+// Same call sites and the same structure as conv_wino.hip (reference: src/megapose/models/torchvision_resnet.py:74-120 BasicBlock
+// conv1 / conv2, src/megapose/models/wide_resnet.py:29-56 behind src/megapose/models/pose_rigid.py:323): workgroup = 64 tiles x 64
+// output channels, wave w owns row w of the 4x4 frequency grid, input transform V = B^T d B computed in fp32 and handed over through
+// the double-buffered fp32 LDS tile, output transform + fused epilogue in fp32.  What changes is the multiplication itself:
+//   * U = G g G^T (fp32, eval-BN scale folded) is split on the host by truncation into three bf16 pieces U = U1 + U2 + U3 EXACTLY
+//     (24 = 3 x 8 mantissa bits) and packed in MFMA fragment order;
+//   * every V fragment (8 fp32 channels per lane, straight from LDS) is split the same way in registers, V = V1 + V2 + V3 (4 VALU per
+//     element + the packing, issued in the shadow of the MFMAs);
+//   * sum_c V U = sum_c sum_{i,j} V_i U_j: ALL nine piece products are evaluated -- each is a bf16 x bf16 product, exact in the
+//     MFMA's fp32 accumulator -- so the result differs from the fp32-MFMA kernel only in the ORDER of fp32 additions (it is NOT a
+//     reduced-precision mode: no product is rounded, none is dropped).
+// Why: v_mfma_f32_32x32x16_bf16 retires 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32 -- nine piece products cost 9/16
+// of one fp32 product.  Together with Winograd's 16/36 the matrix time is 0.25 of the direct fp32 convolution's.
+// Per 16-channel step and wave: 16 ds_read_b128 (as before), 24 weight-fragment loads of 1 KB (L2 -> registers, one frequency point
+// ahead), 4 x 36 MFMAs of 32 cycles.  The schedule is hand-placed (sched_barrier fences, one wave per SIMD issues in order): every MFMA
+// is followed by <= 6 instructions of other work -- the split of the NEXT point's fragments (half an element pair per slot), the next
+// step's input-transform planes, patch / weight requests, fragment reads -- so that the matrix pipe never waits for the vector pipe.
+// Roofline: bf16 MFMA; algorithmic work = 2 * MACs of the direct convolution; executed = 9 x 16/36 of that in bf16 FLOPs.
+#include <cstdlib>
+#include <vector>
+
+#include "wino_common.h"
+
+namespace mp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// v_perm_b32 selector 0x07060302: {hi16(second arg) in the low half, hi16(first arg) in the high half}
+__device__ __forceinline__ unsigned pack_hi16(unsigned e1, unsigned e0) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+// the nine piece pairs (V piece, U piece), small terms first
+__device__ constexpr int WB_PA[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}, WB_PB[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
+
+constexpr int UB_F_BYTES = 2 * 3 * 1024;          // one frequency point of one step: [cout block j][piece][lane][16 B]
+constexpr int UB_STEP_BYTES = 16 * UB_F_BYTES;    // 96 KB per 16-channel step
+
+// Clock telemetry (as conv.hip's): every 64th workgroup adds the shader cycles (s_memtime), the 100 MHz real-time ticks (s_memrealtime)
+// and the number of steps of its K loop: mp_conv_wino_bf16_clock reports the effective shader clock and the cycles per 16-channel step.
+__device__ unsigned long long g_wb_clk[3];
+
+// DIAG (timing experiments only, wrong results; MP_WINO_DIAG): 1 = no split work, 2 = no patch requests / transform, 4 = no weight requests
+template <int DIAG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_bf16x9(WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;
+  int* tile_tab = (int*)(smem + 4 * 2 * WT * WCOUT);   // [64][2]: output element offset of pixel (2ty, 2tx) (-1: no such tile), validity bits
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int cb = wg % p.n_cblocks;      // channel block fastest: the workgroups that share an input tile set run together
+  const int tg = wg / p.n_cblocks;
+  const int tile0 = tg * WT;
+
+  if (tid < WT) {
+    const int t = tile0 + tid;
+    int off = -1, bits = 0;
+    if (t < p.n_tiles) {
+      const int tx = t % p.tiles_x, r = t / p.tiles_x;
+      const int ty = r % p.tiles_y, n = r / p.tiles_y;
+      off = ((n * p.Hop + 2 * ty + p.out_border) * p.Wop + 2 * tx + p.out_border) * p.Cout;
+      bits = ((2 * ty + 1 < p.Ho) ? 1 : 0) | ((2 * tx + 1 < p.Wo) ? 2 : 0);
+    }
+    tile_tab[2 * tid] = off;
+    tile_tab[2 * tid + 1] = bits;
+  }
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, -1, 0x00020000);
+  const int row_bytes = p.Wp * p.C * 4, pix_bytes = p.C * 4;
+  // weights: [cb][step][f][j][piece][lane][8 bf16]; this wave's four frequency points of a step are 24 KB contiguous
+  const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.u) + (size_t)cb * p.n_steps * UB_STEP_BYTES + (size_t)(4 * wave) * UB_F_BYTES;
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, -1, 0x00020000);
+  const int u_voff = lane * 16;
+
+  float4 patch[4][4];
+  const int ptile = tid >> 2, pc4 = tid & 3;
+  int x_voff;
+  {
+    int t = tile0 + ptile;
+    t = t < p.n_tiles ? t : p.n_tiles - 1;
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    const int ty = r % p.tiles_y, n = r / p.tiles_y;
+    const size_t pix = ((size_t)n * p.Hp + (size_t)(2 * ty + p.in_off)) * p.Wp + (size_t)(2 * tx + p.in_off);
+    x_voff = (int)((pix * p.C + pc4 * 4) * sizeof(float));
+  }
+  // V[stage][f][tile][16 floats], 16-byte slot s of a row holds channels 4s..4s+3, slots XOR-swizzled by (tile >> 2) & 3 (as conv_wino.hip)
+  float* vw = Vs + ptile * WCK + ((pc4 ^ ((ptile >> 2) & 3)) * 4);
+
+
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fi][i][j][r] = 0.f;
+
+  const int ns = p.n_steps;
+  u32x4 Ua[2][3], Ub[2][3];   // weight fragments [cout block][piece] of the current / the next frequency point
+  u32x4 AA[2][3], AB[2][3];   // V fragments [tile block][piece], likewise
+  float4 raw[2][2];           // fp32 fragment of the point after next: [tile block][channels 0..3 | 4..7 of the lane's K group]
+  unsigned sm0, sm1, sm2, sm3;            // the split in flight: masked values,
+  float sr0, sr1, sr2, sr3, sq0, sq1, sq2, sq3;   // first and second remainders of the four elements
+  float4 trw[4], tplane;      // row combination of the transform row in flight, the plane on its way to LDS
+  if (DIAG) {   // (timing experiments: whatever the skipped work would have produced just has to be defined)
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) { AA[i][q] = AB[i][q] = Ua[i][q] = Ub[i][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) { trw[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = make_float4(1.f, 1.f, 1.f, 1.f); }
+    tplane = make_float4(0.f, 0.f, 0.f, 0.f);
+    sm0 = sm1 = sm2 = sm3 = 0u; sr0 = sr1 = sr2 = sr3 = sq0 = sq1 = sq2 = sq3 = 0.f;
+  }
+#define WB_SB __builtin_amdgcn_sched_barrier(0);
+#define WB_LOAD_U1(DST, ST, FI, K) \
+  if (!(DIAG & 4)) DST[(K) / 3][(K) % 3] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (ST) * UB_STEP_BYTES + (FI) * UB_F_BYTES + (K) * 1024, 0);
+#define WB_LOAD_PATCH1(A, B, CS) if (!(DIAG & 2)) patch[A][B] = buf4(x_rsrc, x_voff, (CS) + (A) * row_bytes + (B) * pix_bytes);
+  // transform row A of the patch in registers: T(A, b) forms the row combination (B^T d)[A][b]; O(A, col) one frequency plane -> LDS
+#define WB_F4ASM(OP, D, X, Y)                                                                             \
+  asm volatile(OP " %0, %4, %8\n\t" OP " %1, %5, %9\n\t" OP " %2, %6, %10\n\t" OP " %3, %7, %11"           \
+               : "=&v"(D.x), "=&v"(D.y), "=&v"(D.z), "=&v"(D.w)                                            \
+               : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
+#define WB_TR_T(A, B)                                                                                    \
+  if (DIAG & 2) {} else if ((A) == 0) { WB_F4ASM("v_sub_f32", trw[B], patch[0][B], patch[2][B]) }                              \
+  else if ((A) == 1) { WB_F4ASM("v_add_f32", trw[B], patch[1][B], patch[2][B]) }                         \
+  else if ((A) == 2) { WB_F4ASM("v_sub_f32", trw[B], patch[2][B], patch[1][B]) }                         \
+  else { WB_F4ASM("v_sub_f32", trw[B], patch[1][B], patch[3][B]) }
+  // Exact truncation split of the four elements of raw[I][H] (elements 4H .. 4H+3 of fragment I) into the three pieces of AN, spread over
+  // four slots so that no instruction of a slot depends on another one of the same slot (one wave per SIMD issues in order: a dependent
+  // VALU pair stalls for the pipeline latency, and that stall comes straight out of the MFMA shadow):
+  //   S0: m = v & hi16, piece-1 pairs (v_perm of the unmasked v)      S1: r = v - m
+  //   S2: n = r & hi16, piece-2 pairs (v_perm of the unmasked r)      S3: q = r - n      (S4, in the next block's S0: piece-3 pairs of q)
+  // (inline asm: the compiler's machine-sink pass otherwise moves every `and` next to the `sub` that consumes it -- sched_barrier fences
+  //  only the scheduler -- and the dependent pairs are back)
+#define WB_SP0(AN, I, H)                                                                                 \
+  if (!(DIAG & 1)) {                                                                                                     \
+    unsigned p0_, p1_;                                                                                  \
+    asm volatile("v_and_b32 %0, 0xffff0000, %6\n\tv_and_b32 %1, 0xffff0000, %7\n\tv_and_b32 %2, 0xffff0000, %8\n\t"                \
+                 "v_and_b32 %3, 0xffff0000, %9\n\tv_perm_b32 %4, %7, %6, %10\n\tv_perm_b32 %5, %9, %8, %10"                       \
+                 : "=&v"(sm0), "=&v"(sm1), "=&v"(sm2), "=&v"(sm3), "=&v"(p0_), "=&v"(p1_)                                         \
+                 : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w), "s"(0x07060302u));                     \
+    AN[I][0][2 * (H)] = p0_; AN[I][0][2 * (H) + 1] = p1_;                                               \
+  }
+#define WB_SP1(I, H)                                                                                     \
+  if (!(DIAG & 1)) asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11"                    \
+               : "=&v"(sr0), "=&v"(sr1), "=&v"(sr2), "=&v"(sr3)                                                                   \
+               : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w), "v"(sm0), "v"(sm1), "v"(sm2), "v"(sm3));
+#define WB_SP2(AN, I, H)                                                                                 \
+  if (!(DIAG & 1)) {                                                                                                     \
+    unsigned p0_, p1_;                                                                                  \
+    asm volatile("v_and_b32 %0, 0xffff0000, %6\n\tv_and_b32 %1, 0xffff0000, %7\n\tv_and_b32 %2, 0xffff0000, %8\n\t"                \
+                 "v_and_b32 %3, 0xffff0000, %9\n\tv_perm_b32 %4, %7, %6, %10\n\tv_perm_b32 %5, %9, %8, %10"                       \
+                 : "=&v"(sm0), "=&v"(sm1), "=&v"(sm2), "=&v"(sm3), "=&v"(p0_), "=&v"(p1_)                                         \
+                 : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3), "s"(0x07060302u));                                                     \
+    AN[I][1][2 * (H)] = p0_; AN[I][1][2 * (H) + 1] = p1_;                                               \
+  }
+#define WB_SP3()                                                                                         \
+  if (!(DIAG & 1)) asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11"                    \
+               : "=&v"(sq0), "=&v"(sq1), "=&v"(sq2), "=&v"(sq3)                                                                   \
+               : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3), "v"(sm0), "v"(sm1), "v"(sm2), "v"(sm3));
+#define WB_SP4(AN, I, H)                                                                                 \
+  if (!(DIAG & 1)) {                                                                                                     \
+    unsigned p0_, p1_;                                                                                  \
+    asm volatile("v_perm_b32 %0, %3, %2, %6\n\tv_perm_b32 %1, %5, %4, %6"                                \
+                 : "=&v"(p0_), "=&v"(p1_) : "v"(sq0), "v"(sq1), "v"(sq2), "v"(sq3), "s"(0x07060302u));   \
+    AN[I][2][2 * (H)] = p0_; AN[I][2][2 * (H) + 1] = p1_;                                               \
+  }
+#define WB_READ_RAW1(VB, FI, K) \
+  raw[(K) >> 1][(K) & 1] = *reinterpret_cast<const float4*>((VB) + (FI) * (WT * WCK) + ((K) >> 1) * (32 * WCK) + (((K) & 1) ? fo_hi : fo_lo));
+  // MFMA of slot S (0..35): piece pair S / 4 (small terms first), accumulator (tile block, cout block) = S % 4
+#define WB_M(S, AC, UC)                                                                                  \
+  acc[fi][((S) & 3) >> 1][(S) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                            \
+      __builtin_bit_cast(bf16x8, AC[((S) & 3) >> 1][WB_PA[(S) >> 2]]), __builtin_bit_cast(bf16x8, UC[(S) & 1][WB_PB[(S) >> 2]]), \
+      acc[fi][((S) & 3) >> 1][(S) & 1], 0, 0, 0);
+  // slots 0..15 of a group: the split of the NEXT point's fragments + the six weight requests of the next point
+#define WB_HEAD(AC, AN, UC, UN, NST, NFI)                                                                \
+  WB_M(0, AC, UC) WB_SB WB_SP0(AN, 0, 0) WB_SB                                                           \
+  WB_M(1, AC, UC) WB_SB WB_SP1(0, 0) WB_LOAD_U1(UN, NST, NFI, 0) WB_SB                                   \
+  WB_M(2, AC, UC) WB_SB WB_SP2(AN, 0, 0) WB_SB                                                           \
+  WB_M(3, AC, UC) WB_SB WB_SP3() WB_LOAD_U1(UN, NST, NFI, 1) WB_SB                                       \
+  WB_M(4, AC, UC) WB_SB WB_SP4(AN, 0, 0) WB_SP0(AN, 0, 1) WB_SB                                          \
+  WB_M(5, AC, UC) WB_SB WB_SP1(0, 1) WB_LOAD_U1(UN, NST, NFI, 2) WB_SB                                   \
+  WB_M(6, AC, UC) WB_SB WB_SP2(AN, 0, 1) WB_SB                                                           \
+  WB_M(7, AC, UC) WB_SB WB_SP3() WB_LOAD_U1(UN, NST, NFI, 3) WB_SB                                       \
+  WB_M(8, AC, UC) WB_SB WB_SP4(AN, 0, 1) WB_SP0(AN, 1, 0) WB_SB                                          \
+  WB_M(9, AC, UC) WB_SB WB_SP1(1, 0) WB_LOAD_U1(UN, NST, NFI, 4) WB_SB                                   \
+  WB_M(10, AC, UC) WB_SB WB_SP2(AN, 1, 0) WB_SB                                                          \
+  WB_M(11, AC, UC) WB_SB WB_SP3() WB_LOAD_U1(UN, NST, NFI, 5) WB_SB                                      \
+  WB_M(12, AC, UC) WB_SB WB_SP4(AN, 1, 0) WB_SP0(AN, 1, 1) WB_SB                                         \
+  WB_M(13, AC, UC) WB_SB WB_SP1(1, 1) WB_SB                                                              \
+  WB_M(14, AC, UC) WB_SB WB_SP2(AN, 1, 1) WB_SB                                                          \
+  WB_M(15, AC, UC) WB_SB WB_SP3() WB_SB
+  // one frequency plane of the transform row in flight -> tplane (written to LDS one slot later: the store does not wait for its data)
+#define WB_TR_P(COL)                                                                                     \
+  if (DIAG & 2) {} else if ((COL) == 0) { WB_F4ASM("v_sub_f32", tplane, trw[0], trw[2]) }                                      \
+  else if ((COL) == 1) { WB_F4ASM("v_add_f32", tplane, trw[1], trw[2]) }                                 \
+  else if ((COL) == 2) { WB_F4ASM("v_sub_f32", tplane, trw[2], trw[1]) }                                 \
+  else { WB_F4ASM("v_sub_f32", tplane, trw[1], trw[3]) }
+#define WB_TR_W(A, COL, VW) if (!(DIAG & 2)) *reinterpret_cast<float4*>((VW) + ((A) * 4 + (COL)) * (WT * WCK)) = tplane;
+  // slots 16..35, transform kind: rows R0, R1 of the next step's input transform, then the raw fragment reads of the point after next
+#define WB_TAIL_TR(AC, AN, UC, R0, R1, VW, VBN, N2FI)                                                    \
+  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_TR_T(R0, 0) WB_SB                                           \
+  WB_M(17, AC, UC) WB_SB WB_TR_T(R0, 1) WB_SB                                                            \
+  WB_M(18, AC, UC) WB_SB WB_TR_T(R0, 2) WB_SB                                                            \
+  WB_M(19, AC, UC) WB_SB WB_TR_T(R0, 3) WB_SB                                                            \
+  WB_M(20, AC, UC) WB_SB WB_TR_P(0) WB_SB                                                                \
+  WB_M(21, AC, UC) WB_SB WB_TR_W(R0, 0, VW) WB_TR_P(1) WB_SB                                             \
+  WB_M(22, AC, UC) WB_SB WB_TR_W(R0, 1, VW) WB_TR_P(2) WB_SB                                             \
+  WB_M(23, AC, UC) WB_SB WB_TR_W(R0, 2, VW) WB_TR_P(3) WB_SB                                             \
+  WB_M(24, AC, UC) WB_SB WB_TR_W(R0, 3, VW) WB_TR_T(R1, 0) WB_SB                                         \
+  WB_M(25, AC, UC) WB_SB WB_TR_T(R1, 1) WB_SB                                                            \
+  WB_M(26, AC, UC) WB_SB WB_TR_T(R1, 2) WB_SB                                                            \
+  WB_M(27, AC, UC) WB_SB WB_TR_T(R1, 3) WB_SB                                                            \
+  WB_M(28, AC, UC) WB_SB WB_TR_P(0) WB_SB                                                                \
+  WB_M(29, AC, UC) WB_SB WB_TR_W(R1, 0, VW) WB_TR_P(1) WB_SB                                             \
+  WB_M(30, AC, UC) WB_SB WB_TR_W(R1, 1, VW) WB_TR_P(2) WB_SB                                             \
+  WB_M(31, AC, UC) WB_SB WB_TR_W(R1, 2, VW) WB_TR_P(3) WB_SB                                             \
+  WB_M(32, AC, UC) WB_SB WB_TR_W(R1, 3, VW) WB_READ_RAW1(VBN, N2FI, 0) WB_SB                             \
+  WB_M(33, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 1) WB_SB                                                \
+  WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
+  WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
+  // slots 16..35, patch kind: rows R0, R1 of the patch of the step after next are requested
+#define WB_TAIL_PL(AC, AN, UC, R0, R1, CS, VBN, N2FI)                                                    \
+  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_LOAD_PATCH1(R0, 0, CS) WB_SB                                \
+  WB_M(17, AC, UC) WB_SB WB_LOAD_PATCH1(R0, 1, CS) WB_SB                                                 \
+  WB_M(18, AC, UC) WB_SB WB_LOAD_PATCH1(R0, 2, CS) WB_SB                                                 \
+  WB_M(19, AC, UC) WB_SB WB_LOAD_PATCH1(R0, 3, CS) WB_SB                                                 \
+  WB_M(20, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 0, CS) WB_SB                                                 \
+  WB_M(21, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 1, CS) WB_SB                                                 \
+  WB_M(22, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 2, CS) WB_SB                                                 \
+  WB_M(23, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 3, CS) WB_SB                                                 \
+  WB_M(24, AC, UC) WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC)                                    \
+  WB_M(28, AC, UC) WB_M(29, AC, UC) WB_M(30, AC, UC) WB_M(31, AC, UC) WB_SB                              \
+  WB_M(32, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 0) WB_SB                                                \
+  WB_M(33, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 1) WB_SB                                                \
+  WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
+  WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
+
+  // fragment read position: lane (tile row = lane & 31 (+ 32), K group = lane >> 5 = channels 8h .. 8h+7 = 16-byte slots 2h, 2h+1)
+  const int fsw = ((lane & 31) >> 2) & 3;
+  const float* vr = Vs + ((4 * wave) * WT + (lane & 31)) * WCK;
+  const int fo_lo = ((2 * (lane >> 5)) ^ fsw) * 4, fo_hi = ((2 * (lane >> 5) + 1) ^ fsw) * 4;
+
+  // ---- prologue: V of step 0 in stage 0, the patch of step 1 in registers, weights + split fragments of (step 0, point 0), the raw
+  //      fragments of point 1 ---------------------------------------------------------------------------------------------------------
+  _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
+  _Pragma("unroll") for (int a = 0; a < 4; ++a)
+    _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
+#define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
+  WB_TR_ROW(0, vw) WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  {
+    const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, cs1) }
+  }
+  __syncthreads();
+  WB_READ_RAW1(vr, 0, 0) WB_READ_RAW1(vr, 0, 1) WB_READ_RAW1(vr, 0, 2) WB_READ_RAW1(vr, 0, 3)
+#define WB_SPLIT4(AN, I, H) WB_SP0(AN, I, H) WB_SP1(I, H) WB_SP2(AN, I, H) WB_SP3() WB_SP4(AN, I, H)
+  WB_SPLIT4(AA, 0, 0) WB_SPLIT4(AA, 0, 1) WB_SPLIT4(AA, 1, 0) WB_SPLIT4(AA, 1, 1)
+  WB_READ_RAW1(vr, 1, 0) WB_READ_RAW1(vr, 1, 1) WB_READ_RAW1(vr, 1, 2) WB_READ_RAW1(vr, 1, 3)
+
+  // ---- K loop: 16 input channels per step, four frequency points per wave and step, 36 MFMAs per point.  Point f multiplies the
+  //      fragments split during point f-1 (raw fp32 read during point f-2) with the weights requested during point f-1.  ONE barrier per
+  //      step, between points 1 and 2: V of this step is last read in point 1 (for point 3), V of the next step is complete after point 1
+  //      (its transform rides in points 0 and 1) and first read in point 2.
+  const bool clk_sample = (blockIdx.x & 63) == 0 && tid == 0;
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int st = 0; st < ns; ++st) {
+    const int buf = st & 1;
+    const float* vb = vr + buf * WV_STAGE;          // V of this step
+    const float* vbn = vr + (buf ^ 1) * WV_STAGE;   // V of the next step
+    float* vwn = vw + (buf ^ 1) * WV_STAGE;
+    const int cs_patch = (st + 2 < ns ? st + 2 : ns - 1) * (WCK * 4);
+    const int st_next = st + 1 < ns ? st + 1 : st;   // (the last step harmlessly re-requests its own first weights)
+    { constexpr int fi = 0; WB_HEAD(AA, AB, Ua, Ub, st, 1) WB_TAIL_TR(AA, AB, Ua, 0, 1, vwn, vb, 2) }
+    { constexpr int fi = 1; WB_HEAD(AB, AA, Ub, Ua, st, 2) WB_TAIL_TR(AB, AA, Ub, 2, 3, vwn, vb, 3) }
+    __syncthreads();
+    { constexpr int fi = 2; WB_HEAD(AA, AB, Ua, Ub, st, 3) WB_TAIL_PL(AA, AB, Ua, 0, 1, cs_patch, vbn, 0) }
+    { constexpr int fi = 3; WB_HEAD(AB, AA, Ub, Ua, st_next, 0) WB_TAIL_PL(AB, AA, Ub, 2, 3, cs_patch, vbn, 1) }
+  }
+  if (clk_sample) {
+    atomicAdd(&g_wb_clk[0], __builtin_readcyclecounter() - clk_c0);
+    atomicAdd(&g_wb_clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+    atomicAdd(&g_wb_clk[2], (unsigned long long)ns);
+  }
+  __syncthreads();   // (the epilogue reuses the V stages)
+#undef WB_TAIL_PL
+#undef WB_TAIL_TR
+#undef WB_HEAD
+#undef WB_M
+#undef WB_READ_RAW1
+#undef WB_SPLIT4
+#undef WB_SP4
+#undef WB_SP3
+#undef WB_SP2
+#undef WB_SP1
+#undef WB_SP0
+#undef WB_TR_W
+#undef WB_TR_P
+#undef WB_TR_ROW
+#undef WB_TR_T
+#undef WB_F4ASM
+#undef WB_LOAD_PATCH1
+#undef WB_LOAD_U1
+#undef WB_SB
+
+  // ---- epilogue (as conv_wino.hip): output transform through LDS, bias + residual + ReLU (+ second activated output) ----------------
+  const int n = cb * WCOUT + (tid & 15) * 4;
+  constexpr unsigned WOOB = 0xFFFFFFF0u;
+  unsigned voff[4][4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tl = it * 16 + (tid >> 4);
+    const int off = tile_tab[2 * tl], bits = tile_tab[2 * tl + 1];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const bool ok = off >= 0 && (!ii || (bits & 1)) && (!jj || (bits & 2));
+        voff[it][ii * 2 + jj] = ok ? (unsigned)(off + (ii * p.Wop + jj) * p.Cout + n) * 4u : WOOB;
+      }
+  }
+  const int out_bytes = p.out_bytes;
+  u32x4 res[4][4];
+  if (p.residual) {
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, out_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) res[it][k] = __builtin_amdgcn_raw_buffer_load_b128(r_res, voff[it][k], 0, 0);
+  }
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+  if (p.y_act) {
+    sc = *reinterpret_cast<const float4*>(p.act_scale + n);
+    sh = *reinterpret_cast<const float4*>(p.act_shift + n);
+  }
+  float* S = smem;
+  {
+    float* sw = S + (size_t)wave * (2 * WT * WCOUT) + ((lane >> 5) * 4) * WCOUT + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0][i][j][r], m1 = acc[1][i][j][r], m2 = acc[2][i][j][r], m3 = acc[3][i][j][r];
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+          sw[row * WCOUT + j * 32] = (m0 + m1) + m2;
+          sw[WT * WCOUT + row * WCOUT + j * 32] = (m1 - m2) - m3;
+        }
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
+  const bool has_res = p.residual != nullptr, relu = p.relu != 0, has_act = p.y_act != nullptr;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tl = it * 16 + (tid >> 4);
+    float4 s4[4][2];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) s4[w][jj] = *reinterpret_cast<const float4*>(S + ((size_t)(w * 2 + jj) * WT + tl) * WCOUT + (tid & 15) * 4);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        float4 v;
+        if (ii == 0) {
+          v.x = (s4[0][jj].x + s4[1][jj].x) + s4[2][jj].x; v.y = (s4[0][jj].y + s4[1][jj].y) + s4[2][jj].y;
+          v.z = (s4[0][jj].z + s4[1][jj].z) + s4[2][jj].z; v.w = (s4[0][jj].w + s4[1][jj].w) + s4[2][jj].w;
+        } else {
+          v.x = (s4[1][jj].x - s4[2][jj].x) - s4[3][jj].x; v.y = (s4[1][jj].y - s4[2][jj].y) - s4[3][jj].y;
+          v.z = (s4[1][jj].z - s4[2][jj].z) - s4[3][jj].z; v.w = (s4[1][jj].w - s4[2][jj].w) - s4[3][jj].w;
+        }
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (has_res) {
+          const u32x4 rr = res[it][ii * 2 + jj];
+          v.x += __uint_as_float(rr.x); v.y += __uint_as_float(rr.y); v.z += __uint_as_float(rr.z); v.w += __uint_as_float(rr.w);
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        u32x4 o;
+        o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_y, voff[it][ii * 2 + jj], 0, 0);
+        if (has_act) {
+          u32x4 a;
+          a.x = __float_as_uint(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f)); a.y = __float_as_uint(fmaxf(fmaf(v.y, sc.y, sh.y), 0.f));
+          a.z = __float_as_uint(fmaxf(fmaf(v.z, sc.z, sh.z), 0.f)); a.w = __float_as_uint(fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+          __builtin_amdgcn_raw_buffer_store_b128(a, r_act, voff[it][ii * 2 + jj], 0, 0);
+        }
+      }
+  }
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" size_t mp_conv_wino_bf16_packed_bytes(int Cin_p, int Cout) { return (size_t)(Cout / WCOUT) * (Cin_p / WCK) * UB_STEP_BYTES; }
+
+// U = G g G^T per (cout, cin) in double, rounded once to fp32, split into three bf16 pieces, in MFMA fragment order:
+// packed[cb][step][f][j][piece][lane][e] = piece of U_f[cin = step*16 + (lane >> 5)*8 + e][cout = cb*64 + j*32 + (lane & 31)]
+extern "C" int mp_conv_wino_bf16_pack_weights(const float* w, int Cout, int Cin, int Cin_p, const float* scale, void* packed_bytes) {
+  MP_REQUIRE(w && packed_bytes && Cin_p >= Cin && Cin_p % WCK == 0 && Cout % WCOUT == 0,
+             "mp_conv_wino_bf16_pack_weights: bad arguments (Cin_p %% 16, Cout %% 64)");
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int n_steps = Cin_p / WCK;
+  unsigned short* out = (unsigned short*)packed_bytes;
+  memset(out, 0, mp_conv_wino_bf16_packed_bytes(Cin_p, Cout));
+  for (int n = 0; n < Cout; ++n) {
+    const double s = scale ? (double)scale[n] : 1.0;
+    const int cb = n / WCOUT, j = (n % WCOUT) / 32, nl = n % 32;
+    for (int c = 0; c < Cin; ++c) {
+      const float* g = w + ((size_t)n * Cin + c) * 9;
+      double t[4][3], U[4][4];
+      for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < 3; ++k) t[a][k] = G[a][0] * g[0 * 3 + k] * s + G[a][1] * g[1 * 3 + k] * s + G[a][2] * g[2 * 3 + k] * s;
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) U[a][b] = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+      const int st = c / WCK, kh = (c % WCK) / 8, e = c % 8;
+      const int lane = kh * 32 + nl;
+      for (int f = 0; f < 16; ++f) {
+        const float v = (float)U[f / 4][f % 4];
+        unsigned vb, rb, qb;
+        memcpy(&vb, &v, 4);
+        const unsigned h = vb & 0xFFFF0000u;
+        float hf; memcpy(&hf, &h, 4);
+        const float r = v - hf;
+        memcpy(&rb, &r, 4);
+        const unsigned m = rb & 0xFFFF0000u;
+        float mf; memcpy(&mf, &m, 4);
+        const float q = r - mf;
+        memcpy(&qb, &q, 4);
+        const unsigned short pc[3] = {(unsigned short)(h >> 16), (unsigned short)(m >> 16), (unsigned short)(qb >> 16)};
+        for (int piece = 0; piece < 3; ++piece)
+          out[(((((size_t)(cb * n_steps + st) * 16 + f) * 2 + j) * 3 + piece) * 64 + lane) * 8 + e] = pc[piece];
+      }
+    }
+  }
+  return MP_OK;
+}
+
+static double g_wb_direct = 0.0, g_wb_executed = 0.0;
+extern "C" int mp_conv_wino_bf16_stats(double* direct_flops, double* executed_bf16_flops, int reset) {
+  if (direct_flops) *direct_flops = g_wb_direct;
+  if (executed_bf16_flops) *executed_bf16_flops = g_wb_executed;
+  if (reset) g_wb_direct = g_wb_executed = 0.0;
+  return MP_OK;
+}
+
+extern "C" int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int reset) {
+  unsigned long long h[3] = {0, 0, 0};
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wb_clk), sizeof(h)));
+  if (shader_mhz) *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+  if (cycles_per_step) *cycles_per_step = h[2] ? (double)h[0] / (double)h[2] : 0.0;
+  if (reset) {
+    const unsigned long long z[3] = {0, 0, 0};
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wb_clk), z, sizeof(z)));
+  }
+  return MP_OK;
+}
+
+extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_pieces, mp_stream stream) {
+  MP_REQUIRE(d && d->d_x && d_u_pieces && (d->d_y || d->d_y_act), "mp_conv3x3_wino_bf16_nhwc: null pointer");
+  MP_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, "mp_conv3x3_wino_bf16_nhwc: 3x3 / stride 1 / pad 1 only");
+  MP_REQUIRE(d->C % WCK == 0 && d->Cout % WCOUT == 0 && d->in_border >= 1, "mp_conv3x3_wino_bf16_nhwc: C %% 16, Cout %% 64, in_border >= 1");
+  MP_REQUIRE(!d->d_y_act || (d->d_act_scale && d->d_act_shift), "mp_conv3x3_wino_bf16_nhwc: y_act needs scale/shift");
+  WinoParams p;
+  p.x = d->d_x; p.u = (const float*)d_u_pieces; p.bias = d->d_bias; p.residual = d->d_residual; p.act_scale = d->d_act_scale; p.act_shift = d->d_act_shift;
+  p.y = d->d_y; p.y_act = d->d_y_act;
+  p.N = d->N; p.Ho = d->H; p.Wo = d->W;
+  p.Hp = d->H + 2 * d->in_border; p.Wp = d->W + 2 * d->in_border; p.C = d->C;
+  p.in_off = d->in_border - 1;
+  p.Cout = d->Cout;
+  p.Hop = d->H + 2 * d->out_border; p.Wop = d->W + 2 * d->out_border; p.out_border = d->out_border;
+  p.tiles_x = (d->W + 1) / 2; p.tiles_y = (d->H + 1) / 2;
+  const long n_tiles = (long)d->N * p.tiles_x * p.tiles_y;
+  const long in_bytes = ((long)d->N * p.Hp + 2) * p.Wp * p.C * 4, out_elems = (long)d->N * p.Hop * p.Wop * d->Cout;
+  MP_REQUIRE(n_tiles < (1L << 30) && in_bytes < (1L << 31) && out_elems < (1L << 29), "mp_conv3x3_wino_bf16_nhwc: tensor too large for 32-bit offsets");
+  p.out_bytes = (int)(out_elems * 4);
+  p.n_tiles = (int)n_tiles;
+  p.n_chunks = d->C / 8;
+  p.n_steps = d->C / WCK;
+  p.relu = d->relu;
+  p.n_cblocks = d->Cout / WCOUT;
+  int dev = 0;
+  MP_CHECK_HIP(hipGetDevice(&dev));
+  static int attr_dev = -1;
+  if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+#ifdef MP_CONV_EXPERIMENTS
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+#endif
+    attr_dev = dev;
+  }
+  const long n_wg = ((n_tiles + WT - 1) / WT) * p.n_cblocks;
+  hipStream_t s = (hipStream_t)stream;
+  const double c_real = d->c_real > 0 ? d->c_real : d->C;
+  const double direct = 2.0 * 9.0 * (double)d->N * d->H * d->W * c_real * d->Cout;
+  const double executed = 9.0 * 2.0 * 16.0 * (double)n_tiles * c_real * d->Cout;   // bf16 FLOPs: nine piece products per Winograd multiplication
+  g_wb_direct += direct;
+  g_wb_executed += executed;
+  ProfScope prof("conv3x3_wino_bf16x9<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout)) + 6.0 * 16.0 * d->C * d->Cout, s, executed, 2500.0);
+#ifdef MP_CONV_EXPERIMENTS
+  const int diag = getenv("MP_WINO_DIAG") ? atoi(getenv("MP_WINO_DIAG")) : 0;
+  if (diag == 1) hipLaunchKernelGGL(conv3x3_wino_bf16x9<1>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  else if (diag == 2) hipLaunchKernelGGL(conv3x3_wino_bf16x9<2>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  else if (diag == 4) hipLaunchKernelGGL(conv3x3_wino_bf16x9<4>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  else if (diag == 7) hipLaunchKernelGGL(conv3x3_wino_bf16x9<7>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  else
+#endif
+  hipLaunchKernelGGL(conv3x3_wino_bf16x9<0>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}

@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 namespace mp {
 struct ProfRec {
   const char* name;
-  double flops, bytes;
+  double flops, bytes, executed, peak;
   hipEvent_t e0, e1;
 };
 static bool g_prof_on = false;
@@ -34,10 +34,10 @@ static hipEvent_t pool_event() {
   return hipEventCreate(&e) == hipSuccess ? e : nullptr;
 }
 
-ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s, double executed, double peak_tflops) : slot(-1), stream(s) {
   if (!g_prof_on) return;
   ProfRec r;
-  r.name = name; r.flops = flops; r.bytes = bytes;
+  r.name = name; r.flops = flops; r.bytes = bytes; r.executed = executed < 0.0 ? flops : executed; r.peak = peak_tflops;
   r.e0 = pool_event();
   r.e1 = pool_event();
   if (!r.e0 || !r.e1) return;
@@ -63,25 +63,32 @@ extern "C" int mp_profile_end(void) {
 // Aggregated by kernel name.  idx enumerates distinct names; returns 1 when idx is past the end.
 extern "C" int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
                                 double* total_bytes) {
+  return mp_profile_query_ex(idx, name, name_len, launches, total_ms, total_flops, total_bytes, nullptr, nullptr);
+}
+
+extern "C" int mp_profile_query_ex(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
+                                   double* total_bytes, double* total_executed_flops, double* peak_tflops) {
   std::map<std::string, int> order;
   std::vector<std::string> names;
   for (auto& r : mp::g_prof)
     if (!order.count(r.name)) { order[r.name] = (int)names.size(); names.push_back(r.name); }
   if (idx < 0 || idx >= (int)names.size()) return 1;
   int64_t n = 0;
-  double ms = 0, fl = 0, by = 0;
+  double ms = 0, fl = 0, by = 0, ex = 0, pk = 0;
   for (auto& r : mp::g_prof) {
     if (names[idx] != r.name) continue;
     MP_CHECK_HIP(hipEventSynchronize(r.e1));
     float t = 0.f;
     MP_CHECK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-    ms += t; fl += r.flops; by += r.bytes; ++n;
+    ms += t; fl += r.flops; by += r.bytes; ex += r.executed; pk = r.peak; ++n;
   }
   if (name && name_len > 0) { strncpy(name, names[idx].c_str(), name_len - 1); name[name_len - 1] = 0; }
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (total_bytes) *total_bytes = by;
+  if (total_executed_flops) *total_executed_flops = ex;
+  if (peak_tflops) *peak_tflops = pk;
   return MP_OK;
 }
 

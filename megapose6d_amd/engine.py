@@ -85,7 +85,8 @@ def profile_begin() -> None:
 
 
 def profile_end() -> Dict[str, Dict[str, float]]:
-    """Stop the per-launch event profiler and return {kernel: {launches, ms, flops, bytes}} (synchronises)."""
+    """Stop the per-launch event profiler and return {kernel: {launches, ms, flops, bytes, executed, peak_tflops}} (synchronises):
+    flops = algorithmic work, executed = FLOPs issued on the matrix pipe whose dense peak is peak_tflops (mp_profile_query_ex)."""
     global _PROFILING
     lib = _lib.load()
     check(lib.mp_profile_end())
@@ -94,12 +95,13 @@ def profile_end() -> Dict[str, Dict[str, float]]:
     i = 0
     while True:
         name = C.create_string_buffer(128)
-        n, ms, fl, by = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
-        rc = lib.mp_profile_query(i, name, 128, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+        n, ms, fl, by, ex, pk = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        rc = lib.mp_profile_query_ex(i, name, 128, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by), C.byref(ex), C.byref(pk))
         if rc == 1:
             break
         check(rc)
-        out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+        out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value, "executed": ex.value,
+                                    "peak_tflops": pk.value}
         i += 1
     return out
 
@@ -324,7 +326,36 @@ def conv3x3_wino_nhwc(x: torch.Tensor, N: int, H: int, W: int, Cp: int, in_borde
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, 3, 3, 1, 1
     d.d_y, d.out_border, d.d_residual, d.relu = _ptr(y), out_border, _ptr(residual), int(relu)
     d.d_y_act, d.d_act_scale, d.d_act_shift = _ptr(y_act), _ptr(act_scale), _ptr(act_shift)
+    if u_packed.dtype == torch.uint8:   # the three-bf16-piece blob: the exact-piece kernel (mp_conv3x3_wino_bf16_nhwc)
+        check(_lib.load().mp_conv3x3_wino_bf16_nhwc(C.byref(d), u_packed.data_ptr(), _stream()))
+        return
     check(_lib.load().mp_conv3x3_wino_nhwc(C.byref(d), u_packed.data_ptr(), _stream()))
+
+
+def conv_wino_bf16_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
+    """U = G g G^T of a 3x3 layer split into three exact bf16 pieces, MFMA fragment order (mp_conv_wino_bf16_pack_weights); uint8 blob"""
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin, KH, KW = w.shape
+    assert KH == 3 and KW == 3
+    out = np.empty(lib.mp_conv_wino_bf16_packed_bytes(cin_p, Cout), dtype=np.uint8)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    check(lib.mp_conv_wino_bf16_pack_weights(w.ctypes.data, Cout, Cin, cin_p, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    return out
+
+
+def conv_wino_bf16_stats(reset: bool = True) -> Tuple[float, float]:
+    """(algorithmic = direct-convolution FLOPs, executed bf16 FLOPs) of the bf16x9 Winograd launches since the last reset"""
+    a, b = C.c_double(0), C.c_double(0)
+    check(_lib.load().mp_conv_wino_bf16_stats(C.byref(a), C.byref(b), 1 if reset else 0))
+    return a.value, b.value
+
+
+def conv_wino_bf16_clock(reset: bool = True) -> Tuple[float, float]:
+    """(effective shader clock in MHz, shader cycles per 16-channel step) inside the K loops of the bf16x9 Winograd launches"""
+    a, b = C.c_double(0), C.c_double(0)
+    check(_lib.load().mp_conv_wino_bf16_clock(C.byref(a), C.byref(b), 1 if reset else 0))
+    return a.value, b.value
 
 
 def conv_stem_pack_weights(w_oihw: np.ndarray, n_f32: int, scale: Optional[np.ndarray] = None) -> np.ndarray:

@@ -58,9 +58,14 @@ static int run_case(const Case& s, int* n_bad) {
   for (auto& q : w) q = G(rng) * a;
   for (int i = 0; i < s.Cout; ++i) { bias[i] = 0.1f * G(rng); scl[i] = 0.5f + 0.05f * (i % 11); sc2[i] = 0.7f + 0.01f * (i % 13); sh2[i] = 0.05f * G(rng); }
   std::vector<float> packed(mp_conv_packed_floats(s.C, s.Cout, 3, 3)), u(mp_conv_wino_packed_floats(s.C, s.Cout));
+  std::vector<unsigned char> ub(mp_conv_wino_bf16_packed_bytes(s.C, s.Cout));
+  MP_OKAY(mp_conv_wino_bf16_pack_weights(w.data(), s.Cout, s.C, s.C, scl.data(), ub.data()));
   MP_OKAY(mp_conv_pack_weights(w.data(), s.Cout, s.C, 3, 3, s.C, scl.data(), packed.data()));
   MP_OKAY(mp_conv_wino_pack_weights(w.data(), s.Cout, s.C, s.C, scl.data(), u.data()));
-  float *d_x, *d_w, *d_u, *d_b, *d_y0, *d_y1, *d_a0 = nullptr, *d_a1 = nullptr, *d_r = nullptr, *d_s2, *d_h2, *d_sk;
+  float *d_x, *d_w, *d_u, *d_b, *d_y0, *d_y1, *d_y2, *d_a0 = nullptr, *d_a1 = nullptr, *d_a2 = nullptr, *d_r = nullptr, *d_s2, *d_h2, *d_sk;
+  unsigned char* d_ub;
+  HIP_OK(hipMalloc(&d_ub, ub.size()));
+  HIP_OK(hipMemcpy(d_ub, ub.data(), ub.size(), hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&d_x, n_in * 4));
   HIP_OK(hipMalloc(&d_w, packed.size() * 4));
   HIP_OK(hipMalloc(&d_u, u.size() * 4));
@@ -69,6 +74,8 @@ static int run_case(const Case& s, int* n_bad) {
   HIP_OK(hipMalloc(&d_h2, s.Cout * 4));
   HIP_OK(hipMalloc(&d_y0, n_out * 4));
   HIP_OK(hipMalloc(&d_y1, n_out * 4));
+  HIP_OK(hipMalloc(&d_y2, n_out * 4));
+  HIP_OK(hipMemset(d_y2, 0, n_out * 4));
   HIP_OK(hipMalloc(&d_sk, (size_t)(12u << 20) * 4));
   HIP_OK(hipMemset(d_x, 0, n_in * 4));
   HIP_OK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
@@ -91,6 +98,8 @@ static int run_case(const Case& s, int* n_bad) {
     HIP_OK(hipMalloc(&d_a1, n_out * 4));
     HIP_OK(hipMemset(d_a0, 0, n_out * 4));
     HIP_OK(hipMemset(d_a1, 0, n_out * 4));
+    HIP_OK(hipMalloc(&d_a2, n_out * 4));
+    HIP_OK(hipMemset(d_a2, 0, n_out * 4));
   }
   if (s.residual) {
     HIP_OK(hipMalloc(&d_r, n_out * 4));
@@ -109,51 +118,93 @@ static int run_case(const Case& s, int* n_bad) {
   mp_conv_desc e = d;
   e.d_y = d_y1; e.d_y_act = d_a1;
   MP_OKAY(mp_conv3x3_wino_nhwc(&e, d_u, nullptr));
+  mp_conv_desc g = d;
+  g.d_y = d_y2; g.d_y_act = d_a2;
+  MP_OKAY(mp_conv3x3_wino_bf16_nhwc(&g, d_ub, nullptr));
   HIP_OK(hipDeviceSynchronize());
   // compare (all of a small case; the first 2 and the last image of a timed one)
   const size_t per_out = (size_t)Hp * Wp * s.Cout;
   std::vector<size_t> imgs;
   for (int n = 0; n < s.N; ++n)
     if (!s.timed || n < 2 || n == s.N - 1) imgs.push_back(n);
-  double max_err = 0, max_ref = 0, max_err_a = 0;
+  double max_err = 0, max_ref = 0, max_err_a = 0, max_err_b = 0, max_err_ba = 0;
   size_t n_nan = 0;
-  std::vector<float> y0(per_out), y1(per_out);
+  std::vector<float> y0(per_out), y1(per_out), y2(per_out);
   for (size_t n : imgs) {
     for (int which = 0; which < (s.act ? 2 : 1); ++which) {
       HIP_OK(hipMemcpy(y0.data(), (which ? d_a0 : d_y0) + n * per_out, per_out * 4, hipMemcpyDeviceToHost));
       HIP_OK(hipMemcpy(y1.data(), (which ? d_a1 : d_y1) + n * per_out, per_out * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(y2.data(), (which ? d_a2 : d_y2) + n * per_out, per_out * 4, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < per_out; ++i) {
-        if (std::isnan(y1[i])) { ++n_nan; continue; }
+        if (std::isnan(y1[i]) || std::isnan(y2[i])) { ++n_nan; continue; }
+        const double eb_ = std::fabs((double)y0[i] - (double)y2[i]);
+        if (which) max_err_ba = std::max(max_err_ba, eb_); else max_err_b = std::max(max_err_b, eb_);
         const double e_ = std::fabs((double)y0[i] - (double)y1[i]);
         if (which) max_err_a = std::max(max_err_a, e_); else max_err = std::max(max_err, e_);
         max_ref = std::max(max_ref, (double)std::fabs(y0[i]));
       }
     }
   }
-  const bool ok = n_nan == 0 && max_err <= 2e-5 * std::max(1.0, max_ref) && max_err_a <= 2e-5 * std::max(1.0, max_ref);
-  printf("CASE %-34s | max|wino - direct| %.3e (act %.3e) at output scale %.2f, NaN %zu -> %s\n", s.name, max_err, max_err_a, max_ref, n_nan,
-         ok ? "ok" : "MISMATCH");
+  const bool ok = n_nan == 0 && max_err <= 2e-5 * std::max(1.0, max_ref) && max_err_a <= 2e-5 * std::max(1.0, max_ref) &&
+                  max_err_b <= 2e-5 * std::max(1.0, max_ref) && max_err_ba <= 2e-5 * std::max(1.0, max_ref);
+  printf("CASE %-34s | max|wino - direct| fp32 %.3e (act %.3e)  bf16x9 %.3e (act %.3e) at output scale %.2f, NaN %zu -> %s\n", s.name, max_err,
+         max_err_a, max_err_b, max_err_ba, max_ref, n_nan, ok ? "ok" : "MISMATCH");
   *n_bad += !ok;
   if (s.timed) {
-    hipEvent_t e0, e1, e2;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
+    hipEvent_t e0, e1, e2, e3;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2)); HIP_OK(hipEventCreate(&e3));
     const int reps = 6;
     HIP_OK(hipEventRecord(e0, nullptr));
     for (int r = 0; r < reps; ++r) MP_OKAY(mp_conv2d_nhwc(&d, nullptr));
     HIP_OK(hipEventRecord(e1, nullptr));
     for (int r = 0; r < reps; ++r) MP_OKAY(mp_conv3x3_wino_nhwc(&e, d_u, nullptr));
     HIP_OK(hipEventRecord(e2, nullptr));
+    for (int r = 0; r < reps; ++r) MP_OKAY(mp_conv3x3_wino_bf16_nhwc(&g, d_ub, nullptr));
+    HIP_OK(hipEventRecord(e3, nullptr));
+    if (getenv("MP_WINO_DIAG_SWEEP")) {   // timing experiments of an MP_CONV_EXPERIMENTS build of the library (results of diag != 0 are wrong)
+      for (int diag : {0, 1, 2, 4, 7}) {
+        char buf[8];
+        snprintf(buf, sizeof(buf), "%d", diag);
+        setenv("MP_WINO_DIAG", buf, 1);
+        hipEvent_t a0, a1;
+        HIP_OK(hipEventCreate(&a0)); HIP_OK(hipEventCreate(&a1));
+        MP_OKAY(mp_conv3x3_wino_bf16_nhwc(&g, d_ub, nullptr));
+        { double t0_, t1_; MP_OKAY(mp_conv_wino_bf16_clock(&t0_, &t1_, 1)); }
+        HIP_OK(hipEventRecord(a0, nullptr));
+        for (int r = 0; r < reps; ++r) MP_OKAY(mp_conv3x3_wino_bf16_nhwc(&g, d_ub, nullptr));
+        HIP_OK(hipEventRecord(a1, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, a0, a1));
+        double mhz = 0, cps = 0;
+        MP_OKAY(mp_conv_wino_bf16_clock(&mhz, &cps, 1));
+        printf("DIAG %-34s | diag %d (1 no split, 2 no patch/transform, 4 no weight loads): %7.3f ms, %6.0f MHz, %7.0f cycles per step = %5.1f per MFMA\n",
+               s.name, diag, ms / reps, mhz, cps, cps / 144.0);
+      }
+      unsetenv("MP_WINO_DIAG");
+    }
     HIP_OK(hipDeviceSynchronize());
-    float ms_d = 0, ms_w = 0;
+    float ms_d = 0, ms_w = 0, ms_b = 0;
     HIP_OK(hipEventElapsedTime(&ms_d, e0, e1));
     HIP_OK(hipEventElapsedTime(&ms_w, e1, e2));
+    HIP_OK(hipEventElapsedTime(&ms_b, e2, e3));
     const double flops = 2.0 * s.N * s.H * s.W * (double)s.Cout * 9 * s.C;
     const double tiles = (double)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
     const double exec = 2.0 * 16.0 * tiles * s.C * s.Cout;
     printf("TIME %-34s | direct %7.3f ms %6.1f TFLOP/s | winograd %7.3f ms: executed %6.1f TFLOP/s, direct-equivalent %6.1f TFLOP/s | x%.2f\n", s.name,
            ms_d / reps, flops * reps / (ms_d * 1e-3) / 1e12, ms_w / reps, exec * reps / (ms_w * 1e-3) / 1e12, flops * reps / (ms_w * 1e-3) / 1e12,
            ms_d / ms_w);
+    {
+      double mhz = 0, cps = 0;
+      MP_OKAY(mp_conv_wino_bf16_clock(&mhz, &cps, 1));
+      printf("CLK  %-34s | bf16x9 K loop: %6.0f MHz, %7.0f cycles per 16-channel step = %5.1f per MFMA\n", s.name, mhz, cps, cps / 144.0);
+    }
+    printf("TIME %-34s | bf16x9 winograd %7.3f ms: executed bf16 %7.1f TFLOP/s (%.2f of 2500), direct-equivalent %6.1f TFLOP/s | x%.2f vs direct, x%.2f vs fp32 winograd\n",
+           s.name, ms_b / reps, 9.0 * exec * reps / (ms_b * 1e-3) / 1e12, 9.0 * exec * reps / (ms_b * 1e-3) / 1e12 / 2500.0,
+           flops * reps / (ms_b * 1e-3) / 1e12, ms_d / ms_b, ms_w / ms_b);
   }
+  (void)hipFree(d_y2); (void)hipFree(d_ub);
+  if (d_a2) (void)hipFree(d_a2);
   (void)hipFree(d_x); (void)hipFree(d_w); (void)hipFree(d_u); (void)hipFree(d_b); (void)hipFree(d_y0); (void)hipFree(d_y1); (void)hipFree(d_sk);
   (void)hipFree(d_s2); (void)hipFree(d_h2);
   if (d_a0) (void)hipFree(d_a0);

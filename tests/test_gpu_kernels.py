@@ -107,8 +107,10 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("case", WINO_CASES)
 @pytest.mark.parametrize("epi", ["plain", "bias_relu", "res_relu", "dual"])
-def test_winograd_conv_matches_torch_fp32(eng, case, epi):
-    """mp_conv3x3_wino_nhwc (fused Winograd F(2x2, 3x3), csrc/conv_wino.hip) against torch's fp32 convolution, every fused epilogue;
+@pytest.mark.parametrize("kernel", ["bf16x9", "fp32"])
+def test_winograd_conv_matches_torch_fp32(eng, case, epi, kernel):
+    """the fused Winograd F(2x2, 3x3) kernels -- mp_conv3x3_wino_bf16_nhwc (exact bf16 pieces, csrc/conv_wino_bf16.hip: the default of the
+    backbone) and mp_conv3x3_wino_nhwc (fp32 MFMA, csrc/conv_wino.hip) -- against torch's fp32 convolution, every fused epilogue;
     the slack the kernel may read behind an odd-sized input is poisoned with NaN (nothing read there may reach an output).
     Reference layers: models/torchvision_resnet.py:74-120, models/wide_resnet.py:29-56."""
     N, Cin, H, W, Cout, ib = case
@@ -123,7 +125,8 @@ def test_winograd_conv_matches_torch_fp32(eng, case, epi):
     xb = torch.full((n_x + (W + 2 * ib + 1) * Cin + 64,), float("nan"), device="cuda")
     xb[:n_x] = xb0.flatten()[:n_x]
     use_scale = epi != "plain"
-    up = torch.from_numpy(eng.conv_wino_pack_weights(w.numpy(), Cin, scale.numpy() if use_scale else None)).cuda()
+    pack = eng.conv_wino_bf16_pack_weights if kernel == "bf16x9" else eng.conv_wino_pack_weights
+    up = torch.from_numpy(pack(w.numpy(), Cin, scale.numpy() if use_scale else None)).cuda()
     ob = 1
     yb = eng.padded_nhwc(N, H, W, Cout, ob, "cuda")
     yb += 7.0  # poison: interior must be fully overwritten, the border untouched
