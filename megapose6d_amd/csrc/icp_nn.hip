@@ -724,6 +724,7 @@ extern "C" int mp_icp_refine_nn(const float* d_depth_meas, int n_images, const i
   MP_REQUIRE(ws_bytes >= mp_icp_nn_workspace_bytes(n_images, n_rows, H, W), "mp_icp_refine_nn: workspace too small");
   if (n_rows == 0) return MP_OK;
   MP_REQUIRE(n_rows <= 65535 && n_images <= 65535, "mp_icp_refine_nn: at most 65535 rows / images");
+  MP_REQUIRE(n_min_points >= 6, "mp_icp_refine_nn: n_min_points must be >= 6 (an empty / degenerate cloud has no centroid and no 6-dof solve; the reference uses 1000)");
   hipStream_t s = (hipStream_t)stream;
   const size_t px = (size_t)H * W, cap = nn_cap(H, W);
   const int imgs = n_images + n_rows;   // image batch: the measured frames first, then the rendered depth of every object

@@ -78,6 +78,7 @@ def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor
         res["logit_scale"] = max(1.0, lo.abs().max().item())
         res["feature_max"] = max(o["net"]["features"].abs().max().item() for o in outs_c)
         res["coarse_logit_max_err"] = (lg - lo.flatten()).abs().max().item()
+        res["coarse_logit_errs"] = (lg - lo.flatten()).abs().tolist()
     if len(refine_rows):
         rows = np.asarray(refine_rows)
         dff = extra["coarse_filter"]["preds"].infos.reset_index(drop=True).iloc[rows]
@@ -107,14 +108,29 @@ def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor
         res["logit_scale"] = max(res.get("logit_scale", 1.0), sl.abs().max().item())
         res["feature_max"] = max(res.get("feature_max", 0.0), max(o["net"]["features"].abs().max().item() for o in outs_s))
         res["score_logit_max_err"] = (sg - sl.flatten()).abs().max().item()
+        res["score_logit_errs"] = (sg - sl.flatten()).abs().tolist()
     return res
 
 
+def logit_flip_rule(err, scale: float, tol: float = 1e-4) -> Dict[str, object]:
+    """The logit bound of every parity check.  PRIMARY gate: |logit - reference| < tol x scale (north_star 1e-4, scale = max(1, |logit|)).
+    The renders are bit-identical for identical cameras, but the crop cameras agree with the reference's only to the last ulp (fmaf
+    chains on the device, separate torch ops in the reference), so once in a while ONE silhouette sample -- a quarter of a pixel's
+    8-bit value under 4x MSAA -- flips and moves a logit a little further.  Such rows are COUNTED, not waved through: at most one row
+    per 64 (rounded up) may exceed tol x scale, and none may exceed 2 x tol x scale."""
+    e = np.abs(np.asarray(err, dtype=np.float64)).ravel()
+    n_over = int((e >= tol * scale).sum())
+    allowed = (e.size + 63) // 64
+    return {"rows": int(e.size), "max_err": float(e.max()) if e.size else 0.0, "rows_over_tol": n_over, "rows_over_tol_allowed": allowed,
+            "ok": bool(e.size > 0 and n_over <= allowed and (e.max() < 2 * tol * scale))}
+
+
 def parity_ok(res: Dict[str, object], tol: float = 1e-4) -> bool:
-    """north_star tolerance: 1e-4 on the pose tensors; logits 1e-4 x max(1, |logit|)"""
+    """north_star tolerance: 1e-4 on the pose tensors; logits by `logit_flip_rule`"""
     scale = float(res.get("logit_scale", 1.0))
     ok = res.get("coarse_TCO_max_err", 0.0) < tol
-    # (2 x tol on the logits: one flipped silhouette sample may move a sampled logit by a few 1e-5, see tests/conftest.py)
-    ok = ok and res.get("coarse_logit_max_err", 0.0) < 2 * tol * scale and res.get("score_logit_max_err", 0.0) < 2 * tol * scale
+    for key in ("coarse_logit_errs", "score_logit_errs"):
+        if key in res:
+            ok = ok and logit_flip_rule(res[key], scale, tol)["ok"]
     ok = ok and all(e < tol for e in res.get("pose_max_err_per_iter", []))
     return bool(ok)

@@ -28,14 +28,13 @@ def engine_meshes(object_dataset):
 
 
 def assert_logits_close(got, ref, scale):
-    """Classifier logits of the HIP path vs the oracle / the reference goldens.  The renders are bit-identical for identical
-    cameras, but the crop cameras themselves agree only to the last ulp (fmaf chains on the device, separate torch ops in the
-    reference), so once in a while ONE silhouette sample (a quarter of a pixel's 8-bit value under 4x MSAA) flips and moves a logit
-    a little further.  `scale` = max(1, |logit|) -- the seeded networks' features are O(1), there is no feature-scale factor.
-    Bound: 90 % of the logits within 1e-4 * scale (pure fp32 round-off), every logit within 2e-4 * scale."""
+    """Classifier logits of the HIP path vs the oracle / the reference goldens: `oracle.harness.logit_flip_rule` -- every logit within
+    1e-4 x scale (scale = max(1, |logit|): the seeded networks' features are O(1), there is no feature-scale factor) EXCEPT at most one
+    row per 64 whose silhouette sample flipped (the crop cameras agree to 1 ulp only), and those within 2e-4 x scale."""
     import numpy as np
 
+    from oracle.harness import logit_flip_rule
+
     err = np.abs(np.asarray(got, dtype=np.float64).ravel() - np.asarray(ref, dtype=np.float64).ravel())
-    assert err.size > 0
-    assert np.quantile(err, 0.9) < 1e-4 * scale, (np.quantile(err, 0.9), scale)
-    assert err.max() < 2e-4 * scale, (err.max(), scale)
+    r = logit_flip_rule(err, scale)
+    assert r["ok"], (r, scale)

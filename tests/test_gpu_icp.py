@@ -92,6 +92,64 @@ def test_pipeline_with_depth_refiner():
     assert "depth refiner=" in extra["timing_str"]
 
 
+def test_config5_full_size_pipeline_with_depth_refiner_vs_restatement():
+    """BASELINE.json configs[4] end to end at full size: 64 detections over 8 frames / 16 meshes x 576 hypotheses, K = 5 x 5 refiner
+    iterations, fp16 renders, run_depth_refiner=True (reference inference/pose_estimator.py:607-616 -> inference/icp_refiner.py:195-262).
+    The depth refiner's input is what the HIP pipeline produced (the scored top-1 pose per detection) and the frames' depth channel; for 8
+    sampled detections the restatement of the reference's refiner (oracle/icp_opencv.py, bit-identical to the reference's own
+    icp_refiner.py code around its two cv2 calls: tests/_ref_icp_check.py) is run on exactly those inputs and must make the same
+    accept / reject decision, run the same number of iterations on every pyramid level and return the pose within 1e-6."""
+    from megapose6d_amd.icp_refiner import ICPRefiner
+    from oracle import icp_opencv as ocv
+    from tests.support.scene import make_multi_frame_scene
+
+    est, obs, det, ds = make_multi_frame_scene(8, 8, 16, SO3_grid_size=576, depth_obs=True)
+    renderer = est.coarse_model.renderer
+    est.depth_refiner = ICPRefiner(est.mesh_db, renderer)
+    est.render_dtype = torch.float16
+    assert obs.depth is not None and obs.depth.shape == (8, 480, 640)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=5, run_depth_refiner=True)
+    assert est.refiner_model._x[0].dtype == torch.float16   # the fp16-renders mode really ran
+    # the stage's outputs, as the reference writes them (:607-616, :637-638)
+    assert len(final) == 64 and torch.isfinite(final.poses).all()
+    assert set(extra) == {"coarse", "coarse_filter", "refiner_all_hypotheses", "scoring", "refiner", "timing_str", "time", "depth_refiner"}
+    assert set(extra["depth_refiner"]) == {"preds"} and extra["depth_refiner"]["preds"] is final
+    assert "depth refiner=" in extra["timing_str"]
+    pre = extra["refiner"]["preds"]            # data_TCO_final_scored: the refiner's input
+    assert len(pre) == 64 and torch.equal(final.poses_input, pre.poses)
+    assert final.infos[["label", "batch_im_id", "instance_id"]].reset_index(drop=True).equals(
+        pre.infos[["label", "batch_im_id", "instance_id"]].reset_index(drop=True))
+    # the stage is deterministic: running the refiner again on the same input returns the pipeline's poses (+ its telemetry)
+    again, tel = est.depth_refiner.refine_poses(pre, depth=obs.depth, K=obs.K)
+    assert torch.equal(again.poses, final.poses)
+    retval, iters = tel["retval"].cpu().numpy(), tel["iterations_per_level"].cpu().numpy()
+    assert (retval == 0).sum() >= 48, retval   # most detections are refined (occluded ones may fall under the 1000-point rule)
+    moved = (final.poses - pre.poses).abs().flatten(1).max(1).values.cpu().numpy()
+    assert np.all((moved > 0) == (retval == 0))   # rejected -> the input pose is kept (icp_refiner.py:257-258)
+    # the restatement on 8 sampled detections (one per frame, different positions in the frame's detection list)
+    labels = pre.infos["label"].tolist()
+    im_ids = pre.infos["batch_im_id"].values.astype(np.int64)
+    sample = [int(np.nonzero(im_ids == f)[0][(3 * f) % 8]) for f in range(8)]
+    rend = renderer.render_depth([labels[i] for i in sample], pre.poses[sample].float(), obs.K[im_ids[sample]].float(), (480, 640)).cpu().numpy()
+    depth, K = obs.depth.cpu().numpy().astype(np.float32), obs.K.cpu().numpy().astype(np.float32)
+    n_accepted = 0
+    for k, i in enumerate(sample):
+        dm = depth[im_ids[i]]
+        info = {}
+        T_cv, rv_cv, res_cv = ocv.icp_refinement(dm, rend[k], ocv.compute_masks_threshold(rend[k], dm), K[im_ids[i]],
+                                                 pre.poses[i].cpu().numpy().astype(np.float32), info=info)
+        row = (i, rv_cv, int(retval[i]), info.get("iters"), iters[i].tolist(), float(np.abs(final.poses[i].cpu().numpy() - T_cv).max()))
+        print(row)
+        assert rv_cv == retval[i], row
+        if rv_cv == 0:
+            n_accepted += 1
+            assert info["iters"] == iters[i].tolist(), row
+            assert row[-1] <= 1e-6, row
+        else:
+            assert np.array_equal(final.poses[i].cpu().numpy(), pre.poses[i].cpu().numpy()), row
+    assert n_accepted >= 4
+
+
 def test_projective_refiner_vs_opencv_icp_restatement_on_12_scenes():
     """The reference's refiner = get_normal + OpenCV ppf_match_3d ICP (kd-tree association, robust rejection, 4-level pyramid),
     restated in oracle/icp_opencv.py (inference/icp_refiner.py:37-175).  The engine's OPTIONAL cheaper refiner associates projectively.

@@ -52,8 +52,8 @@ def test_pipeline_matches_reference_golden(scene72):
         p = extra["refiner_all_hypotheses"]["preds"][f"iteration={n}"]
         assert np.abs(p.poses.cpu().numpy()[order] - g[f"refiner_poses_{n}"]).max() < 1e-4, n
         kc, kg = p.K_crop.cpu().numpy()[order], g[f"refiner_K_crop_{n}"]
-        assert (np.abs(kc - kg) / np.maximum(np.abs(kg), 1)).max() < 1e-4
-        assert np.abs(p.boxes_crop.cpu().numpy()[order] - g[f"refiner_boxes_crop_{n}"]).max() < 0.05
+        assert (np.abs(kc - kg) / np.maximum(np.abs(kg), 1)).max() < 2e-6   # fp32 round-off of values up to ~1e3
+        assert np.abs(p.boxes_crop.cpu().numpy()[order] - g[f"refiner_boxes_crop_{n}"]).max() < 1e-3   # pixels
     sl = extra["scoring"]["data"]["logits"].cpu().numpy().flatten()[order]
     assert_logits_close(sl, g["scoring_logits"], scale)
     assert np.abs(final.poses.cpu().numpy() - g["final_TCO"]).max() < 1e-4
