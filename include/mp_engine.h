@@ -271,6 +271,11 @@ size_t mp_conv_stem_packed_bytes(int KS, int n_f32, int n_u8, int Cout);
 int mp_conv_stem_pack_weights(const float* h_w_oihw, int Cout, int Cin, int KS, int n_f32, const float* h_scale /*[Cout] or NULL*/,
                               void* h_packed);
 int mp_conv_stem_xrec(const mp_conv_desc* desc, const void* d_packed, int n_f32, mp_stream stream);
+/* the same with the 3x3 / stride-2 / pad-1 max pool that follows the stem (models/torchvision_resnet.py:216) fused into the epilogue:
+ * d_ypool = padded NHWC [N, (Ho-1)/2+1, (Wo-1)/2+1, Cout] with border pool_border; desc->relu must be set; desc->d_y may be NULL (the stem
+ * map is then never written).  Windows that straddle the kernel's 8 x 16 tiles are combined with unsigned atomicMax on the (non-negative)
+ * float bits: deterministic. */
+int mp_conv_stem_xrec_pool(const mp_conv_desc* desc, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream);
 
 /* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
 int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,

@@ -367,6 +367,7 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
   }
   float* SK = p;  // split-K scratch (SPLITK_WS_FLOATS)
   int rc;
+  bool stem_pooled = false;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
   if (x_mode == 2) {
     MP_REQUIRE(mp_backbone_xrec_elements(bb, n_f32) > 0, "mp_backbone_forward_xrec: this backbone's stem has no exact-piece form for %d fp32 channels of %d",
@@ -376,15 +377,26 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
     d.d_x = d_x; d.N = batch; d.H = h; d.W = w; d.C = bb->stem.Cin_p; d.c_real = bb->c_in; d.in_border = bb->in_border;
     d.d_bias = bb->stem.d_b; d.Cout = bb->stem.Cout; d.KH = bb->stem.K; d.KW = bb->stem.K; d.stride = 2; d.pad = bb->stem.pad;
     d.d_y = S; d.out_border = 1; d.relu = 1;
-    rc = mp_conv_stem_xrec(&d, bb->d_stem_pieces, n_f32, s);
+    // vanilla ResNet: the max pool rides in the stem's epilogue and the stem map is never written (MP_STEM_POOL=0: separate kernels);
+    // the pre-activation WideResNets need relu(bn1(pooled)) as a second output of the pool, which takes the complete maximum
+    static const bool fuse_pool = !(getenv("MP_STEM_POOL") && atoi(getenv("MP_STEM_POOL")) == 0);
+    if (!bb->wide && fuse_pool) {
+      d.d_y = nullptr;
+      rc = mp_conv_stem_xrec_pool(&d, bb->d_stem_pieces, n_f32, A[0], 1, s);
+      stem_pooled = true;
+    } else {
+      rc = mp_conv_stem_xrec(&d, bb->d_stem_pieces, n_f32, s);
+    }
   } else {
     rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
   }
   if (rc) return rc;
   const Block& b0 = bb->blocks[0];
-  rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, bb->stageC[0], 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
-                       bb->wide ? b0.pre.d_shift : nullptr, s);
-  if (rc) return rc;
+  if (!stem_pooled) {
+    rc = mp_maxpool3x3s2(S, batch, g.h1, g.w1, bb->stageC[0], 1, A[0], 1, bb->wide ? Aact[0] : nullptr, bb->wide ? b0.pre.d_scale : nullptr,
+                         bb->wide ? b0.pre.d_shift : nullptr, s);
+    if (rc) return rc;
+  }
   const int nb = (int)bb->blocks.size();
   for (int i = 0; i < nb; ++i) {
     const Block& blk = bb->blocks[i];

@@ -59,6 +59,9 @@ struct Params {
   int relu;
   unsigned img_bytes;    // Hp * Wp * 16Q
   unsigned out_bytes;
+  // fused 3x3 / stride-2 / pad-1 max pool (POOL instances): pooled output, padded NHWC with border pool_border
+  float* __restrict__ ypool;
+  int Hq, Wq, pool_border;
 };
 
 template <int KS, int Q>
@@ -76,7 +79,12 @@ struct Geo {
   static_assert(4 * T + 4 - S <= KWQ, "padding slices (and the look-ahead read past the last step) must stay inside the extra row");
 };
 
-template <int KS, int Q>
+// POOL: the 3x3 / stride-2 / pad-1 max pool that follows the stem (models/torchvision_resnet.py:216) is taken from the tile while it sits in
+// LDS: a pooled pixel whose window lies inside the tile (21 of the 45 an 8 x 16 tile touches) is stored; one whose window straddles tiles
+// is combined with unsigned atomicMax on the float bits (the values are post-ReLU, >= 0: the integer order IS the float order; max is
+// associative and commutative, so the result is deterministic) into a position that pool_zero_kernel cleared beforehand.  The stem map
+// itself is then never written (y may be NULL) and the separate pool kernel + its 2.9-GB read at 576 rows disappear.
+template <int KS, int Q, bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem_bf16x3(Params p) {
   using G = Geo<KS, Q>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -190,7 +198,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
   }
   __syncthreads();
-  {
+  if constexpr (POOL) {
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int Hqp = p.Hq + 2 * p.pool_border, Wqp = p.Wq + 2 * p.pool_border;
+    const float4* tile4 = reinterpret_cast<const float4*>(lds);   // [128 pixels][16 groups of 4 channels]
+    for (int item = tid; item < (TH / 2 + 1) * (TW / 2 + 1) * 16; item += 256) {
+      const int part = item & 15, pp = item >> 4;
+      const int ppy = pp / (TW / 2 + 1), ppx = pp - ppy * (TW / 2 + 1);
+      const int PY = ty * (TH / 2) + ppy, PX = tx * (TW / 2) + ppx;
+      if (PY >= p.Hq || PX >= p.Wq) continue;
+      // the part of the window [2P-1, 2P+1] that is inside the image ...
+      const int wr0 = max(2 * PY - 1, 0), wr1 = min(2 * PY + 1, p.Ho - 1), wc0 = max(2 * PX - 1, 0), wc1 = min(2 * PX + 1, p.Wo - 1);
+      // ... and inside this tile
+      const int r0 = max(wr0, oy0), r1 = min(wr1, oy0 + TH - 1), c0 = max(wc0, ox0), c1 = min(wc1, ox0 + TW - 1);
+      if (r0 > r1 || c0 > c1) continue;
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = r0; r <= r1; ++r)
+        for (int c = c0; c <= c1; ++c) {
+          const float4 v = tile4[((r - oy0) * TW + (c - ox0)) * 16 + part];
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      float* dst = p.ypool + ((((size_t)n * Hqp + PY + p.pool_border) * Wqp + PX + p.pool_border) * p.Cout + cb * NCO + part * 4);
+      if (r0 == wr0 && r1 == wr1 && c0 == wc0 && c1 == wc1) {
+        *reinterpret_cast<float4*>(dst) = m;
+      } else {   // (& 0x7FFFFFFF: a -0.0 out of the ReLU must not outrank every positive value)
+        unsigned* du = reinterpret_cast<unsigned*>(dst);
+        atomicMax(du, __float_as_uint(m.x) & 0x7FFFFFFFu); atomicMax(du + 1, __float_as_uint(m.y) & 0x7FFFFFFFu);
+        atomicMax(du + 2, __float_as_uint(m.z) & 0x7FFFFFFFu); atomicMax(du + 3, __float_as_uint(m.w) & 0x7FFFFFFFu);
+      }
+    }
+  }
+  if (!POOL || p.y != nullptr) {
     const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.out_bytes, 0x00020000);
     const int oy0 = ty * TH, ox0 = tx * TW;
 #pragma unroll
@@ -206,7 +244,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int KS, int Q>
+// clears the pooled positions that more than one tile contributes to (every pooled row 4k and pooled column 8k: the windows that straddle
+// the 8 x 16 stem tiles), one thread per (position, 4 channels)
+__global__ __launch_bounds__(256) void pool_zero_kernel(float* __restrict__ y, int N, int Hq, int Wq, int C, int border) {
+  const int c4n = C / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * Hq * Wq * c4n) return;
+  const int c4 = (int)(idx % c4n);
+  long t = idx / c4n;
+  const int px = (int)(t % Wq);
+  t /= Wq;
+  const int py = (int)(t % Hq), n = (int)(t / Hq);
+  if ((py % (TH / 2)) != 0 && (px % (TW / 2)) != 0) return;
+  *reinterpret_cast<float4*>(y + ((((size_t)n * (Hq + 2 * border) + py + border) * (Wq + 2 * border) + px + border) * C + c4 * 4)) =
+      make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int KS, int Q, bool POOL = false>
 int launch(const Params& p, hipStream_t s, double flops, double bytes, const char* name) {
   // executed on the bf16 pipe: every 16x16x32 MFMA of every step, three weight pieces (this counts the record padding, the step padding
   // and the nine products of the fp32-kind channels as what they cost)
@@ -216,11 +270,16 @@ int launch(const Params& p, hipStream_t s, double flops, double bytes, const cha
   int dev = 0;
   MP_CHECK_HIP(hipGetDevice(&dev));
   if (attr_dev != dev) {
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_bf16x3<KS, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_bf16x3<KS, Q, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
     attr_dev = dev;
   }
+  if (POOL) {
+    ProfScope prof0("pool_zero", 0.0, 16.0 * p.N * (p.Hq / 4 + 1) * p.Wq * p.Cout, s);
+    const long total = (long)p.N * p.Hq * p.Wq * (p.Cout / 4);
+    hipLaunchKernelGGL(pool_zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.ypool, p.N, p.Hq, p.Wq, p.Cout, p.pool_border);
+  }
   ProfScope prof(name, flops, bytes, s, executed, 2500.0);
-  hipLaunchKernelGGL((conv_stem_bf16x3<KS, Q>), dim3((unsigned)((long)p.N * p.tiles_y * p.tiles_x * p.n_cb)), dim3(256), G::LDS, s, p);
+  hipLaunchKernelGGL((conv_stem_bf16x3<KS, Q, POOL>), dim3((unsigned)((long)p.N * p.tiles_y * p.tiles_x * p.n_cb)), dim3(256), G::LDS, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
@@ -298,8 +357,9 @@ extern "C" int mp_conv_stem_pack_weights(const float* w, int Cout, int Cin, int 
 
 // d_x = xrec tensor (bf16 records, padded NHWC with border in_border); the other fields as mp_conv2d_nhwc; KH = KW in {5, 7},
 // stride 2, Cout % 64 == 0, no residual / second output
-extern "C" int mp_conv_stem_xrec(const mp_conv_desc* d, const void* d_packed, int n_f32, mp_stream stream) {
-  MP_REQUIRE(d && d->d_x && d_packed && d->d_y, "mp_conv_stem_xrec: null pointer");
+static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream) {
+  MP_REQUIRE(d && d->d_x && d_packed && (d->d_y || d_ypool), "mp_conv_stem_xrec: null pointer");
+  MP_REQUIRE(!d_ypool || (d->relu && pool_border >= 0), "mp_conv_stem_xrec_pool: the fused max pool needs the ReLU (its atomicMax orders non-negative floats)");
   const int n_u8 = d->c_real - n_f32;
   MP_REQUIRE(d->KH == d->KW && d->stride == 2 && d->Cout % stem::NCO == 0 && !d->d_residual && !d->d_y_act && d->in_border >= d->pad &&
                  mp_conv_stem_supported(d->KH, n_f32, n_u8),
@@ -317,15 +377,32 @@ extern "C" int mp_conv_stem_xrec(const mp_conv_desc* d, const void* d_packed, in
   const long img = (long)p.Hp * p.Wp * 16 * Q, outb = (long)d->N * p.Hop * p.Wop * d->Cout * 4;
   MP_REQUIRE(img < (1L << 31) && outb < 0xFFFFFF00L && (long)d->N * p.tiles_y * p.tiles_x * p.n_cb < (1L << 31), "mp_conv_stem_xrec: tensor too large for 32-bit offsets");
   p.img_bytes = (unsigned)img; p.out_bytes = (unsigned)outb;
+  p.ypool = d_ypool; p.pool_border = pool_border;
+  p.Hq = (p.Ho + 2 - 3) / 2 + 1; p.Wq = (p.Wo + 2 - 3) / 2 + 1;
   const double M = (double)d->N * p.Ho * p.Wo;
   const double flops = 2.0 * M * d->Cout * d->KH * d->KW * d->c_real;
-  const double bytes = (double)d->N * img + 4.0 * M * d->Cout + (double)mp_conv_stem_packed_bytes(d->KH, n_f32, n_u8, d->Cout);
+  const double bytes = (double)d->N * img + (d->d_y ? 4.0 * M * d->Cout : 0.0) + (d_ypool ? 4.0 * (double)d->N * p.Hq * p.Wq * d->Cout : 0.0) +
+                       (double)mp_conv_stem_packed_bytes(d->KH, n_f32, n_u8, d->Cout);
   hipStream_t s = (hipStream_t)stream;
-#define MP_STEM_GO(KSV, QV) \
-  if (d->KH == KSV && Q == QV) return stem::launch<KSV, QV>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");
+#define MP_STEM_GO(KSV, QV)                                                                                                          \
+  if (d->KH == KSV && Q == QV)                                                                                                     \
+    return d_ypool ? stem::launch<KSV, QV, true>(p, s, flops, bytes, "conv_stem_bf16x3+maxpool<" #KSV "x" #KSV ",Q" #QV ">")         \
+                   : stem::launch<KSV, QV, false>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");
   MP_STEM_GO(7, 2) MP_STEM_GO(7, 3) MP_STEM_GO(7, 4) MP_STEM_GO(7, 5)
   MP_STEM_GO(5, 2) MP_STEM_GO(5, 3) MP_STEM_GO(5, 4) MP_STEM_GO(5, 5)
 #undef MP_STEM_GO
   set_error("mp_conv_stem_xrec: no instance for %dx%d, record of %d elements", d->KH, d->KW, R);
   return MP_ERR_INVALID;
+}
+
+extern "C" int mp_conv_stem_xrec(const mp_conv_desc* d, const void* d_packed, int n_f32, mp_stream stream) {
+  MP_REQUIRE(d && d->d_y, "mp_conv_stem_xrec: null output");
+  return stem_xrec_impl(d, d_packed, n_f32, nullptr, 0, stream);
+}
+
+// the same + the 3x3 / stride-2 / pad-1 max pool of the stem output (models/torchvision_resnet.py:216) fused into the epilogue: d_ypool =
+// padded NHWC [N][(Ho+1)/2 ...] with border pool_border (zero border, interior fully written); desc->d_y may be NULL (no stem map)
+extern "C" int mp_conv_stem_xrec_pool(const mp_conv_desc* d, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream) {
+  MP_REQUIRE(d_ypool, "mp_conv_stem_xrec_pool: null pooled output");
+  return stem_xrec_impl(d, d_packed, n_f32, d_ypool, pool_border, stream);
 }

@@ -56,19 +56,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tg = wg / p.n_cblocks;
   const int tile0 = tg * WT;
 
-  if (tid < WT) {
-    const int t = tile0 + tid;
-    int off = -1, bits = 0;
-    if (t < p.n_tiles) {
-      const int tx = t % p.tiles_x, r = t / p.tiles_x;
-      const int ty = r % p.tiles_y, n = r / p.tiles_y;
-      off = ((n * p.Hop + 2 * ty + p.out_border) * p.Wop + 2 * tx + p.out_border) * p.Cout;
-      bits = ((2 * ty + 1 < p.Ho) ? 1 : 0) | ((2 * tx + 1 < p.Wo) ? 2 : 0);
-    }
-    tile_tab[2 * tid] = off;
-    tile_tab[2 * tid + 1] = bits;
-  }
-
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, -1, 0x00020000);
   const int row_bytes = p.Wp * p.C * 4, pix_bytes = p.C * 4;
   // weights: [cb][step][f][j][piece][lane][8 bf16]; this wave's four frequency points of a step are 24 KB contiguous
@@ -93,15 +80,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 
   f32x16 acc[4][2][2];
-#pragma unroll
-  for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[fi][i][j][r] = 0.f;
-
   const int ns = p.n_steps;
   u32x4 Ua[2][3], Ub[2][3];   // weight fragments [cout block][piece] of the current / the next frequency point
   u32x4 AA[2][3], AB[2][3];   // V fragments [tile block][piece], likewise
@@ -109,7 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   unsigned sm0, sm1, sm2, sm3;            // the split in flight: masked values,
   float sr0, sr1, sr2, sr3, sq0, sq1, sq2, sq3;   // first and second remainders of the four elements
   float4 trw[4], tplane;      // row combination of the transform row in flight, the plane on its way to LDS
-  if (DIAG) {   // (timing experiments: whatever the skipped work would have produced just has to be defined)
+  if (DIAG & 7) {   // (timing experiments: whatever the skipped work would have produced just has to be defined)
     _Pragma("unroll") for (int i = 0; i < 2; ++i)
       _Pragma("unroll") for (int q = 0; q < 3; ++q) { AA[i][q] = AB[i][q] = Ua[i][q] = Ub[i][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }
     _Pragma("unroll") for (int a = 0; a < 4; ++a) { trw[a] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -249,16 +227,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- prologue: V of step 0 in stage 0, the patch of step 1 in registers, weights + split fragments of (step 0, point 0), the raw
   //      fragments of point 1 ---------------------------------------------------------------------------------------------------------
-  _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
-  _Pragma("unroll") for (int a = 0; a < 4; ++a)
-    _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
-#define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
-  WB_TR_ROW(0, vw) WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  // every request the first two steps need goes out at once (one memory round trip instead of two: the CU runs ONE workgroup, nothing
+  // else hides this latency); the tile table of the epilogue and the accumulator reset fill the wait
+  float4 pnext[4][4];
   {
     const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
     _Pragma("unroll") for (int a = 0; a < 4; ++a)
-      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, cs1) }
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) pnext[a][bb] = buf4(x_rsrc, x_voff, cs1 + a * row_bytes + bb * pix_bytes);
   }
+  WB_SB
+  if (tid < WT) {
+    const int t = tile0 + tid;
+    int off = -1, bits = 0;
+    if (t < p.n_tiles) {
+      const int tx = t % p.tiles_x, r = t / p.tiles_x;
+      const int ty = r % p.tiles_y, n = r / p.tiles_y;
+      off = ((n * p.Hop + 2 * ty + p.out_border) * p.Wop + 2 * tx + p.out_border) * p.Cout;
+      bits = ((2 * ty + 1 < p.Ho) ? 1 : 0) | ((2 * tx + 1 < p.Wo) ? 2 : 0);
+    }
+    tile_tab[2 * tid] = off;
+    tile_tab[2 * tid + 1] = bits;
+  }
+
+  {   // accumulator reset by the matrix pipe itself (0 x 0 + 0: 16 instructions instead of 256 register writes right before the loop;
+      // asm volatile: as a builtin the 16 identical products are merged into one and copied)
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    _Pragma("unroll") for (int fi = 0; fi < 4; ++fi)
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4));
+  }
+  WB_SB
+#define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
+  WB_TR_ROW(0, vw) WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  _Pragma("unroll") for (int a = 0; a < 4; ++a)
+    _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = pnext[a][bb];
   __syncthreads();
   WB_READ_RAW1(vr, 0, 0) WB_READ_RAW1(vr, 0, 1) WB_READ_RAW1(vr, 0, 2) WB_READ_RAW1(vr, 0, 3)
 #define WB_SPLIT4(AN, I, H) WB_SP0(AN, I, H) WB_SP1(I, H) WB_SP2(AN, I, H) WB_SP3() WB_SP4(AN, I, H)
@@ -282,6 +288,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     { constexpr int fi = 0; WB_HEAD(AA, AB, Ua, Ub, st, 1) WB_TAIL_TR(AA, AB, Ua, 0, 1, vwn, vb, 2) }
     { constexpr int fi = 1; WB_HEAD(AB, AA, Ub, Ua, st, 2) WB_TAIL_TR(AB, AA, Ub, 2, 3, vwn, vb, 3) }
     __syncthreads();
+#ifdef MP_CONV_EXPERIMENTS
+    if (DIAG & 8) { for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(1); }    // skew the four waves by 64 cycles each
+    if (DIAG & 16) { for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(2); }   // ... by 128 cycles each
+#endif
     { constexpr int fi = 2; WB_HEAD(AA, AB, Ua, Ub, st, 3) WB_TAIL_PL(AA, AB, Ua, 0, 1, cs_patch, vbn, 0) }
     { constexpr int fi = 3; WB_HEAD(AB, AA, Ub, Ua, st_next, 0) WB_TAIL_PL(AB, AA, Ub, 2, 3, cs_patch, vbn, 1) }
   }
@@ -502,6 +512,8 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
 #endif
     attr_dev = dev;
   }
@@ -519,6 +531,8 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   else if (diag == 2) hipLaunchKernelGGL(conv3x3_wino_bf16x9<2>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   else if (diag == 4) hipLaunchKernelGGL(conv3x3_wino_bf16x9<4>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   else if (diag == 7) hipLaunchKernelGGL(conv3x3_wino_bf16x9<7>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  else if (diag == 8) hipLaunchKernelGGL(conv3x3_wino_bf16x9<8>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  else if (diag == 16) hipLaunchKernelGGL(conv3x3_wino_bf16x9<16>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   else
 #endif
   hipLaunchKernelGGL(conv3x3_wino_bf16x9<0>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);

@@ -376,14 +376,19 @@ def xrec_elements(n_f32: int, n_u8: int) -> int:
 
 
 def conv_stem_xrec(xrec: torch.Tensor, N: int, H: int, W: int, c_real: int, n_f32: int, in_border: int, w_pieces: torch.Tensor,
-                   bias: Optional[torch.Tensor], Cout: int, K: int, pad: int, y: torch.Tensor, out_border: int, relu: bool = False) -> None:
-    """stride-2 stem convolution of a bfloat16 record tensor (mp_conv_stem_xrec)"""
+                   bias: Optional[torch.Tensor], Cout: int, K: int, pad: int, y: Optional[torch.Tensor], out_border: int, relu: bool = False,
+                   y_pool: Optional[torch.Tensor] = None, pool_border: int = 1) -> None:
+    """stride-2 stem convolution of a bfloat16 record tensor (mp_conv_stem_xrec); with `y_pool` the 3x3 / stride-2 / pad-1 max pool of its
+    output is written too (mp_conv_stem_xrec_pool; `y` may then be None)"""
     assert xrec.dtype == torch.bfloat16 and w_pieces.dtype == torch.uint8
     d = ConvDesc()
     d.d_x, d.N, d.H, d.W, d.C, d.c_real, d.in_border = xrec.data_ptr(), N, H, W, (c_real + 3) // 4 * 4, c_real, in_border
     d.d_bias = _ptr(bias)
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, 2, pad
-    d.d_y, d.out_border, d.relu = y.data_ptr(), out_border, int(relu)
+    d.d_y, d.out_border, d.relu = _ptr(y), out_border, int(relu)
+    if y_pool is not None:
+        check(_lib.load().mp_conv_stem_xrec_pool(C.byref(d), w_pieces.data_ptr(), n_f32, y_pool.data_ptr(), pool_border, _stream()))
+        return
     check(_lib.load().mp_conv_stem_xrec(C.byref(d), w_pieces.data_ptr(), n_f32, _stream()))
 
 

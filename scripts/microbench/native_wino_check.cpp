@@ -162,7 +162,7 @@ static int run_case(const Case& s, int* n_bad) {
     for (int r = 0; r < reps; ++r) MP_OKAY(mp_conv3x3_wino_bf16_nhwc(&g, d_ub, nullptr));
     HIP_OK(hipEventRecord(e3, nullptr));
     if (getenv("MP_WINO_DIAG_SWEEP")) {   // timing experiments of an MP_CONV_EXPERIMENTS build of the library (results of diag != 0 are wrong)
-      for (int diag : {0, 1, 2, 4, 7}) {
+      for (int diag : {0, 8, 16, 1, 2, 4, 7}) {
         char buf[8];
         snprintf(buf, sizeof(buf), "%d", diag);
         setenv("MP_WINO_DIAG", buf, 1);
@@ -178,7 +178,7 @@ static int run_case(const Case& s, int* n_bad) {
         HIP_OK(hipEventElapsedTime(&ms, a0, a1));
         double mhz = 0, cps = 0;
         MP_OKAY(mp_conv_wino_bf16_clock(&mhz, &cps, 1));
-        printf("DIAG %-34s | diag %d (1 no split, 2 no patch/transform, 4 no weight loads): %7.3f ms, %6.0f MHz, %7.0f cycles per step = %5.1f per MFMA\n",
+        printf("DIAG %-34s | diag %d (1 no split, 2 no patch/transform, 4 no weight loads, 8 / 16 wave skew 64 / 128 cycles): %7.3f ms, %6.0f MHz, %7.0f cycles per step = %5.1f per MFMA\n",
                s.name, diag, ms / reps, mhz, cps, cps / 144.0);
       }
       unsetenv("MP_WINO_DIAG");

@@ -93,6 +93,38 @@ def test_stem_conv_on_records_matches_torch_fp32(eng, case, relu):
     assert full[:, 0].abs().max() == 0 and full[:, -1].abs().max() == 0 and full[:, :, 0].abs().max() == 0 and full[:, :, -1].abs().max() == 0
 
 
+@pytest.mark.parametrize("case", [STEM_CASES[1], STEM_CASES[0], (2, 3, 24, 34, 70, 7, 64), (1, 3, 24, 240, 320, 7, 64)])
+def test_fused_max_pool_equals_the_separate_pool_kernel_bit_for_bit(eng, case):
+    """mp_conv_stem_xrec_pool (max pool taken from the tile in LDS, windows that straddle tiles combined with atomicMax) against
+    mp_conv_stem_xrec + mp_maxpool3x3s2: the same fp32 maxima -> identical bits, whatever the order of the atomics; ragged tiles, odd
+    output sizes, with and without the stem map written as well.  Reference: models/torchvision_resnet.py:213-216."""
+    N, nf, nu, H, W, K, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.cat([torch.rand(N, nf, H, W, generator=g), torch.randint(0, 256, (N, nu, H, W), generator=g).float() / 255.0], dim=1)
+    w = torch.randn(Cout, nf + nu, K, K, generator=g) * (2.0 / ((nf + nu) * K * K)) ** 0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    pad = K // 2
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    rec = to_records(eng, x, nf, pad)
+    wp = torch.from_numpy(eng.conv_stem_pack_weights(w.numpy(), nf, scale.numpy())).cuda()
+    y = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda")
+    eng.conv_stem_xrec(rec, N, H, W, nf + nu, nf, pad, wp, bias.cuda(), Cout, K, pad, y, 1, relu=True)
+    ref = eng.padded_nhwc(N, Hq, Wq, Cout, 1, "cuda")
+    eng.maxpool3x3s2(y, N, Ho, Wo, Cout, 1, ref, 1)
+    for with_map in (False, True):
+        y2 = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda") if with_map else None
+        got = eng.padded_nhwc(N, Hq, Wq, Cout, 1, "cuda")
+        eng.padded_view(got, N, Hq, Wq, Cout, 1)[:] = 7.0   # stale values: every interior position must be cleared / overwritten
+        eng.conv_stem_xrec(rec, N, H, W, nf + nu, nf, pad, wp, bias.cuda(), Cout, K, pad, y2, 1, relu=True, y_pool=got, pool_border=1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        if with_map:
+            assert torch.equal(y2, y)
+    tref = F.max_pool2d(F.relu(F.conv2d(x, w * scale.view(-1, 1, 1, 1), bias, stride=2, padding=pad)), 3, 2, 1)
+    assert (eng.padded_view(ref, N, Hq, Wq, Cout, 1).permute(0, 3, 1, 2).cpu() - tref).abs().max().item() < 1e-5 * max(1.0, tref.abs().max().item())
+
+
 @pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 27)])
 def test_backbone_forward_on_records_matches_the_fp32_tensor_path(eng, kind, c_in):
     from tests.support import synthetic as syn
