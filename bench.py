@@ -354,9 +354,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # MP_BENCH_SHARED_GPU=1 (test rig only, never a measurement): all ranks share GPU 0 and talk over gloo -- exercises the world > 1
+    # code path of this script (sharding, gathers, per-rank diagnostics) on a 1-GPU box
+    shared_gpu = os.environ.get("MP_BENCH_SHARED_GPU", "0") == "1"
+    torch.cuda.set_device(0 if shared_gpu else int(os.environ.get("LOCAL_RANK", "0")))
     if world > 1:
-        mpd.init_from_env("nccl")
+        mpd.init_from_env("gloo" if shared_gpu else "nccl")
         mpd.stats.timing = True
     n_cu, lds, arch = eng.device_info()
 
@@ -392,6 +395,7 @@ def main():
         step()
     fence()
     mpd.stats.reset()
+    mpd.stats.timing = world > 1
     eng.conv_clock(reset=True)
     eng.conv_wino_bf16_clock(reset=True)
     eng.profile_begin()
@@ -404,11 +408,24 @@ def main():
     conv_mhz = eng.conv_clock(reset=True)   # shader clock INSIDE the (direct fp32) conv kernels of the timed steps
     wb_mhz, wb_cps = eng.conv_wino_bf16_clock(reset=True)   # ... and inside the K loops of the bf16x9 Winograd launches (+ cycles per step)
     gather_ms = mpd.stats.ms() if world > 1 else 0.0
+    gather_calls, gather_bytes = mpd.stats.calls, mpd.stats.bytes   # (of the timed steps only: the extra stage-timing call below gathers too)
+    host_topk_ms = mpd.stats.host_s * 1e3 / a.steps   # the replicated pandas top-K / arg-max of a step (does not shrink with the world size)
+    dt_local = dt
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     assert len(final) == n_obj and torch.isfinite(final.poses).all()
+    per_rank = None
+    if world > 1:   # one diagnostic row per rank, so that the first multi-GPU run says where each rank's time went
+        mine = {"rank": rank, "timed_region_ms_per_step": dt_local / a.steps * 1e3, "all_gather_ms_per_step": gather_ms / a.steps,
+                "host_topk_ms_per_step": host_topk_ms,
+                "kernel_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+        per_rank = [None] * world
+        try:
+            torch.distributed.all_gather_object(per_rank, mine)
+        except Exception as e:  # noqa: BLE001  (diagnostics must never take the measurement down)
+            per_rank = [{"error": f"{type(e).__name__}: {e}"[:200]}]
     # stage times from HIP events: one extra, untimed call with cuda_timer=True (each stage fenced, DEVICE render/model times)
     _, extra_t = step(cuda_timer=True)
     # sustained shader clock of THIS box under fp32-MFMA load (boxes of one pool differ by ~10 %): context for `roofline.frac`, not part of it
@@ -486,9 +503,15 @@ def main():
                         **{s: {"time": sd[s]["time"], "render_time": sd[s]["render_time"], "model_time": sd[s]["model_time"]} for s in sd},
                         "total": extra_t["time"]},
         }
+        out["host"] = {"replicated_topk_ms_per_step": host_topk_ms,
+                       "share_of_step": host_topk_ms / (dt / a.steps * 1e3),
+                       "projected_share_at_8_gpus_same_total_work": host_topk_ms / (dt / a.steps * 1e3 / 8.0 + host_topk_ms * 7.0 / 8.0),
+                       "note": "every rank repeats the pandas top-K / arg-max on the gathered table (DESIGN.md 5); if the projected share at 8 "
+                               "GPUs exceeds 0.10 move it to rank 0 + broadcast"}
         if world > 1:
+            out["per_rank"] = per_rank
             out["rccl"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
-                           "all_gathers_per_step": mpd.stats.calls / a.steps, "all_gather_bytes_per_step": mpd.stats.bytes / a.steps,
+                           "all_gathers_per_step": gather_calls / a.steps, "all_gather_bytes_per_step": gather_bytes / a.steps,
                            "all_gather_ms_per_step": gather_ms / a.steps}
             # one all-gather per stage (coarse | refiner, all iterations packed | scoring); config 5 adds none (ICP shards by object)
             assert abs(out["rccl"]["all_gathers_per_step"] - 3.0) < 1e-9, out["rccl"]

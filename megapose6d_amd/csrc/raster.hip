@@ -114,6 +114,7 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
                                                           int* __restrict__ ws, BinLayout lay) {
   extern __shared__ int counts[];  // [2][n_tiles]: counters of the binned / the large pieces, then (in place) exclusive offsets = fill cursors
   __shared__ int partial[2][BIN_THREADS];
+  __shared__ unsigned nearest;     // max over the pieces of (bits of the nearest vertex's 1/z, low bit replaced by the piece's orientation flag)
   const int view = blockIdx.x;
   const int tid = threadIdx.x;
   int* hdr = ws + (size_t)view * lay.view_ints;
@@ -126,10 +127,12 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
   const float* T = TCO + (size_t)view * 16;
   const float* Kv = K + (size_t)view * 9;
   for (int i = tid; i < 2 * lay.n_tiles; i += BIN_THREADS) counts[i] = 0;
+  if (tid == 0) nearest = 0u;
   __syncthreads();
   const bool finite = rc::view_finite(T, Kv);  // non-finite pose / intrinsics: empty lists -> zero image (panda3d_batch_renderer.py:109-135)
   const int F = finite ? m.n_faces : 0;
   // ---- phase 1: count ------------------------------------------------------------------------------------------------------
+  unsigned my_nearest = 0u;
   for (int t = tid; t < F; t += BIN_THREADS) {
     int n_pieces = 1;
     for (int which = 0; which < n_pieces; ++which) {
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
       int tx0, ty0, tx1, ty1;
       tile_range(p, ns, w, h, tx0, ty0, tx1, ty1);
       if (tx0 > tx1 || ty0 > ty1) continue;
+      my_nearest = max(my_nearest, (__float_as_uint(fmaxf(p.iz[0], fmaxf(p.iz[1], p.iz[2]))) & ~1u) | (unsigned)(p.flags & 1));
       int* cnt = ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > LARGE_TILES || rc::piece_extent(p) > rc::SMALL_EXTENT) ? counts_l : counts;
       const TileTest tt = tile_test_setup(p, ns);
       for (int ty = ty0; ty <= ty1; ++ty)
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
           if (tile_touched(tt, tx, ty)) atomicAdd(&cnt[ty * lay.tiles_x + tx], 1);
     }
   }
+  if (my_nearest) atomicMax(&nearest, my_nearest);
   __syncthreads();
   // ---- phase 2: exclusive scans of the two counter arrays (in place) ---------------------------------------------------------
   const int per = (lay.n_tiles + BIN_THREADS - 1) / BIN_THREADS;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
     hdr[0] = total_l;
     hdr[1] = total;
     hdr[2] = overflow ? 1 : 0;  // the lists do not fit: raster_tiles walks ALL piece indices of this view instead (slow, correct)
-    hdr[3] = 0;
+    hdr[3] = (int)(nearest & 1u);   // orientation flag of the view's nearest piece: which pieces raster_tiles visits first (a hint, see there)
   }
   __syncthreads();
   if (overflow) return;
@@ -255,6 +260,17 @@ __device__ unsigned long long g_raster_prof[16];
 #define PROF_COUNT(slot, n)
 #endif
 
+// minimum of a 32-bit value over the 64 lanes (wave-uniform result): four DPP steps inside the rows of 16, the rows through SGPRs
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+
 // ---- coverage form 1 (every binned record): block visits (arithmetic and lane layout: raster_core.h "block-visit coverage form").
 // The batch's <= 64 pieces sit one per lane; each lane turns its piece into a 48-byte BlkRec in the wave's LDS slice and tests it
 // against the tile's blocks (NS = 4: four 4x4-pixel blocks; NS = 1: the tile).  Then, block by block, the wave walks the set bits of
@@ -264,7 +280,7 @@ __device__ unsigned long long g_raster_prof[16];
 template <int NS>
 __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, int tile_x0, int tile_y0, int lane, int slot,
                                                    const uint32_t (&rel)[NS == 1 ? 1 : 4], unsigned ok_mask, uint4* blk,
-                                                   unsigned long long (&best)[NS == 1 ? 1 : 4], unsigned long long* n_visits = nullptr) {
+                                                   unsigned long long (&best)[NS == 1 ? 1 : 4], int front_swap, unsigned long long* n_visits = nullptr) {
   constexpr int NB = NS == 1 ? 1 : 4;
 #ifdef MP_RASTER_PROF
   const unsigned long long prof_ta = __builtin_readcyclecounter();
@@ -292,40 +308,34 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
   const unsigned long long prof_tb = __builtin_readcyclecounter();
   if (n_visits) n_visits[4] += prof_tb - prof_ta;
 #endif
+  // Occlusion bound (exact, hierarchical-z style).  Half of a closed mesh's pieces face away from the camera and can never win a sample
+  // that a facing piece covers; the two-sided contract still requires them wherever they might.  So per block the batch's pieces are
+  // visited in two phases: first the pieces whose screen orientation is the one of the view's NEAREST piece (`front_swap`, a hint from
+  // the binning pass: whichever phase order is taken, the result is the same), then the others -- and a piece of the second phase is
+  // visited only if it could still win a sample: if every sample of the block already holds a piece, a piece whose nearest vertex lies
+  // behind the FARTHEST of those holders loses every depth comparison (its 1/z at any covered sample is a convex combination of its
+  // vertices' 1/z; the bound carries a 2^-20 margin for the rounding of that combination, and ties are never culled).
+  const bool phase_a = active && (int)(p.flags & 1u) == front_swap;
+  const unsigned ub_hi = __float_as_uint(fmaxf(p.iz[0], fmaxf(p.iz[1], p.iz[2])) * (1.0f + 9.5367431640625e-7f));
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
 #ifdef MP_RASTER_PROF
-    unsigned long long m = touched[k];
+    const unsigned long long m_all = touched[k];
 #else
-    unsigned long long m = __ballot(active && rc::blk_touched(mine, rxmin, rxmax, rymin, rymax, NS, k));
+    const unsigned long long m_all = __ballot(active && rc::blk_touched(mine, rxmin, rxmax, rymin, rymax, NS, k));
 #endif
-#ifdef MP_RASTER_PROF
-    if (n_visits) *n_visits += __popcll(m);
-#endif
+    if (m_all == 0ull) continue;
+    const unsigned long long m_a = m_all & __ballot(phase_a);
     const bool ok = (ok_mask >> k) & 1u;
     const uint32_t rel_k = rel[k];
     unsigned long long bk = best[k];
     // visits, software-pipelined: the record of the NEXT visit is requested before the current one is evaluated (the LDS latency
     // of a visit would otherwise be exposed on every trip: the chain read -> 3 dot products -> compare -> depth is serial)
-#ifdef MP_RASTER_NOPIPE
-    while (m) {
-      const int j = __ffsll((long long)m) - 1;
-      m &= m - 1ull;
-      const uint4 a = blk[j * 3], b = blk[j * 3 + 1], c = blk[j * 3 + 2];
-      rc::BlkRec r;
-      r.dxy[0] = a.x; r.dxy[1] = a.y; r.dxy[2] = a.z;
-      r.thr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w);
-      r.e0[0] = (int)b.x; r.e0[1] = (int)b.y; r.e0[2] = (int)b.z;
-      r.inv_area = __uint_as_float(b.w);
-      r.iz[0] = __uint_as_float(c.x); r.iz[1] = __uint_as_float(c.y); r.iz[2] = __uint_as_float(c.z);
-      r.key_lo = c.w;
-      rc::cover_sample_rel(r, rel_k, [&](float wsum) {
-        const unsigned long long key = rc::depth_key_lo(wsum, r.key_lo);
-        if (ok && key > bk) bk = key;
-      });
-    }
-#else
-    if (m) {
+    auto visit_all = [&](unsigned long long m) {
+#ifdef MP_RASTER_PROF
+      if (n_visits) *n_visits += __popcll(m);
+#endif
+      if (!m) return;
       int j = __ffsll((long long)m) - 1;
       m &= m - 1ull;
       uint4 a = blk[j * 3], b = blk[j * 3 + 1], c = blk[j * 3 + 2];   // wave-uniform address: broadcast reads
@@ -349,8 +359,14 @@ __device__ __forceinline__ void cover_batch_blocks(const Piece& p, bool active, 
         if (!more) break;
         a = an; b = bn; c = cn;
       }
+    };
+    visit_all(m_a);
+    unsigned long long m_b = m_all & ~m_a;
+    if (m_b != 0ull && __ballot(bk != 0ull || !ok) == ~0ull) {   // every sample of the block (inside the image) holds a piece
+      const unsigned far_hi = wave_min_u32(ok ? (unsigned)(bk >> 32) : 0xFFFFFFFFu);   // 1/z bits of the farthest holder
+      m_b &= __ballot(ub_hi >= far_hi);
     }
-#endif
+    visit_all(m_b);
     best[k] = bk;
   }
   wave_lds_fence();   // the next batch rewrites the records
@@ -408,9 +424,10 @@ __host__ __device__ constexpr size_t tiles_zt_bytes(int ns) {
              ? (size_t)64 * ns * (sizeof(unsigned long long) + sizeof(unsigned)) : 64 * sizeof(rc::BlkRec);
 }
 
-constexpr size_t HDR_LDS_BYTES = 128;   // per wave: the list headers of an item's first four views (5 ints each)
+constexpr size_t HDR_LDS_BYTES = 128;   // per wave: the list headers of an item's first four views (6 ints each)
 struct ViewHdr {   // what a wave needs to know about one view's lists for its tile (wave-uniform)
   int begin, n_list, begin_l, n_large, overflow;
+  int front_swap;   // screen orientation (Piece.flags & 1) of the view's nearest piece: a hint for the order of the two visit phases
 };
 
 // OUT = OUT_F16 (MP_RASTER_F16, the "fp16 renders" mode of BASELINE.json configs[4]): `out` holds IEEE binary16 elements -- same element
@@ -501,6 +518,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const int* hdr = ws + (size_t)view * lay.view_ints;
     ViewHdr v;
     v.overflow = hdr[2];
+    v.front_swap = hdr[3];
     v.begin = 0; v.begin_l = 0; v.n_large = 0;
     if (v.overflow) {   // rare: the view's lists did not fit -> its tiles walk all 2F piece indices through the recompute path
       v.n_list = 2 * meshes[mesh_ids[view]].n_faces;
@@ -512,12 +530,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     return v;
   };
-  int* hdr_lds = (int*)(mine + per_wave - HDR_LDS_BYTES);   // [FAST_VIEWS][5] ints of this wave (behind its staging area)
+  int* hdr_lds = (int*)(mine + per_wave - HDR_LDS_BYTES);   // [FAST_VIEWS][6] ints of this wave (behind its staging area)
   {
     if (lane < min(views_per_item, FAST_VIEWS)) {
       int h_begin = 0, h_nlist = 0, h_begin_l = 0, h_nlarge = 0, h_over = 0;
       const int* hdr = ws + (size_t)(view0 + lane) * lay.view_ints;
       h_over = hdr[2];
+      const int h_front = hdr[3];
       if (h_over) {
         h_nlist = 2 * meshes[mesh_ids[view0 + lane]].n_faces;
       } else {
@@ -526,18 +545,18 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         h_begin_l = hdr[lay.off_tl + tile];
         h_nlarge = hdr[lay.off_tl + tile + 1] - h_begin_l;
       }
-      int* d = hdr_lds + lane * 5;
-      d[0] = h_begin; d[1] = h_nlist; d[2] = h_begin_l; d[3] = h_nlarge; d[4] = h_over;
+      int* d = hdr_lds + lane * 6;
+      d[0] = h_begin; d[1] = h_nlist; d[2] = h_begin_l; d[3] = h_nlarge; d[4] = h_over; d[5] = h_front;
     }
     wave_lds_fence();
   }
   auto hdr_of = [&](int r) {   // r is wave-uniform: broadcast LDS reads, straight into scalar registers
     if (r >= FAST_VIEWS) return fetch_hdr(view0 + r);
-    const int* d = hdr_lds + r * 5;
+    const int* d = hdr_lds + r * 6;
     ViewHdr v;
     v.begin = __builtin_amdgcn_readfirstlane(d[0]); v.n_list = __builtin_amdgcn_readfirstlane(d[1]);
     v.begin_l = __builtin_amdgcn_readfirstlane(d[2]); v.n_large = __builtin_amdgcn_readfirstlane(d[3]);
-    v.overflow = __builtin_amdgcn_readfirstlane(d[4]);
+    v.overflow = __builtin_amdgcn_readfirstlane(d[4]); v.front_swap = __builtin_amdgcn_readfirstlane(d[5]);
     return v;
   };
   ViewHdr vh_next = hdr_of(0);
@@ -599,11 +618,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         }
         const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
 #ifdef MP_RASTER_PROF
-        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best, &prof_acc[9]);
+        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best, vh.front_swap, &prof_acc[9]);
         PROF_COUNT(10, __popcll(__ballot(hit)))
         PROF_COUNT(12, 1)
 #else
-        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best);
+        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best, vh.front_swap);
 #endif
         PROF(2)
       }

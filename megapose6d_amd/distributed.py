@@ -63,6 +63,7 @@ class GatherStats:
         self.bytes = 0
         self.backend = None
         self._events = []
+        self.host_s = 0.0   # host time of the replicated table work (pandas top-K / arg-max): does not shrink with the world size
 
     def ms(self) -> float:
         """sum of the recorded all-gather intervals (synchronises)"""

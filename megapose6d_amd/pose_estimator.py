@@ -498,10 +498,13 @@ class PoseEstimator(torch.nn.Module):
         """Keep the top_K rows per (batch_im_id, label, instance_id) by `filter_field` (:643-667).  The sort is made
         stable so that exact ties resolve deterministically (lowest row first); the reference's default quicksort leaves
         tie order unspecified."""
+        t0 = time.perf_counter()
         df = data_TCO.infos
         group_cols = ["batch_im_id", "label", "instance_id"]
         df = df.sort_values(filter_field, ascending=ascending, kind="stable").groupby(group_cols).head(top_K)
-        return data_TCO[df.index.tolist()]
+        out = data_TCO[df.index.tolist()]
+        mpdist.stats.host_s += time.perf_counter() - t0   # (replicated on every rank: bench.py reports its share of a step)
+        return out
 
 
 # name used by BASELINE.json's north_star; the reference snapshot only has PoseEstimator (SURVEY.md section 0 item 6)

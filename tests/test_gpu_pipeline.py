@@ -272,6 +272,32 @@ def test_bench_self_launches_two_ranks_over_rccl():
     assert j["config"]["objects"] == 2
 
 
+def test_bench_multi_rank_code_path_with_two_ranks_on_one_gpu():
+    import os
+    """The world > 1 path of bench.py (row sharding, the three all-gathers per step, max-over-ranks timing, the per-rank diagnostic rows,
+    the host-share estimate) exactly as the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2` -- on the one GPU a test box has: MP_BENCH_SHARED_GPU=1 puts both ranks on GPU 0 and swaps RCCL for gloo (a test rig, not a
+    measurement).  The RCCL variant of the same call is test_bench_self_launches_two_ranks_over_rccl (needs two GPUs)."""
+    import json
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MP_BENCH_SHARED_GPU="1")
+    port = 29800 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["objects"] == 2
+    assert j["rccl"]["backend"] == "gloo" and j["rccl"]["world_size"] == 2 and j["rccl"]["all_gathers_per_step"] == 3
+    assert [r["rank"] for r in j["per_rank"]] == [0, 1] and all(r["timed_region_ms_per_step"] > 0 for r in j["per_rank"])
+    assert 0.0 < j["host"]["replicated_topk_ms_per_step"] < 200.0
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import subprocess
     import sys
