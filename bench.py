@@ -536,8 +536,13 @@ def main():
         if not a.no_cpu_baseline and world == 1 and a.config == 2 and k_hyp == N_HYP:
             cb = cpu_baseline(ds, obs.images, obs.K, det.bboxes)
             out["parity"] = parity_block(cb.pop("_values"), extra)
+            # The port is the SLOWER stand-in: the reference's own orchestration (imported from /root/reference, same CNN / rasteriser) ran the
+            # same rows 1.16-1.21x faster in the build container (profiles/r02_reference_vs_port_cpu.json; it cannot travel to the GPU box).
+            # A slower baseline would inflate the ratio, so `vs_cpu_baseline` is quoted against the port's rate x 1.21.
+            cb["reference_orchestration_factor"] = 1.21
+            cb["value_reference_orchestration_estimate"] = cb["value"] * 1.21
             out["cpu_baseline"] = cb
-            out["vs_cpu_baseline"] = out["value"] / cb["value"]
+            out["vs_cpu_baseline"] = out["value"] / cb["value_reference_orchestration_estimate"]
             # the thread setting `import megapose` itself enforces (reference src/megapose/__init__.py:39-40), smaller sample
             cb1 = cpu_baseline(ds, obs.images, obs.K, det.bboxes, budget_s=8.0, threads=1)
             cb1.pop("_values")

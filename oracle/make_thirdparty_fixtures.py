@@ -13,6 +13,7 @@ present and `pytest.skip("fixture absent")` otherwise.  Nothing here is imported
                              hash-defined synthetic weights of oracle.mask_rcnn, eval mode, on oracle.mask_rcnn.synthetic_images
                              -> boxes / labels / scores / masks of oracle.mask_rcnn.mask_rcnn_forward
   thirdparty_icp.npz         cv2.ppf_match_3d_ICP(100, 0.05, 2.5, 4).registerModelToScene on seeded point clouds with normals
+  thirdparty_inpaint.npz     cv2.inpaint(depth, holes, 5, cv2.INPAINT_NS) on a seeded depth map with holes (the un-restated call of get_normal)
                              (reference inference/icp_refiner.py:166-169)                 -> oracle.icp_opencv.opencv_icp
   thirdparty_panda3d.npz     the reference's Panda3dSceneRenderer (panda3d_scene_renderer.py:58-101, 298-358: 4x MSAA, mip-mapping,
                              16x anisotropy) on the lathe test mesh: rgb / normals / depth of a few views
@@ -123,6 +124,33 @@ def make_icp(out: Path) -> bool:
     return True
 
 
+def inpaint_inputs():
+    """a 120 x 160 metric depth map of a tilted, rippled surface with three kinds of holes (specks, a blob on the surface, a border strip)"""
+    rng = np.random.RandomState(9)
+    v, u = np.mgrid[0:120, 0:160].astype(np.float32)
+    d = (0.6 + 0.0009 * u - 0.0006 * v + 0.004 * np.sin(u / 9.0) * np.cos(v / 7.0)).astype(np.float32)
+    d[rng.rand(120, 160) < 0.03] = 0.0
+    d[50:62, 70:90] = 0.0
+    d[:, :5] = 0.0
+    return d
+
+
+def make_inpaint(out: Path) -> bool:
+    """cv2.inpaint(depth, mask, 5, cv2.INPAINT_NS) exactly as inference/icp_refiner.py:54 calls it: the one cv2 call of get_normal that is
+    NOT restated (engine and oracle use an onion-peel mean fill instead, INTEGRATION.md "Known deviation"); the fixture quantifies the gap."""
+    try:
+        import cv2
+    except Exception as e:  # noqa: BLE001
+        print(f"[skip] cv2 not available ({e})")
+        return False
+    d = inpaint_inputs()
+    mask = (d == 0).astype(np.uint8)
+    filled = cv2.inpaint(d, mask, 5, cv2.INPAINT_NS)
+    np.savez_compressed(out / "thirdparty_inpaint.npz", depth=d, filled=np.asarray(filled, np.float32), cv2_version=str(cv2.__version__))
+    print("thirdparty_inpaint.npz written, cv2", cv2.__version__)
+    return True
+
+
 def panda3d_views():
     """the lathe test mesh (tests/support/synthetic.make_lathe_mesh, seed 0) under three poses, K of the example scaled to 320x240"""
     from tests.support import synthetic as syn
@@ -174,7 +202,7 @@ def main():
     a = ap.parse_args()
     out = Path(a.out)
     out.mkdir(parents=True, exist_ok=True)
-    done = [f.__name__ for f in (make_roi_align, make_maskrcnn, make_icp, make_panda3d) if f(out)]
+    done = [f.__name__ for f in (make_roi_align, make_maskrcnn, make_icp, make_inpaint, make_panda3d) if f(out)]
     print("fixtures written by:", done or "none (no third-party package importable here)")
 
 

@@ -54,6 +54,69 @@ def test_opencv_icp_restatement_vs_cv2():
     assert abs(residual - float(g["residual"])) < 1e-4 * max(1.0, float(g["residual"]))
 
 
+def test_hole_fill_vs_cv2_inpaint_ns_gap_is_reported():
+    """`cv2.inpaint(..., INPAINT_NS)` (inference/icp_refiner.py:54) is NOT restated: engine and oracle fill depth holes with an onion-peel
+    mean (INTEGRATION.md "Known deviation").  Where the fixture exists this reports how far the two fills are apart on the same holes and
+    bounds the gap loosely -- both interpolate a smooth surface, so they must agree to millimetres, not bit for bit."""
+    from oracle import icp_opencv as oi
+
+    g = _fixture("thirdparty_inpaint.npz")
+    ours = oi._fill_holes(g["depth"].astype(np.float32))
+    holes = g["depth"] == 0
+    gap = np.abs(ours - g["filled"])[holes]
+    print(f"hole fill vs cv2.inpaint NS: mean |diff| {gap.mean() * 1e3:.3f} mm, max {gap.max() * 1e3:.3f} mm over {holes.sum()} hole pixels")
+    assert np.array_equal(ours[~holes], g["filled"][~holes])
+    assert gap.mean() < 2e-3 and gap.max() < 2e-2
+
+
+def test_reference_readme_known_answer_for_the_barbecue_sauce_example():
+    """The ONE known-answer vector of the reference (/root/reference/README.md:259): `run_inference_on_example barbecue-sauce
+    --run-inference` with the released megapose-1.0-RGB-multi-hypothesis weights writes TWO = quaternion (xyzw) + translation below.  The
+    example data and the checkpoints are downloads (no network here): the test runs where MEGAPOSE_DATA_DIR holds them and a GPU is
+    present, through THIS package's classes on the reference's own script logic; otherwise it skips."""
+    import json
+    import os
+
+    data = os.environ.get("MEGAPOSE_DATA_DIR")
+    if not data or not (Path(data) / "examples" / "barbecue-sauce" / "inputs" / "object_data.json").is_file():
+        pytest.skip("MEGAPOSE_DATA_DIR with examples/barbecue-sauce and the released checkpoints is absent (downloads)")
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from PIL import Image  # noqa: F401  (the example's rgb is a PNG)
+
+    from megapose6d_amd.load_model import NAMED_MODELS, load_named_model
+    from megapose6d_amd.object_dataset import RigidObject, RigidObjectDataset
+    from megapose6d_amd.tcoll import PandasTensorCollection
+    from megapose6d_amd.types import ObservationTensor
+    import pandas as pd
+
+    ex = Path(data) / "examples" / "barbecue-sauce"
+    cam = json.loads((ex / "camera_data.json").read_text())
+    det_j = json.loads((ex / "inputs" / "object_data.json").read_text())
+    rgb = np.asarray(Image.open(ex / "image_rgb.png"), dtype=np.uint8)
+    K = np.asarray(cam["K"], np.float32)
+    mesh = next(p for p in (ex / "meshes" / "barbecue-sauce").iterdir() if p.suffix in (".obj", ".ply"))
+    ds = RigidObjectDataset([RigidObject(label="barbecue-sauce", mesh_path=mesh, mesh_units="mm")])
+    model = "megapose-1.0-RGB-multi-hypothesis"
+    est = load_named_model(model, ds).cuda()
+    obs = ObservationTensor.from_numpy(rgb, None, K).cuda()
+    det = PandasTensorCollection(pd.DataFrame(dict(label=[d["label"] for d in det_j], batch_im_id=0, instance_id=np.arange(len(det_j)))),
+                                 bboxes=torch.as_tensor(np.asarray([d["bbox_modal"] for d in det_j], np.float32))).cuda()
+    final, _ = est.run_inference_pipeline(obs, detections=det, **NAMED_MODELS[model]["inference_parameters"])
+    T = final.poses[0].cpu().numpy()
+    q_ref = np.array([0.5453961536730983, 0.6226545207599095, -0.43295293693197473, 0.35692612413663855])
+    t_ref = np.array([0.10723329335451126, 0.07313819974660873, 0.45735278725624084])
+    x, y, z, w = q_ref
+    R_ref = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    # a Panda3D-vs-ours pixel difference can move a trained refiner's fixed point a little: millimetres / tenths of a degree, not 1e-4
+    assert np.abs(T[:3, 3] - t_ref).max() < 5e-3, (T[:3, 3], t_ref)
+    ang = np.degrees(np.arccos(np.clip((np.trace(R_ref.T @ T[:3, :3]) - 1) / 2, -1, 1)))
+    assert ang < 2.0, ang
+
+
 def test_oracle_rasteriser_vs_panda3d_pixel_statistics():
     """Panda3D's GL driver decides sample pattern / resolve / LOD: bit-exactness is not expected.  The test REPORTS the per-pixel mismatch
     statistics and bounds them loosely (silhouette agreement, mean colour error) -- a regression alarm, not a parity proof."""
