@@ -267,6 +267,40 @@ def extras(est, obs, det, steps: int) -> dict:
         finally:
             shutil.rmtree(tmp2, ignore_errors=True)
 
+    def activation_statistics():
+        # the seeded networks' post-ReLU activations are about half zeros; a trained network's are what they are.  bf16 MFMA work is
+        # power-limited, so the clock -- and with it every rate of this line -- depends on how much the operands toggle.  This entry makes
+        # that visible to the driver: one 576-row refiner backbone forward on the CNN input of the last step, (a) with the bench's network,
+        # (b) with every BatchNorm shift raised by 0.75 (dense activations: few zeros, N(0,1)-like operand statistics).
+        from megapose6d_amd import engine as eng_
+
+        m = est.refiner_model
+        x = m._x[0]
+        h, w = m.render_size
+        rows = min(576, m._x_rows[0])
+        res = {}
+        for name, shift in (("bench_network", 0.0), ("dense_activations", 0.75)):
+            sd = {k: (v.clone() + shift if (".bn" in k or k.endswith("bn1.bias") or "downsample.1" in k) and k.endswith(".bias") else v)
+                  for k, v in m.state_dict().items()}
+            bb = eng_.Backbone(m.backbone.backbone_str, m.backbone.n_inputs, "pose", 9, sd)
+            out_ = torch.empty(rows, 9, device="cuda")
+            kw = dict(n_f32=3) if x.dtype == torch.bfloat16 else {}
+            bb.forward(x, rows, h, w, out_, None, **kw)
+            torch.cuda.synchronize()
+            eng_.conv_wino_bf16_clock(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                bb.forward(x, rows, h, w, out_, None, **kw)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            mhz, cps = eng_.conv_wino_bf16_clock(reset=True)
+            res[name] = {"ms_per_576_row_forward": dt * 1e3, "bf16_winograd_k_loop_mhz": mhz, "k_loop_cycles_per_step": cps,
+                         "finite": bool(torch.isfinite(out_).all())}
+            bb.close()
+        res["note"] = ("conv stack of one refiner forward under two operand statistics; the ratio says how much slower a network with dense "
+                       "activations runs on the same kernels (clock give-back under bf16 MFMA load); informational")
+        return res
+    guarded("conv_stack_activation_statistics", activation_statistics)
     guarded("released_recipe_64_detections_K5", lambda: other_workload(
         4, "vanilla_resnet34", 5, "BASELINE configs[3] on one GPU with the RELEASED inference parameters (n_pose_hypotheses = 5, utils/load_model.py:31-34): "
         "64 detections over 8 frames, 36 864 coarse rows + 320 x 5 refiner rows + 320 score rows per call"))

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short_name(k: str) -> str:
-    k = k.replace("void ", "").replace("mp::", "")
+    k = k.replace("void ", "").replace("mp::", "").replace("stem::", "")
     m = re.match(r"(\w+)(<(.*)>)?\(", k + "(")
     if not m:
         return k
@@ -24,6 +24,13 @@ def short_name(k: str) -> str:
         return s
     if name == "conv3x3_wino_f32":
         return "conv3x3_wino_f32<64t,64c>"   # (the in-library profiler's row name of the Winograd kernel)
+    if name == "conv3x3_wino_bf16x9":
+        return "conv3x3_wino_bf16x9<64t,64c>"
+    if name == "conv_stem_bf16x3" and len(args) >= 2:
+        pool = len(args) >= 3 and args[2] in ("true", "1")
+        return f"conv_stem_bf16x3{'+maxpool' if pool else ''}<{args[0]}x{args[0]},Q{args[1]}>"
+    if name == "raster_tiles" and len(args) >= 2:
+        return {"0": "raster_tiles", "1": "raster_tiles/f16", "2": "raster_tiles/xrec"}.get(args[1], name)
     return name
 
 
