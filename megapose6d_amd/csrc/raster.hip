@@ -584,9 +584,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const int n_total = vh.n_list + vh.n_large;
     const long long cv = (long long)r * stride_view;
     if (n_total == 0) {   // nothing of this view reaches the tile (most tiles of a crop): background
-      if (c_rgb >= 0) { put(c_rgb + (int)cv, 0.f); put(c_rgb + (int)cv + 1, 0.f); put(c_rgb + (int)cv + 2, 0.f); }
-      if (do_norm) { put(c_normals + (int)cv, 0.f); put(c_normals + (int)cv + 1, 0.f); put(c_normals + (int)cv + 2, 0.f); }
-      if (do_depth) put(c_depth + (int)cv, 0.f);
+      if constexpr (OUT != OUT_XREC) {   // (a stem record was cleared as a whole when the wave started)
+        if (c_rgb >= 0) { put(c_rgb + (int)cv, 0.f); put(c_rgb + (int)cv + 1, 0.f); put(c_rgb + (int)cv + 2, 0.f); }
+        if (do_norm) { put(c_normals + (int)cv, 0.f); put(c_normals + (int)cv + 1, 0.f); put(c_normals + (int)cv + 2, 0.f); }
+        if (do_depth) put(c_depth + (int)cv, 0.f);
+      }
       PROF(0)
       continue;
     }

@@ -14,6 +14,33 @@ def _by_key(final):
     return {(int(df["batch_im_id"][i]), str(df["label"][i]), int(df["instance_id"][i])): final.poses[i] for i in range(len(df))}
 
 
+def _hyps(extra, im_map=lambda im: im):
+    """(frame, label, instance, hypothesis) -> (refined pose, score logit) of every scored hypothesis of a call"""
+    sc = extra["scoring"]["preds"]
+    df = sc.infos.reset_index(drop=True)
+    return {(im_map(int(df["batch_im_id"][i])), str(df["label"][i]), int(df["instance_id"][i]), int(df["hypothesis_id"][i])):
+            (sc.poses[i], float(df["pose_logit"][i])) for i in range(len(df))}
+
+
+def _assert_same_result(full_extra, full_final, part_extra, part_final, im_map=lambda im: im):
+    """Row independence, stated on what is row-wise: every refined hypothesis of `part` has the pose (5e-5) and the score logit (1e-4) it has
+    in `full`.  The FINAL pose is an arg-max over a detection's hypotheses: it must agree too, unless the detection's two best logits tie
+    within the comparison tolerance (the lathe test meshes are nearly symmetric: two hypotheses half a turn apart can score within 1e-5,
+    and which one wins then depends on the summation order of the launch shapes -- split-K for a 40-row call, Winograd for 320 rows)."""
+    H, Hp = _hyps(full_extra), _hyps(part_extra, im_map)
+    assert len(Hp) > 0
+    for k, (pose, lg) in Hp.items():
+        assert (pose - H[k][0]).abs().max().item() < 5e-5, k
+        assert abs(lg - H[k][1]) < 1e-4 * max(1.0, abs(lg)), (k, lg, H[k][1])
+    F = _by_key(full_final)
+    for (im, lab, inst), pose in _by_key(part_final).items():
+        key = (im_map(im), lab, inst)
+        if (pose - F[key]).abs().max().item() < 5e-5:
+            continue
+        lgs = sorted((v[1] for kk, v in H.items() if kk[:3] == key), reverse=True)
+        assert len(lgs) >= 2 and lgs[0] - lgs[1] < 2e-4 * max(1.0, abs(lgs[0])), (key, lgs[:3])
+
+
 def test_config3_rgbd_8_objects_x_576_hypotheses_row_independence():
     """megapose-1.0-RGBD structure (RGB coarse + 32-channel RGBD refiner), 8 objects x 576 hypotheses ALL refined 5 iterations"""
     from tests.support.scene import make_scene
@@ -28,17 +55,16 @@ def test_config3_rgbd_8_objects_x_576_hypotheses_row_independence():
     full = _by_key(final)
     # (1) one detection alone == the same detection inside the 8-object launch
     one = PandasTensorCollection(det.infos.iloc[[5]].reset_index(drop=True), bboxes=det.bboxes[[5]])
-    f1, _ = est.run_inference_pipeline(obs, detections=one, n_refiner_iterations=5, n_pose_hypotheses=576)
+    f1, e1 = est.run_inference_pipeline(obs, detections=one, n_refiner_iterations=5, n_pose_hypotheses=576)
     k = (0, str(det.infos.iloc[5]["label"]), int(det.infos.iloc[5]["instance_id"]))   # make_detections numbers instances 0..7
     assert k in full, list(full)
     # (rows at the end of a launch may take the split-K tail path of the conv: another summation order, hence not bit-equal)
-    assert (f1.poses[0] - full[k]).abs().max().item() < 5e-5
+    _assert_same_result(extra, final, e1, f1)
     # (2) reversed detection order -> same per-object poses
     rev = list(range(7, -1, -1))
     detr = PandasTensorCollection(det.infos.iloc[rev].reset_index(drop=True), bboxes=det.bboxes[rev])
-    fr, _ = est.run_inference_pipeline(obs, detections=detr, n_refiner_iterations=5, n_pose_hypotheses=576)
-    for key, pose in _by_key(fr).items():
-        assert (pose - full[key]).abs().max().item() < 5e-5
+    fr, er = est.run_inference_pipeline(obs, detections=detr, n_refiner_iterations=5, n_pose_hypotheses=576)
+    _assert_same_result(extra, final, er, fr)
     # (3) per-hypothesis scores: the arg-max really is the best-scoring refined hypothesis of each object
     sc = extra["scoring"]["preds"].infos
     best = sc.loc[sc.groupby("label")["pose_logit"].idxmax()].set_index("label")["pose_logit"]
@@ -80,15 +106,13 @@ def test_config4_64_detections_over_8_frames_multi_hypothesis():
     sel = np.nonzero(det.infos["batch_im_id"].values == 6)[0].tolist()
     sub = PandasTensorCollection(det.infos.iloc[sel].assign(batch_im_id=0).reset_index(drop=True), bboxes=det.bboxes[sel])
     obs6 = ObservationTensor(obs.images[[6]].contiguous(), obs.K[[6]].contiguous())
-    f6, _ = est.run_inference_pipeline(obs6, detections=sub, n_refiner_iterations=5, n_pose_hypotheses=5)
-    for (im, lab, inst), pose in _by_key(f6).items():   # 40 refiner rows alone take the split-K conv path (other summation order)
-        assert (pose - full[(6, lab, inst)]).abs().max().item() < 5e-5
+    f6, e6 = est.run_inference_pipeline(obs6, detections=sub, n_refiner_iterations=5, n_pose_hypotheses=5)
+    _assert_same_result(extra, final, e6, f6, im_map=lambda im: 6)   # 40 refiner rows alone take the split-K conv path (other summation order)
     # chunking: 36 864 coarse rows in launches of 1000 (ragged tail) == launches of 576
     old = est.max_rows_per_launch
     try:
         est.max_rows_per_launch = 1000
-        f2, _ = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=5)
+        f2, e2 = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=5)
     finally:
         est.max_rows_per_launch = old
-    for key, pose in _by_key(f2).items():
-        assert (pose - full[key]).abs().max().item() < 5e-5
+    _assert_same_result(extra, final, e2, f2)
