@@ -254,6 +254,9 @@ int mp_conv_wino_bf16_stats(double* direct_flops, double* executed_bf16_flops, i
 /* effective shader clock (MHz) inside the K loops of the bf16 Winograd launches since the last reset and their shader cycles per
  * 16-channel step (every 64th workgroup samples s_memtime / s_memrealtime); synchronises the device; 0.0 if none ran */
 int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int reset);
+/* shader cycles a sampled workgroup of those launches spent before its K loop (requests, first transform) and after it (output transform,
+ * exchange, stores), averaged since the last mp_conv_wino_bf16_clock reset; call BEFORE the resetting clock read */
+int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogue_cycles);
 
 /* Stem convolution on the bf16 MFMA through EXACT operand pieces (csrc/conv_stem.hip; same call site as mp_conv2d_nhwc for the first
  * layer: models/torchvision_resnet.py:213-216, models/wide_resnet.py:65-67).  The render channels of the CNN input are 8-bit integers

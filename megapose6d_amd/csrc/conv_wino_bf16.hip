@@ -40,7 +40,7 @@ constexpr int UB_STEP_BYTES = 16 * UB_F_BYTES;    // 96 KB per 16-channel step
 
 // Clock telemetry (as conv.hip's): every 64th workgroup adds the shader cycles (s_memtime), the 100 MHz real-time ticks (s_memrealtime)
 // and the number of steps of its K loop: mp_conv_wino_bf16_clock reports the effective shader clock and the cycles per 16-channel step.
-__device__ unsigned long long g_wb_clk[3];
+__device__ unsigned long long g_wb_clk[6];   // K-loop cycles, K-loop 100 MHz ticks, steps | prologue cycles, epilogue cycles, sampled workgroups
 
 // DIAG (timing experiments only, wrong results; MP_WINO_DIAG): 1 = no split work, 2 = no patch requests / transform, 4 = no weight requests
 template <int DIAG>
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float* Vs = smem;
   int* tile_tab = (int*)(smem + 4 * 2 * WT * WCOUT);   // [64][2]: output element offset of pixel (2ty, 2tx) (-1: no such tile), validity bits
 
+  const unsigned long long clk_start = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //      (its transform rides in points 0 and 1) and first read in point 2.
   const bool clk_sample = (blockIdx.x & 63) == 0 && tid == 0;
   unsigned long long clk_c0 = 0, clk_r0 = 0;
-  if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+  if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_wb_clk[3], clk_c0 - clk_start); }
   for (int st = 0; st < ns; ++st) {
     const int buf = st & 1;
     const float* vb = vr + buf * WV_STAGE;          // V of this step
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     atomicAdd(&g_wb_clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
     atomicAdd(&g_wb_clk[2], (unsigned long long)ns);
   }
+  const unsigned long long clk_epi = __builtin_readcyclecounter();
   __syncthreads();   // (the epilogue reuses the V stages)
 #undef WB_TAIL_PL
 #undef WB_TAIL_TR
@@ -408,6 +410,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
   }
+  if (clk_sample) {
+    __builtin_amdgcn_s_waitcnt(0);   // the stores are out
+    atomicAdd(&g_wb_clk[4], __builtin_readcyclecounter() - clk_epi);
+    atomicAdd(&g_wb_clk[5], 1ull);
+  }
 }
 
 }  // namespace mp
@@ -466,14 +473,23 @@ extern "C" int mp_conv_wino_bf16_stats(double* direct_flops, double* executed_bf
   return MP_OK;
 }
 
+extern "C" int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogue_cycles) {   // per workgroup, since the last clock reset
+  unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wb_clk), sizeof(h)));
+  if (prologue_cycles) *prologue_cycles = h[5] ? (double)h[3] / (double)h[5] : 0.0;
+  if (epilogue_cycles) *epilogue_cycles = h[5] ? (double)h[4] / (double)h[5] : 0.0;
+  return MP_OK;
+}
+
 extern "C" int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int reset) {
-  unsigned long long h[3] = {0, 0, 0};
+  unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
   MP_CHECK_HIP(hipDeviceSynchronize());
   MP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wb_clk), sizeof(h)));
   if (shader_mhz) *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
   if (cycles_per_step) *cycles_per_step = h[2] ? (double)h[0] / (double)h[2] : 0.0;
   if (reset) {
-    const unsigned long long z[3] = {0, 0, 0};
+    const unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
     MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wb_clk), z, sizeof(z)));
   }
   return MP_OK;

@@ -195,9 +195,11 @@ static int run_case(const Case& s, int* n_bad) {
            ms_d / reps, flops * reps / (ms_d * 1e-3) / 1e12, ms_w / reps, exec * reps / (ms_w * 1e-3) / 1e12, flops * reps / (ms_w * 1e-3) / 1e12,
            ms_d / ms_w);
     {
-      double mhz = 0, cps = 0;
+      double mhz = 0, cps = 0, pro = 0, epi = 0;
+      MP_OKAY(mp_conv_wino_bf16_phases(&pro, &epi));
       MP_OKAY(mp_conv_wino_bf16_clock(&mhz, &cps, 1));
-      printf("CLK  %-34s | bf16x9 K loop: %6.0f MHz, %7.0f cycles per 16-channel step = %5.1f per MFMA\n", s.name, mhz, cps, cps / 144.0);
+      printf("CLK  %-34s | bf16x9 K loop: %6.0f MHz, %7.0f cycles per 16-channel step = %5.1f per MFMA; per workgroup: prologue %6.0f, K loop %7.0f, epilogue %6.0f cycles\n",
+             s.name, mhz, cps, cps / 144.0, pro, cps * (s.C / 16), epi);
     }
     printf("TIME %-34s | bf16x9 winograd %7.3f ms: executed bf16 %7.1f TFLOP/s (%.2f of 2500), direct-equivalent %6.1f TFLOP/s | x%.2f vs direct, x%.2f vs fp32 winograd\n",
            s.name, ms_b / reps, 9.0 * exec * reps / (ms_b * 1e-3) / 1e12, 9.0 * exec * reps / (ms_b * 1e-3) / 1e12 / 2500.0,
