@@ -168,14 +168,16 @@ int run_conv(const mp_backbone* bb, const ConvLayer& L, const float* x, int N, i
   d.d_splitk_ws = splitk_ws;
   d.splitk_ws_floats = splitk_ws ? (int64_t)SPLITK_WS_FLOATS : 0;
   if ((L.d_u || L.d_ub) && !x_f16) {
-    static int n_cu = 0, n_cu_dev = -1;
+    static int n_cu = 0, n_cu_dev = -1, lds_ok = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (n_cu_dev != dev) {
       if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+      int lds = 0;   // the Winograd kernels take 128.5 KB of LDS per workgroup (gfx950: 160 KB per CU); a part with less keeps the direct kernel
+      lds_ok = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && lds >= 132 * 1024;
       n_cu_dev = dev;
     }
-    if (mp_conv_wino_eligible(&d, n_cu))   // (the workspace buffers carry the read slack the Winograd kernels need)
+    if (lds_ok && mp_conv_wino_eligible(&d, n_cu))   // (the workspace buffers carry the read slack the Winograd kernels need)
       return L.d_ub ? mp_conv3x3_wino_bf16_nhwc(&d, L.d_ub, s) : mp_conv3x3_wino_nhwc(&d, L.d_u, s);
   }
   return mp_conv2d_nhwc(&d, s);
