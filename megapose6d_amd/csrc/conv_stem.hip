@@ -58,7 +58,7 @@ struct Params {
   int n_steps;           // even
   int relu;
   unsigned img_bytes;    // Hp * Wp * 16Q
-  unsigned out_bytes;
+  unsigned out_bytes;    // of ONE image of y: Hop * Wop * Cout * 4
   // fused 3x3 / stride-2 / pad-1 max pool (POOL instances): pooled output, padded NHWC with border pool_border
   float* __restrict__ ypool;
   int Hq, Wq, pool_border;
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   if (!POOL || p.y != nullptr) {
-    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.out_bytes, 0x00020000);
+    // (one resource per image: the batch may exceed 4 GB -- coarse launches of 1000 rows do)
+    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)n * (p.out_bytes / 4)), 0, p.out_bytes, 0x00020000);
     const int oy0 = ty * TH, ox0 = tx * TW;
 #pragma unroll
     for (int k = 0; k < (TH * TW * NCO / 4) / 256; ++k) {
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int pix = c >> 4, part = c & 15;
       const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + c * 16);
-      const long off = (((long)n * p.Hop + oy + p.out_border) * p.Wop + ox + p.out_border) * p.Cout + cb * NCO + part * 4;
-      const unsigned voff = (oy < p.Ho && ox < p.Wo) ? (unsigned)(off * 4) : 0xFFFFFFF0u;   // outside the image: dropped by the range check
+      const int off = ((oy + p.out_border) * p.Wop + ox + p.out_border) * p.Cout + cb * NCO + part * 4;
+      const unsigned voff = (oy < p.Ho && ox < p.Wo) ? (unsigned)off * 4u : 0xFFFFFFF0u;   // outside the image: dropped by the range check
       __builtin_amdgcn_raw_buffer_store_b128(v, r_y, (int)voff, 0, 0);
     }
   }
@@ -374,8 +375,8 @@ static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32
   p.tiles_x = ceil_div(p.Wo, stem::TW); p.tiles_y = ceil_div(p.Ho, stem::TH); p.n_cb = d->Cout / stem::NCO;
   p.n_steps = stem::n_steps(d->KH, Q);
   p.relu = d->relu;
-  const long img = (long)p.Hp * p.Wp * 16 * Q, outb = (long)d->N * p.Hop * p.Wop * d->Cout * 4;
-  MP_REQUIRE(img < (1L << 31) && outb < 0xFFFFFF00L && (long)d->N * p.tiles_y * p.tiles_x * p.n_cb < (1L << 31), "mp_conv_stem_xrec: tensor too large for 32-bit offsets");
+  const long img = (long)p.Hp * p.Wp * 16 * Q, outb = (long)p.Hop * p.Wop * d->Cout * 4;   // per image: the batch index is applied in 64 bits
+  MP_REQUIRE(img < (1L << 31) && outb < (1L << 31) && (long)d->N * p.tiles_y * p.tiles_x * p.n_cb < (1L << 31), "mp_conv_stem_xrec: image too large for 32-bit offsets");
   p.img_bytes = (unsigned)img; p.out_bytes = (unsigned)outb;
   p.ypool = d_ypool; p.pool_border = pool_border;
   p.Hq = (p.Ho + 2 - 3) / 2 + 1; p.Wq = (p.Wo + 2 - 3) / 2 + 1;

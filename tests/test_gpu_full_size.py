@@ -6,6 +6,8 @@ import pandas as pd
 import pytest
 import torch
 
+from oracle.harness import logit_flip_rule
+
 pytestmark = pytest.mark.gpu
 
 
@@ -23,15 +25,20 @@ def _hyps(extra, im_map=lambda im: im):
 
 
 def _assert_same_result(full_extra, full_final, part_extra, part_final, im_map=lambda im: im):
-    """Row independence, stated on what is row-wise: every refined hypothesis of `part` has the pose (5e-5) and the score logit (1e-4) it has
-    in `full`.  The FINAL pose is an arg-max over a detection's hypotheses: it must agree too, unless the detection's two best logits tie
+    """Row independence, stated on what is row-wise: every refined hypothesis of `part` has the pose (5e-5) and the score logit (1e-4, `logit_flip_rule`) it
+    has in `full`.  The FINAL pose is an arg-max over a detection's hypotheses: it must agree too, unless the detection's two best logits tie
     within the comparison tolerance (the lathe test meshes are nearly symmetric: two hypotheses half a turn apart can score within 1e-5,
     and which one wins then depends on the summation order of the launch shapes -- split-K for a 40-row call, Winograd for 320 rows)."""
     H, Hp = _hyps(full_extra), _hyps(part_extra, im_map)
     assert len(Hp) > 0
+    rel = []
     for k, (pose, lg) in Hp.items():
         assert (pose - H[k][0]).abs().max().item() < 5e-5, k
-        assert abs(lg - H[k][1]) < 1e-4 * max(1.0, abs(lg)), (k, lg, H[k][1])
+        rel.append(abs(lg - H[k][1]) / max(1.0, abs(lg)))
+    # (the refined poses of two launch shapes agree to 5e-5, not bit for bit: the re-render behind a score logit may flip a silhouette
+    # sample -- the same counted rule as every parity check: 1e-4, at most one row per 64 up to 2e-4)
+    r = logit_flip_rule(rel, 1.0)
+    assert r["ok"], r
     F = _by_key(full_final)
     for (im, lab, inst), pose in _by_key(part_final).items():
         key = (im_map(im), lab, inst)

@@ -125,6 +125,38 @@ def test_fused_max_pool_equals_the_separate_pool_kernel_bit_for_bit(eng, case):
     assert (eng.padded_view(ref, N, Hq, Wq, Cout, 1).permute(0, 3, 1, 2).cpu() - tref).abs().max().item() < 1e-5 * max(1.0, tref.abs().max().item())
 
 
+def test_stem_map_of_a_batch_beyond_4_gb_is_addressed_per_image(eng):
+    """A coarse launch of `max_rows_per_launch` = 1000 rows (tests/test_gpu_full_size.py chunking case) has a 5 GB stem map: the kernel's
+    32-bit buffer offsets are per image, the batch index is applied in 64 bits.  860 x 240 x 320 coarse records (4.3 GB map): the last
+    and the first image equal the same images convolved alone, with and without the fused pool."""
+    N, nf, nu, H, W, K, Cout = 860, 3, 6, 240, 320, 7, 64
+    g = torch.Generator().manual_seed(5)
+    x2 = torch.cat([torch.rand(2, nf, H, W, generator=g), torch.randint(0, 256, (2, nu, H, W), generator=g).float() / 255.0], dim=1)
+    w = torch.randn(Cout, nf + nu, K, K, generator=g) * (2.0 / ((nf + nu) * K * K)) ** 0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, (torch.randn(Cout, generator=g) * 0.1).cuda()
+    pad = K // 2
+    Ho, Wo = H // 2, W // 2
+    Hq, Wq = Ho // 2, Wo // 2
+    R = eng.xrec_elements(nf, nu)
+    rec2 = to_records(eng, x2, nf, pad)
+    wp = torch.from_numpy(eng.conv_stem_pack_weights(w.numpy(), nf, scale.numpy())).cuda()
+    y2, q2 = eng.padded_nhwc(2, Ho, Wo, Cout, 1, "cuda"), eng.padded_nhwc(2, Hq, Wq, Cout, 1, "cuda")
+    eng.conv_stem_xrec(rec2, 2, H, W, nf + nu, nf, pad, wp, bias, Cout, K, pad, y2, 1, relu=True, y_pool=q2, pool_border=1)
+    rec = eng.padded_nhwc(N, H, W, R, pad, "cuda", dtype=torch.bfloat16)
+    per = (H + 2 * pad) * (W + 2 * pad) * R
+    rec[: N * per].view(N, per)[:] = rec2[:per]          # image 0 everywhere ...
+    rec[(N - 1) * per : N * per] = rec2[per : 2 * per]    # ... image 1 in the last slot
+    y, q = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda"), eng.padded_nhwc(N, Hq, Wq, Cout, 1, "cuda")
+    assert y.numel() * 4 > 2 ** 32
+    eng.conv_stem_xrec(rec, N, H, W, nf + nu, nf, pad, wp, bias, Cout, K, pad, y, 1, relu=True, y_pool=q, pool_border=1)
+    torch.cuda.synchronize()
+    py, pq = (Ho + 2) * (Wo + 2) * Cout, (Hq + 2) * (Wq + 2) * Cout
+    for n_big, n_small in ((0, 0), (N // 2, 0), (N - 1, 1)):
+        assert torch.equal(y[n_big * py : (n_big + 1) * py], y2[n_small * py : (n_small + 1) * py]), n_big
+        assert torch.equal(q[n_big * pq : (n_big + 1) * pq], q2[n_small * pq : (n_small + 1) * pq]), n_big
+    assert eng.padded_view(y2, 2, Ho, Wo, Cout, 1).abs().max() > 0
+
+
 @pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 27)])
 def test_backbone_forward_on_records_matches_the_fp32_tensor_path(eng, kind, c_in):
     from tests.support import synthetic as syn
