@@ -600,14 +600,25 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     unsigned long long best[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) best[k] = 0ull;
+    bool any_sweep = vh.overflow != 0;   // (wave-uniform) is there a piece left for the sweep form?
     if (!vh.overflow) {
-      for (int base = 0; base < vh.n_list; base += 64) {
-        const int e = base + lane;
+      // batches of <= 64 pieces, one per lane: first the tile's binned records, then the view's "large" list.  A piece of that list
+      // touches too many tiles to be replicated into their lists, but if it still fits the 32-bit edge functions (extent <=
+      // SMALL_EXTENT = 81 pixels: the cap fans of a lathe mesh, long slivers) it takes the same block visits -- re-derived from the mesh
+      // (no record: slot SLOT_NONE), with arithmetic that is bit for bit the one of the sweep form.
+      const int nb_list = (vh.n_list + 63) >> 6, nb_all = nb_list + ((vh.n_large + 63) >> 6);
+      for (int b = 0; b < nb_all; ++b) {
+        const bool from_list = b < nb_list;
+        const int e = ((from_list ? b : b - nb_list) << 6) + lane;
         Piece mine_p;
         mine_p.id = -1;
-        if (e < vh.n_list) {     // two coalesced 16-byte loads, nothing to recompute
-          const rc::TileRec rec = base == 0 ? rec_first : load_tile_rec(list + vh.begin + e);
-          rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
+        if (from_list) {
+          if (e < vh.n_list) {     // two coalesced 16-byte loads, nothing to recompute
+            const rc::TileRec rec = b == 0 ? rec_first : load_tile_rec(list + vh.begin + e);
+            rc::unpack_tile_rec(rec, tile_x0, tile_y0, mine_p);
+          }
+        } else if (e < vh.n_large) {
+          rc::piece_from_index<true>(m, T, Kv, large[vh.begin_l + e], mine_p);
         }
 #ifdef MP_RASTER_PROF
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (probe only: the wait for the records counts as list fetch, not as coverage)
@@ -618,13 +629,16 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
           rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
           x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
         }
-        const bool hit = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
+        const bool touches = mine_p.id >= 0 && x0 <= x1 && y0 <= y1;
+        const bool hit = touches && (from_list || rc::piece_extent(mine_p) <= rc::SMALL_EXTENT);
+        any_sweep = any_sweep || __ballot(touches && !hit) != 0ull;
+        const int slot = from_list ? e : rc::SLOT_NONE;
 #ifdef MP_RASTER_PROF
-        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best, vh.front_swap, &prof_acc[9]);
+        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, slot, rel, ok_mask, blk, best, vh.front_swap, &prof_acc[9]);
         PROF_COUNT(10, __popcll(__ballot(hit)))
         PROF_COUNT(12, 1)
 #else
-        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, e, rel, ok_mask, blk, best, vh.front_swap);
+        if (__ballot(hit) != 0ull) cover_batch_blocks<NS>(mine_p, hit, tile_x0, tile_y0, lane, slot, rel, ok_mask, blk, best, vh.front_swap);
 #endif
         PROF(2)
       }
@@ -633,8 +647,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int k = 0; k < NB; ++k) zb[rc::blk_lane_pixel(NS, k, lane) * NS + rc::blk_lane_sample(NS, lane)] = best[k];
     wave_lds_fence();
-    // ---- coverage + depth, the view's "large" list / the overflow fallback: recomputed from the mesh, wave-per-piece sweep -----
-    const int n_idx = vh.overflow ? vh.n_list : vh.n_large;
+    // ---- coverage + depth, what is left of the "large" list (pieces beyond the 32-bit edge functions) / the overflow fallback:
+    // recomputed from the mesh, wave-per-piece sweep with the 64-bit edge functions -------------------------------------------------
+    const int n_idx = !any_sweep ? 0 : vh.overflow ? vh.n_list : vh.n_large;
     for (int base = 0; base < n_idx; base += 64) {
       const int e = base + lane;
       Piece mine_p;
@@ -645,7 +660,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         rc::piece_pixel_bbox(mine_p, NS, w, h, x0, y0, x1, y1);
         x0 = max(x0, tile_x0); y0 = max(y0, tile_y0); x1 = min(x1, tile_x0 + TILE - 1); y1 = min(y1, tile_y0 + TILE - 1);
       }
-      unsigned long long big = __ballot(mine_p.id >= 0 && x0 <= x1 && y0 <= y1);
+      unsigned long long big = __ballot(mine_p.id >= 0 && x0 <= x1 && y0 <= y1 && (vh.overflow || rc::piece_extent(mine_p) > rc::SMALL_EXTENT));
       while (big) {
         const int j = __ffsll((long long)big) - 1;
         big &= big - 1ull;

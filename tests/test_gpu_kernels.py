@@ -375,6 +375,51 @@ def test_raster_large_triangles_and_close_camera(eng):
         assert (dep[0] > 0).mean() > 0.1 and (dep[3] > 0).mean() > 0.1 and dep[3][dep[3] > 0].min() >= 0.1 - 1e-6
 
 
+def test_raster_mid_size_triangles_take_block_visits_bit_exact(eng):
+    """Fan triangles of 30 .. 120 pixels (the caps of a lathe mesh): they touch more than 16 tiles, so they are not replicated into the
+    tile lists; up to 81 pixels they take the block visits (re-derived from the mesh, no record slot), beyond that the 64-bit sweep.
+    Two discs a little apart with opposite orientation + a tessellated strip in front: depth interplay between pieces with and
+    without a record, both occlusion-bound phases.  Bit-exact vs the oracle, with and without multisampling."""
+    from oracle import raster as orr
+
+    n = 24
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], 1) * 0.05
+    v = [np.zeros((1, 3)), ring, np.array([[0.004, -0.003, 0.012]]), ring * 0.9 + np.array([0, 0, 0.012])]
+    f = [[0, 1 + i, 1 + (i + 1) % n] for i in range(n)] + [[n + 1, n + 2 + (i + 1) % n, n + 2 + i] for i in range(n)]   # second disc: flipped
+    base = 2 * n + 2
+    gx, gy = np.meshgrid(np.linspace(-0.03, 0.03, 13), np.linspace(-0.008, 0.008, 4))
+    strip = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -0.01)], 1)
+    v.append(strip)
+    for r in range(3):
+        for c in range(12):
+            a = base + r * 13 + c
+            f += [[a, a + 1, a + 14], [a, a + 14, a + 13]]
+    v = np.concatenate(v).astype(np.float32)
+    f = np.asarray(f, np.int32)
+    rs = np.random.RandomState(3)
+    nrm = rs.randn(*v.shape).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    mesh = {"vertices": v, "normals": nrm, "colors": rs.rand(len(v), 3).astype(np.float32), "faces": f}
+    db = eng.MeshDB([mesh])
+    zs = [0.5, 0.3, 0.2, 0.15, 0.25, 0.3]
+    T = np.tile(np.eye(4, dtype=np.float32), (len(zs), 1, 1))
+    T[:, 2, 3] = zs
+    T[:, 0, 3] = [0.0, 0.01, -0.02, 0.0, 0.03, -0.05]
+    c, s_ = np.cos(0.7), np.sin(0.7)
+    T[4, :3, :3] = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], np.float32)
+    T[5, :3, :3] = np.array([[1, 0, 0], [0, -c, s_], [0, -s_, -c]], np.float32)      # seen from behind, tilted
+    K = np.tile(np.array([[300, 0, 160], [0, 300, 120], [0, 0, 1]], np.float32), (len(zs), 1, 1))
+    for flags in (3, 16 | 3):
+        out = torch.zeros(len(zs), 240, 320, 8, device="cuda")
+        eng.raster_render(db, torch.zeros(len(zs), dtype=torch.int32, device="cuda"), torch.from_numpy(T).cuda(), torch.from_numpy(K).cuda(),
+                          240, 320, flags, eng.make_lights(), out, 240 * 320 * 8, 320 * 8, 8, 0, 3, 6)
+        got = out.cpu().numpy()
+        rgb, nr, dep = orr.render(mesh, T, K, 240, 320, flags)
+        assert np.array_equal(got[..., 6], dep) and np.array_equal(got[..., 0:3], rgb) and np.array_equal(got[..., 3:6], nr)
+        assert all((dep[i] > 0).mean() > 0.01 for i in range(len(zs)))
+
+
 @pytest.mark.parametrize("C", [3, 4])
 def test_crop_roi_align_vs_oracle(eng, C):
     from oracle import thirdparty as tp
