@@ -125,12 +125,12 @@ def backbone_vectors(r) -> dict:
 def make_scene(tmp, n_objects=1, seed=0):
     """Synthetic scene shared by the golden generator and the tests (tests/scene_util.py re-implements nothing: it calls this
     through the saved npz inputs)."""
-    from megapose6d_amd import mesh_io
     from tests.support import synthetic as syn
+    from oracle import mesh_loader
     from oracle import raster as orr
 
     ds = syn.make_object_dataset(tmp, n_objects=n_objects, seed=seed)
-    meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}
+    meshes = {o.label: mesh_loader.load_object(o) for o in ds.list_objects}   # (the oracle's own reader, not the product's)
     rng = np.random.RandomState(seed + 100)
     K = syn.K_EXAMPLE.astype(np.float32)
     img = rng.uniform(0, 1, size=(480, 640, 3)).astype(np.float32) * 0.3
@@ -168,9 +168,13 @@ def pipeline_vectors(r) -> dict:
         import megapose.models.pose_rigid as pr
 
         pr.Panda3dBatchRenderer = orr.OracleBatchRenderer  # the isinstance assert in render_images_multiview (:378)
-        from megapose6d_amd.load_model import Config
+        from types import SimpleNamespace
 
-        cfg = Config.from_any(cfg)  # supports `"x" in cfg` like OmegaConf
+        class _Cfg(SimpleNamespace):   # attribute access + `"x" in cfg`, like the OmegaConf node the reference passes around
+            def __contains__(self, key):
+                return hasattr(self, key)
+
+        cfg = _Cfg(**cfg) if isinstance(cfg, dict) else _Cfg(**{k: getattr(cfg, k) for k in vars(cfg)})
         model = r.pmc.create_model_pose(r.pmc.check_update_config(cfg), renderer=renderer, mesh_db=mesh_db)
         model.load_state_dict(sd, strict=True)
         model.eval()
