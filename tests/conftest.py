@@ -27,6 +27,15 @@ def engine_meshes(object_dataset):
     return [mesh_io.load_rigid_object(o) for o in object_dataset.list_objects]
 
 
+@pytest.fixture(scope="session")
+def oracle_meshes(object_dataset):
+    """the same objects through the ORACLE's own reader (oracle/mesh_loader.py): what the independent C rasteriser / the oracle pose math
+    are fed in the parity tests, so that a defect of the product loader cannot cancel out on both sides"""
+    from oracle import mesh_loader
+
+    return [mesh_loader.load_object(o) for o in object_dataset.list_objects]
+
+
 def assert_logits_close(got, ref, scale):
     """Classifier logits of the HIP path vs the oracle / the reference goldens: `oracle.harness.logit_flip_rule` -- every logit within
     1e-4 x scale (scale = max(1, |logit|): the seeded networks' features are O(1), there is no feature-scale factor) EXCEPT at most one

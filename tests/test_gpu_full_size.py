@@ -40,12 +40,22 @@ def _assert_same_result(full_extra, full_final, part_extra, part_final, im_map=l
     r = logit_flip_rule(rel, 1.0)
     assert r["ok"], r
     F = _by_key(full_final)
+    ties = 0
     for (im, lab, inst), pose in _by_key(part_final).items():
         key = (im_map(im), lab, inst)
         if (pose - F[key]).abs().max().item() < 5e-5:
             continue
-        lgs = sorted((v[1] for kk, v in H.items() if kk[:3] == key), reverse=True)
-        assert len(lgs) >= 2 and lgs[0] - lgs[1] < 2e-4 * max(1.0, abs(lgs[0])), (key, lgs[:3])
+        # a different winner: it must BE one of the hypotheses that tie with the full run's best logit, with the pose that very
+        # hypothesis has in the full run (a tie excuses the choice between them, nothing else)
+        cand = sorted(((v[1], kk[3], v[0]) for kk, v in H.items() if kk[:3] == key), key=lambda t: -t[0])
+        assert len(cand) >= 2, key
+        tied = [c for c in cand if cand[0][0] - c[0] < 2e-4 * max(1.0, abs(cand[0][0]))]
+        assert len(tied) >= 2, (key, [c[0] for c in cand[:3]])
+        assert any((pose - c[2]).abs().max().item() < 5e-5 for c in tied), (key, [c[:2] for c in tied])
+        ties += 1
+    if ties:
+        print(f"[row independence] {ties} detection(s) resolved a logit tie differently between the two launch shapes")
+    assert ties <= max(1, len(F) // 8), ties
 
 
 def test_config3_rgbd_8_objects_x_576_hypotheses_row_independence():

@@ -130,16 +130,14 @@ def pipeline_gold():
 
 
 def build_oracle_estimator(tmp, backbone="vanilla_resnet34", grid=72):
-    from megapose6d_amd import mesh_io
     from tests.support import synthetic as syn
-    from megapose6d_amd.mesh_db import MeshDataBase
-    from megapose6d_amd.pose_estimator import load_SO3_grid
+    from oracle import mesh_loader
     from oracle import pipeline as op
     from oracle import raster as orr
 
     ds = syn.make_object_dataset(tmp, n_objects=1, seed=0)
-    meshes = {o.label: mesh_io.load_rigid_object(o) for o in ds.list_objects}
-    db = MeshDataBase.from_object_ds(ds).batched()
+    meshes, db = mesh_loader.load_dataset(ds)          # the oracle's own reader, not the product's (megapose6d_amd.mesh_io)
+    load_SO3_grid = lambda n: mesh_loader.load_so3_grid(Path(__file__).resolve().parent.parent / "megapose6d_amd" / "data" / f"so3_grid_{n}_xyzw.npy")
     renderer = orr.OracleBatchRenderer(meshes)
     preds = {}
     for role, seed in (("coarse", 11), ("refiner", 12)):
