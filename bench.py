@@ -12,7 +12,8 @@ N > 1: `python bench.py --gpus N` re-launches itself through `python -m torch.di
 hypotheses per GPU; rows are sharded rank::world and the packed logits/poses are all-gathered once per stage.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     the dominant kernel (fp32-MFMA implicit-GEMM conv) measured live with HIP events on its launch stream
+  "roofline":     the dominant kernel (conv3x3_wino_bf16x9: the fused Winograd 3x3 convolution on the bf16 MFMA through exact operand
+                  pieces, csrc/conv_wino_bf16.hip) measured live with HIP events on its launch stream: executed bf16 rate / 2.5 PFLOP/s
   "cpu_baseline": the oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample
   "parity":       the rows the cpu_baseline leg computed, compared with the same rows of the timed GPU call (N = 1).
 """

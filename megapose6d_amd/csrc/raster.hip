@@ -984,7 +984,6 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
   const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
   MP_REQUIRE(n_wg < (1LL << 31), "mp_raster_render: grid too large");
-  const size_t lds = (size_t)TILE_WAVES * (tiles_zt_bytes(ns) + (((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15) + HDR_LDS_BYTES);
   const int n_ch = (c_rgb >= 0 ? 3 : 0) + (do_norm ? 3 : 0) + (do_depth ? 1 : 0);
   // algorithmic bytes: output channels written once + the mesh (32 B/vertex, 12 B/triangle) read once per view
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
@@ -993,10 +992,14 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
     MP_REQUIRE(!f16 && !do_depth && crop.images && crop.c0 == 0 && c_lo == 0 && mask == (run >= 32 ? 0xFFFFFFFFu : (1u << run) - 1u),
                "mp_raster_render: MP_RASTER_XREC needs the fused crop at channel 0, no depth channel, and every channel of the record written "
                "by this launch");
-    MP_REQUIRE(stride_x == mp_xrec_elements(crop.C, run - crop.C) && stride_x <= 2 * run && stride_x <= 40,
+    MP_REQUIRE(stride_x == mp_xrec_elements(crop.C, run - crop.C) && stride_x <= 40,
                "mp_raster_render: MP_RASTER_XREC: stride_x (%lld) must be the record length mp_xrec_elements(%d, %d)", (long long)stride_x, crop.C,
                run - crop.C);
   }
+  // LDS staging per pixel, in floats: the channel run -- or, for stem records, the record itself if that is longer (a 6-channel model, 3 crop
+  // + 3 render channels, has a 16-element = 32-byte record but a run of only 6 floats: the record's zero padding is part of what is staged)
+  const int run_lds = xrec ? std::max(run, ((int)stride_x + 1) / 2) : run;
+  const size_t lds = (size_t)TILE_WAVES * (tiles_zt_bytes(ns) + (((size_t)64 * run_lds * sizeof(float) + 15) & ~(size_t)15) + HDR_LDS_BYTES);
   const double out_es = f16 ? 2.0 : 4.0;   // bytes per output element
   ProfScope prof(f16 ? "raster_tiles/f16" : xrec ? "raster_tiles/xrec" : "raster_tiles", 0.0,
                  xrec ? (double)n_views * (32.0 * db->max_verts + 12.0 * db->max_faces) + (double)n_items * (2.0 * stride_x + 4.0 * crop.C) * h * w :
@@ -1007,7 +1010,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
 #define MP_LAUNCH_TILES(NSV, OUTV, FULLV)                                                                                              \
   hipLaunchKernelGGL((raster_tiles<NSV, OUTV, FULLV>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,    \
                      d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,  \
-                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run, mask, crop)
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop)
   const int sel = (ns == 4 ? 8 : 0) | (xrec ? 4 : f16 ? 2 : 0) | (full ? 1 : 0);
   switch (sel) {
     case 0: MP_LAUNCH_TILES(1, OUT_F32, false); break;

@@ -190,8 +190,14 @@ def test_rasteriser_record_output_holds_exactly_the_fp32_values(object_dataset):
     from megapose6d_amd.renderer import Panda3dBatchRenderer
     from tests.support import synthetic as syn
 
-    for role in ("refiner", "coarse"):
-        cfg = syn.make_cfg(role)
+    for role in ("refiner", "coarse", "coarse_no_normals"):
+        cfg = syn.make_cfg(role.split("_")[0])
+        if role == "coarse_no_normals":
+            # the 6-channel input of the legacy / *-no_normals configs (utils/load_model.py check_update_config_pose defaults: one view,
+            # render_normals False): 3 crop + 3 lit render channels = a 16-element record for a 6-float channel run
+            cfg.render_normals = False
+            assert syn.n_inputs_for(cfg) == 6
+        role = role.split("_")[0]
         head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
         sd = syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), head, n_out, seed=5)
         renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)

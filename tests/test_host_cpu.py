@@ -30,6 +30,30 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_integration_md_lists_exactly_the_exported_entry_points():
+    """INTEGRATION.md's entry-point table is generated from include/mp_engine.h (scripts/gen_entry_points.py): it must be current, name
+    every symbol the library exports and none that it does not (round 4's list had drifted: deleted entry points still listed, new ones
+    missing)."""
+    from megapose6d_amd import _lib
+
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import gen_entry_points as gep
+
+    text = (ROOT / "INTEGRATION.md").read_text()
+    block = gep.current_block(text)
+    assert block is not None, "entry-point markers missing from INTEGRATION.md"
+    assert block == gep.render_block(gep.parse_header()), "stale: run python scripts/gen_entry_points.py"
+    listed = set(re.findall(r"^\| `(mp_[A-Za-z0-9_]+)` \|", block, flags=re.M))
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mp_[A-Za-z0-9_]+)", out))
+    assert listed == exported, (sorted(listed - exported), sorted(exported - listed))
+    # and the prose around the table may only name entry points that exist (wildcards like mp_mesh_db_* aside)
+    prose = text.replace(block, "")
+    named = set(re.findall(r"`(mp_[A-Za-z0-9_]+)(?:\(|`)", prose)) - {"mp_stream", "mp_lights", "mp_conv_desc", "mp_mesh_desc", "mp_mesh_db", "mp_backbone", "mp_detector_config", "mp_detector"}
+    unknown = {n for n in named if n not in exported and not any(e.startswith(n) for e in exported)}
+    assert not unknown, sorted(unknown)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from megapose6d_amd import _lib
 
