@@ -305,10 +305,76 @@ def extras(est, obs, det, steps: int) -> dict:
     guarded("released_recipe_64_detections_K5", lambda: other_workload(
         4, "vanilla_resnet34", 5, "BASELINE configs[3] on one GPU with the RELEASED inference parameters (n_pose_hypotheses = 5, utils/load_model.py:31-34): "
         "64 detections over 8 frames, 36 864 coarse rows + 320 x 5 refiner rows + 320 score rows per call"))
+    # the 8-GPU claim, checkable on one GPU (north_star: ">= 6x at 8 GPUs"): one rank's share of BASELINE configs[3] (64 detections,
+    # released K = 5: strong scaling) and of the weak-scaled `value` workload
+    guarded("emulated_rank_of_8_config4_K5", lambda: emulate_rank_share(4, 8, "vanilla_resnet34", 5, 2))
+    guarded("emulated_rank_of_8_config2_weak", lambda: emulate_rank_share(2, 8, "vanilla_resnet34", N_HYP, 1))
     guarded("wide_resnet34_backbone", lambda: other_workload(
         2, "resnet34", N_HYP, "the `value` workload on the OTHER backbone the reference can ship (backbone_str 'resnet34' = WideResNet-34, "
         "training/pose_models_cfg.py:110-111; the released config.yaml is not available offline to tell which one it is)"))
     return out
+
+
+def emulate_rank_share(cfg_id: int, world: int, backbone: str, k_hyp: int, steps: int = 2, rank: int = 0) -> dict:
+    """`--emulate-rank-of N` (never `value`): what ONE rank of an N-GPU run does, measured on this one GPU.
+
+    The N-GPU workload of configuration `cfg_id` is built exactly as `bench.py --gpus N` builds it (config 2: weak-scaled, N objects;
+    configs 4 / 5: the fixed 64 detections = strong scaling), and run twice on this GPU: (a) whole, undistributed -- the time ONE GPU
+    needs for all of it; (b) as rank `rank` of N through megapose6d_amd.distributed.emulate (rows rank::N of every stage table, the three
+    all-gathers replaced by local copies).  T(a) / T(b) projects the speed-up of N GPUs over one on that workload, minus the RCCL time
+    (3 latency-bound all-gathers per call) and inter-rank skew.  The per-stage split (HIP events, one extra fenced call each) says which
+    stage keeps a rank busy -- SURVEY.md 8e expects the refiner's small per-rank batch at K = 5 (320 rows / 8 = 40) to be the limiter."""
+    import shutil
+
+    from megapose6d_amd import distributed as mpd_
+    from megapose6d_amd import engine as eng_
+
+    tmp2 = tempfile.mkdtemp(prefix="mp_bench_emul_")
+    try:
+        est2, obs2, det2, _, desc2, n_obj2, run2 = build_workload(cfg_id, world, backbone, tmp2, k_hyp)
+        est2.distributed = True   # (build_workload sets it for world > 1; without a process group it is inert until emulate() is on)
+
+        def timed():
+            est2.run_inference_pipeline(obs2, detections=det2, **run2)
+            torch.cuda.synchronize()
+            eng_.profile_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                est2.run_inference_pipeline(obs2, detections=det2, **run2)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            prof_ = eng_.profile_end()
+            _, ex = est2.run_inference_pipeline(obs2, detections=det2, cuda_timer=True, **run2)
+            stages = {s_: ex[s_]["data"]["time"] * 1e3 for s_ in ("coarse", "refiner", "scoring")}
+            top = {k: round(v["ms"] / steps, 3) for k, v in sorted(prof_.items(), key=lambda kv: -kv[1]["ms"])[:6]}
+            return dt * 1e3, stages, top
+
+        mpd_.emulate(None)
+        full_ms, full_st, full_top = timed()
+        mpd_.emulate(rank, world)
+        mpd_.stats.reset()
+        try:
+            share_ms, share_st, share_top = timed()
+            gathers = mpd_.stats.calls / (steps + 2)
+        finally:
+            mpd_.emulate(None)
+        rows_per_obj = N_HYP + k_hyp * N_ITERS + k_hyp
+        line = {"workload": desc2, "emulated": f"rank {rank} of {world}", "objects": n_obj2,
+                "one_gpu_whole_workload_ms": full_ms, "one_rank_share_ms": share_ms,
+                "projected_speedup": full_ms / share_ms, "projected_efficiency": full_ms / share_ms / world,
+                "projected_pose_hypotheses_per_s_at_N": n_obj2 * N_HYP / (share_ms * 1e-3),
+                "rows_whole": n_obj2 * rows_per_obj, "rows_rank_share": -(-n_obj2 * rows_per_obj // world),
+                "stage_ms_whole": full_st, "stage_ms_rank_share": share_st,
+                "stage_speedup": {k: (full_st[k] / share_st[k] if share_st[k] > 0 else None) for k in full_st},
+                "limiting_stage": min(full_st, key=lambda k: full_st[k] / max(share_st[k], 1e-9)),
+                "top_kernels_ms_rank_share": share_top, "all_gathers_stubbed_per_call": gathers,
+                "note": "projection from ONE GPU: one rank's share of the N-GPU call (rows rank::N, gathers replaced by local copies) against the "
+                        "whole workload on one GPU; excludes RCCL time (3 all-gathers of <= 8.5 MB per call) and rank skew; never `value`"}
+        del est2, obs2, det2
+        torch.cuda.empty_cache()
+        return line
+    finally:
+        shutil.rmtree(tmp2, ignore_errors=True)
 
 
 def _free_port() -> int:
@@ -377,7 +443,20 @@ def main():
     ap.add_argument("--cpu-thread-sweep", default="", help="comma list of thread counts: time the cpu_baseline sample at each, write "
                                                           "gpurun_out/cpu_thread_sweep.json and exit")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (faithful K=1/K=5 configs, other backbone / modes)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N",
+                    help="one GPU only, never `value`: run ONE rank's share of the N-GPU workload of --config (rows rank::N, gathers stubbed) and "
+                         "the whole workload, print projected_speedup = T(one GPU, whole) / T(rank share) with the per-stage split, and exit")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="which rank --emulate-rank-of emulates (default 0)")
     a = ap.parse_args()
+
+    if a.emulate_rank_of:
+        if a.gpus != 1 or "WORLD_SIZE" in os.environ:
+            raise SystemExit("--emulate-rank-of is a single-process, single-GPU measurement")
+        torch.cuda.set_device(0)
+        k_e = a.k_hyp or (N_HYP if a.config in (2, 3) else 5)
+        print(json.dumps({"emulate_rank_of": a.emulate_rank_of, "config": a.config,
+                          **emulate_rank_share(a.config, a.emulate_rank_of, a.backbone, k_e, max(1, min(a.steps, 3)), a.emulate_rank)}))
+        return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_relaunch(a.gpus))

@@ -328,7 +328,11 @@ extern "C" int mp_conv_wino_eligible(const mp_conv_desc* d, int n_cu) {
   const long in_bytes = ((long)d->N * Hp + 2) * Wp * d->C * 4;
   const long out_elems = (long)d->N * (d->H + 2 * d->out_border) * (d->W + 2 * d->out_border) * d->Cout;
   if (tiles >= (1L << 30) || in_bytes >= (1L << 31) || out_elems >= (1L << 29)) return 0;
-  return wgs >= (long)n_cu ? 1 : 0;
+  // Grid threshold: below it the direct kernel's split-K path takes the layer.  MP_WINO_MIN_WGS overrides it (A/B runs; see DESIGN.md 5:
+  // the per-rank refiner batch of an 8-GPU run at the released K = 5 is 40 rows = 200 / 104 workgroups for the 256- / 512-channel layers)
+  static const long min_wgs_env = getenv("MP_WINO_MIN_WGS") ? atol(getenv("MP_WINO_MIN_WGS")) : -1;
+  const long min_wgs = min_wgs_env >= 0 ? min_wgs_env : (long)n_cu;
+  return wgs >= min_wgs ? 1 : 0;
 }
 
 static double g_wino_direct = 0.0, g_wino_executed = 0.0;   // host-side totals over the launches since the last reset

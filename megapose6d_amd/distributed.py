@@ -23,11 +23,37 @@ def is_initialized() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+# One-rank emulation (a MEASUREMENT RIG, bench.py --emulate-rank-of N; never a result): the process behaves like rank `r` of `world` --
+# it owns rows r::world of every stage table -- without a process group; a "gather" fills the other ranks' rows with copies of its own
+# block (right shapes, plausible values, wrong poses).  What it times is exactly one rank's share of an N-GPU call minus the RCCL
+# all-gathers (3 per call, a few MB: tens of microseconds over xGMI), on a box that has one GPU.
+_emulated: Optional[tuple] = None
+
+
+def emulate(r: Optional[int], world: int = 1) -> None:
+    """switch the one-rank emulation on (r, world) or off (None)"""
+    global _emulated
+    if r is None:
+        _emulated = None
+        return
+    assert not is_initialized(), "emulate() is for a process WITHOUT a process group"
+    assert 0 <= r < world and world >= 1
+    _emulated = (int(r), int(world))
+
+
+def emulated() -> bool:
+    return _emulated is not None
+
+
 def rank() -> int:
+    if _emulated is not None:
+        return _emulated[0]
     return dist.get_rank() if is_initialized() else 0
 
 
 def world_size() -> int:
+    if _emulated is not None:
+        return _emulated[1]
     return dist.get_world_size() if is_initialized() else 1
 
 
@@ -84,6 +110,13 @@ def gather_rows(local: torch.Tensor, n: int, r: int, world: int, group=None) -> 
     k = local.shape[1]
     block = torch.zeros(per, k, dtype=local.dtype, device=local.device)
     block[: local.shape[0]] = local
+    if _emulated is not None:   # measurement rig: every other rank's block := a copy of ours (see `emulate`)
+        stats.calls += 1
+        stats.bytes += world * per * k * local.element_size()
+        stats.backend = "emulated"
+        if local.shape[0] < per and local.shape[0] > 0:
+            block[local.shape[0]:] = local[-1]
+        return block.unsqueeze(1).expand(per, world, k).reshape(per * world, k)[:n].contiguous()
     out = torch.empty(world * per, k, dtype=local.dtype, device=local.device)
     backend = dist.get_backend(group)
     stats.calls += 1

@@ -54,6 +54,33 @@ def test_integration_md_lists_exactly_the_exported_entry_points():
     assert not unknown, sorted(unknown)
 
 
+def test_one_rank_emulation_shards_like_a_rank_and_gathers_locally():
+    """bench.py --emulate-rank-of N (a measurement rig): the process owns rows r::N like rank r of N, a gather returns a full-size table
+    whose rows r::N are its own (the other ranks' rows are copies); switching it off restores the single-process behaviour."""
+    from megapose6d_amd import distributed as mpd
+
+    assert mpd.world_size() == 1 and mpd.rank() == 0 and not mpd.emulated()
+    mpd.emulate(3, 8)
+    try:
+        assert mpd.emulated() and mpd.rank() == 3 and mpd.world_size() == 8
+        n = 45   # ragged: ranks 0..4 own 6 rows, ranks 5..7 own 5
+        idx = mpd.shard_indices(n, 3, 8)
+        assert list(idx[:3]) == [3, 11, 19] and len(idx) == mpd.shard_size(n, 3, 8) == 6
+        local = torch.arange(len(idx) * 2, dtype=torch.float32).view(len(idx), 2) + 100.0
+        mpd.stats.reset()
+        full = mpd.gather_rows(local, n, 3, 8)
+        assert full.shape == (n, 2) and torch.equal(full[idx], local)
+        assert mpd.stats.calls == 1 and mpd.stats.backend == "emulated"
+        mpd.emulate(7, 8)   # a rank with the shorter shard: the padded tail must not leak zeros into its own rows
+        idx7 = mpd.shard_indices(n, 7, 8)
+        local7 = torch.ones(len(idx7), 3)
+        full7 = mpd.gather_rows(local7, n, 7, 8)
+        assert full7.shape == (n, 3) and torch.equal(full7[idx7], local7) and bool((full7 == 1).all())
+    finally:
+        mpd.emulate(None)
+    assert mpd.world_size() == 1 and not mpd.emulated()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from megapose6d_amd import _lib
 
