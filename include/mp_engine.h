@@ -117,7 +117,8 @@ float mp_mesh_db_radius(const mp_mesh_db* db, int mesh_id);
 #define MP_RASTER_XREC 64u         /* d_out points at the bf16 pixel RECORDS of the exact-piece stem convolution (mp_conv_stem_xrec):
                                      [x1,x2,x3 of every crop channel | the 8-bit integer k of every render channel (NOT divided by 255) |
                                      zero padding], mp_xrec_elements(C_crop, n_render_channels) elements per pixel.  mp_raster_render_crop
-                                     only (c0_crop = 0, no depth channel, one launch writes every channel of the record); stride_v /
+                                     (c0_crop = 0, no depth channel, one launch writes every channel of the record) or, with depth channels,
+                                     mp_raster_render_xrec; stride_v /
                                      stride_y / stride_x count bf16 elements (stride_x = the record length), c_rgb / c_normals /
                                      stride_view stay logical channel numbers.  The values are the ones the fp32 output holds: k = the
                                      integer whose k / 255 the fp32 path stores, x1 + x2 + x3 = the fp32 crop value exactly.            */
@@ -159,6 +160,19 @@ int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh_ids, const
                           int c_normals, int c_depth, void* d_workspace, size_t workspace_bytes,
                           const float* d_images /*[n_im,C,H,W], or [n_im,H,W,4] if images_nhwc4*/, int images_nhwc4, int n_im,
                           int C, int H, int W, const int32_t* d_im_ids, const float* d_boxes, int c0_crop, mp_stream stream);
+/* The record form of that launch for models WITH depth channels (the RGBD refiner, training/pose_models_cfg.py:101-103: observation depth
+ * + one rendered depth per view; BASELINE.json configs[2]): MP_RASTER_XREC is implied, d_out = bf16 records of
+ * mp_xrec_elements(popcount(f32_mask), n_channels - popcount(f32_mask)) elements.  Bit c of f32_mask marks logical channel c as fp32-kind
+ * (three exact bf16 pieces): the crop's channels and every depth channel must be marked, the rgb / normal channels must not.  Depth
+ * channels -- the 4th crop channel and c_depth of every view -- are normalised BEFORE the split exactly as mp_normalize_depth does it on the
+ * fp32 tensor (models/pose_rigid.py:466-496; depth_mode 0..3, d_tCR [n_items,3]: the row's object-centre translation, z = reference depth;
+ * background depth 0 is normalised like any other value), so the record decodes to the fp32 tensor path's values bit for bit. */
+int mp_raster_render_xrec(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K, int n_views,
+                          int h, int w, uint32_t flags, const mp_lights* lights, void* d_out_records, int64_t stride_v,
+                          int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb,
+                          int c_normals, int c_depth, void* d_workspace, size_t workspace_bytes,
+                          const float* d_images, int images_nhwc4, int n_im, int C, int H, int W, const int32_t* d_im_ids,
+                          const float* d_boxes, uint32_t f32_mask, const float* d_tCR, int depth_mode, mp_stream stream);
 /* observation frames [n_im,C,H,W] (C = 3 | 4) -> [n_im,H,W,4] (4th channel 0 for RGB): one 16-byte load per roi_align tap in the
  * fused crop; done once per observation, not per step */
 int mp_pack_observation_nhwc4(const float* d_images, int n_im, int C, int H, int W, float* d_out, mp_stream stream);
@@ -262,17 +276,22 @@ int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogue_cycles);
  * layer: models/torchvision_resnet.py:213-216, models/wide_resnet.py:65-67).  The render channels of the CNN input are 8-bit integers
  * k / 255 by the reference's contract (uint8 -> float, panda3d_batch_renderer.py:261-274): k is ONE bf16 exactly; the weights (BN scale
  * and 1/255 folded in) and the fp32 observation-crop channels are split by truncation into three bf16 pieces each (24 = 3 x 8 mantissa
- * bits), so every bf16 x bf16 product is exact in the fp32 accumulator and the result differs from the fp32 convolution only in the
- * order of the fp32 additions -- at 3/16 (9/16 for the crop channels) of the fp32-MFMA time.
+ * bits), so every bf16 x bf16 product is exact in the fp32 accumulator and the result differs from the fp32 convolution in the order of
+ * the fp32 additions and in one rounding per integer-channel weight (the folded 1/255) -- at 3/16 (9/16 for the fp32-kind channels) of
+ * the fp32-MFMA time.
  * Input = "xrec": padded NHWC of bf16 RECORDS, mp_xrec_elements(n_f32, n_u8) = roundup8(3 n_f32 + n_u8) elements per pixel:
- *   [x1,x2,x3 of fp32 channel 0 | .. | channel n_f32-1 | k of integer channel 0 | .. | zero padding]   (what MP_RASTER_XREC writes).
+ *   [x1,x2,x3 of the first fp32-kind channel | .. | of the last | k of the first integer channel | .. | zero padding]   (what MP_RASTER_XREC writes).
  * mp_conv_stem_xrec: desc as for mp_conv2d_nhwc with d_x = the record tensor, C ignored, c_real = n_f32 + n_u8; KH = KW in {5, 7},
- * stride 2, Cout % 64 == 0, records of 16..40 elements, no residual / second output. */
+ * stride 2, Cout % 64 == 0, records of 16..48 elements, no residual / second output. */
 int mp_xrec_elements(int n_f32, int n_u8);
 int mp_conv_stem_supported(int KS, int n_f32, int n_u8);
 size_t mp_conv_stem_packed_bytes(int KS, int n_f32, int n_u8, int Cout);
 int mp_conv_stem_pack_weights(const float* h_w_oihw, int Cout, int Cin, int KS, int n_f32, const float* h_scale /*[Cout] or NULL*/,
                               void* h_packed);
+/* the same for a record whose fp32-kind channels are not the leading ones: input channel c (< 32) is fp32-kind iff bit c of f32_mask is
+ * set (an RGBD refiner: crop rgb + crop depth + one rendered depth per view = 0x8102040F for 32 channels, 4 views) */
+int mp_conv_stem_pack_weights_mask(const float* h_w_oihw, int Cout, int Cin, int KS, uint32_t f32_mask, const float* h_scale,
+                                   void* h_packed);
 int mp_conv_stem_xrec(const mp_conv_desc* desc, const void* d_packed, int n_f32, mp_stream stream);
 /* the same with the 3x3 / stride-2 / pad-1 max pool that follows the stem (models/torchvision_resnet.py:216) fused into the epilogue:
  * d_ypool = padded NHWC [N, (Ho-1)/2+1, (Wo-1)/2+1, Cout] with border pool_border; desc->relu must be set; desc->d_y may be NULL (the stem
@@ -334,12 +353,20 @@ int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, in
 /* the same forward on the bf16 stem RECORDS the rasteriser writes with MP_RASTER_XREC (n_f32 fp32-kind channels first, all other   */
 /* input channels 8-bit integers): only the stem convolution differs (mp_conv_stem_xrec: exact bf16 pieces, 16x the fp32 MFMA rate). */
 /* mp_backbone_xrec_elements: record length in bf16 elements for this backbone (packs the piece blob on first use), 0 = the stem has   */
-/* no such form (records outside 16..40 elements): use mp_backbone_forward.  The tensor has the geometry    */
+/* no such form (records outside 16..48 elements): use mp_backbone_forward.  The tensor has the geometry    */
 /* of the fp32 input (border mp_backbone_input_border()) with records of that many bf16 elements per pixel.                            */
 int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32);
 int mp_backbone_forward_xrec(mp_backbone* bb, const void* d_xrec, int n_f32, int batch, int h, int w, float* d_out,
                              float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
                              mp_stream stream);
+/* ... with the fp32-kind channels given as a mask (bit c = input channel c; depth channels of an RGBD model).  mp_backbone_xrec_prepare
+ * packs and uploads the stem's piece blob for that mask (host work + a synchronous copy: call it once, outside stream capture, from one
+ * thread) and returns the record length (0 = no exact-piece form); mp_backbone_forward_xrec_mask only uses a prepared blob and fails if
+ * there is none -- it never allocates. */
+int mp_backbone_xrec_prepare(mp_backbone* bb, uint32_t f32_mask);
+int mp_backbone_forward_xrec_mask(mp_backbone* bb, const void* d_xrec, uint32_t f32_mask, int batch, int h, int w, float* d_out,
+                                  float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
+                                  mp_stream stream);
 /* algorithmic conv+fc FLOPs of one forward at this batch (2*MACs, real channels only)       */
 double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w);
 

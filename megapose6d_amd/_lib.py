@@ -102,6 +102,8 @@ SIGNATURES = {
                               _vp, _sz, _vp]),
     "mp_raster_render_crop": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
                                    _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mp_raster_render_xrec": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
+                                   _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _vp, _u32, _vp, _i, _vp]),
     "mp_pack_observation_nhwc4": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mp_crop_roi_align": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _i, _vp]),
     "mp_normalize_depth": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),
@@ -126,6 +128,7 @@ SIGNATURES = {
     "mp_conv_stem_supported": (_i, [_i, _i, _i]),
     "mp_conv_stem_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "mp_conv_stem_pack_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mp_conv_stem_pack_weights_mask": (_i, [_vp, _i, _i, _i, _u32, _vp, _vp]),
     "mp_conv_stem_xrec": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
     "mp_conv_stem_xrec_pool": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -141,6 +144,8 @@ SIGNATURES = {
     "mp_backbone_forward_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_xrec_elements": (_i, [_vp, _i]),
     "mp_backbone_forward_xrec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_backbone_xrec_prepare": (_i, [_vp, _u32]),
+    "mp_backbone_forward_xrec_mask": (_i, [_vp, _vp, _u32, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_flops": (C.c_double, [_vp, _i, _i, _i]),
     "mp_normalize_T": (_i, [_vp, _i, _vp, _vp]),
     "mp_init_extents": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

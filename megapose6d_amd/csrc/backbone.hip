@@ -52,8 +52,7 @@ struct mp_backbone {
   // exact-piece bf16 stem (conv_stem.hip): the stem's OIHW weights + folded BN scale stay on the host so that the piece blob can be
   // packed for the record layout (number of fp32-kind channels) the caller's rasteriser launch writes
   std::vector<float> stem_w_host, stem_scale_host;
-  void* d_stem_pieces = nullptr;
-  int stem_pieces_nf32 = -1;
+  std::map<uint32_t, void*> stem_blobs;   // f32-kind channel mask -> device blob (mp_backbone_xrec_prepare); never freed before destroy
   // workspace bookkeeping: borders are zeroed once per (pointer, batch, h, w); several workspaces may be live at once
   // (one per HIP stream when half-batches are interleaved on two streams)
   struct WsKey { void* ptr; int batch, h, w; };
@@ -316,29 +315,37 @@ extern "C" int mp_backbone_workspace_reset(mp_backbone* bb, const void* d_ws) {
   return MP_OK;
 }
 
-// The piece blob of the stem for records with `n_f32` fp32-kind channels (packed and uploaded on first use); returns the record length
-// in bf16 elements, 0 if this backbone's stem has no exact-piece form (unsupported record sizes).
-extern "C" int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32) {
-  if (!bb || n_f32 < 0 || n_f32 > bb->c_in || bb->stem_w_host.empty()) return 0;
-  const int n_u8 = bb->c_in - n_f32;
+// The piece blob of the stem for records whose fp32-kind channels are the set bits of `f32_mask` (packed and uploaded on the first call
+// for a mask: host work + a synchronous copy, so this is the explicit PREPARE step -- once, outside stream capture, from one thread; the
+// forward only looks the blob up); returns the record length in bf16 elements, 0 if this backbone's stem has no exact-piece form.
+extern "C" int mp_backbone_xrec_prepare(mp_backbone* bb, uint32_t f32_mask) {
+  if (!bb || bb->stem_w_host.empty() || bb->c_in > 32) return 0;
+  if (bb->c_in < 32 && (f32_mask >> bb->c_in) != 0u) return 0;
+  const int n_f32 = __builtin_popcount(f32_mask), n_u8 = bb->c_in - n_f32;
   if (!mp_conv_stem_supported(bb->stem.K, n_f32, n_u8) || bb->stem.Cout % 64 != 0) return 0;
-  if (bb->stem_pieces_nf32 != n_f32) {
+  if (!bb->stem_blobs.count(f32_mask)) {
     std::vector<unsigned char> blob(mp_conv_stem_packed_bytes(bb->stem.K, n_f32, n_u8, bb->stem.Cout));
-    if (mp_conv_stem_pack_weights(bb->stem_w_host.data(), bb->stem.Cout, bb->c_in, bb->stem.K, n_f32,
-                                  bb->stem_scale_host.empty() ? nullptr : bb->stem_scale_host.data(), blob.data()) != MP_OK)
+    if (mp_conv_stem_pack_weights_mask(bb->stem_w_host.data(), bb->stem.Cout, bb->c_in, bb->stem.K, f32_mask,
+                                       bb->stem_scale_host.empty() ? nullptr : bb->stem_scale_host.data(), blob.data()) != MP_OK)
       return 0;
     void* d = nullptr;
     if (hipMalloc(&d, blob.size()) != hipSuccess) return 0;
     if (hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return 0; }
-    bb->allocs.push_back(d);   // (an older blob for another n_f32 stays allocated until destroy: in-flight launches may still read it)
-    bb->d_stem_pieces = d;
-    bb->stem_pieces_nf32 = n_f32;
+    bb->allocs.push_back(d);
+    bb->stem_blobs[f32_mask] = d;
   }
   return mp_xrec_elements(n_f32, n_u8);
 }
 
-// x_mode: 0 = fp32 padded NHWC, 1 = binary16 elements (MP_RASTER_F16), 2 = bf16 stem records with n_f32 fp32-kind channels (MP_RASTER_XREC)
-static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, int n_f32, int batch, int h, int w, float* d_out, float* d_sigmoid,
+static uint32_t leading_mask(int n_f32) { return n_f32 >= 32 ? 0xFFFFFFFFu : n_f32 <= 0 ? 0u : (1u << n_f32) - 1u; }
+
+extern "C" int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32) {
+  if (!bb || n_f32 < 0 || n_f32 > bb->c_in) return 0;
+  return mp_backbone_xrec_prepare(bb, leading_mask(n_f32));
+}
+
+// x_mode: 0 = fp32 padded NHWC, 1 = binary16 elements (MP_RASTER_F16), 2 = bf16 stem records whose fp32-kind channels are f32_mask (MP_RASTER_XREC)
+static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, uint32_t f32_mask, int batch, int h, int w, float* d_out, float* d_sigmoid,
                                  float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
   const bool x_f16 = x_mode == 1;
   MP_REQUIRE(bb && d_x && d_out && d_ws, "mp_backbone_forward: null pointer");
@@ -372,8 +379,11 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
   bool stem_pooled = false;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
   if (x_mode == 2) {
-    MP_REQUIRE(mp_backbone_xrec_elements(bb, n_f32) > 0, "mp_backbone_forward_xrec: this backbone's stem has no exact-piece form for %d fp32 channels of %d",
-               n_f32, bb->c_in);
+    const auto blob_it = bb->stem_blobs.find(f32_mask);
+    MP_REQUIRE(blob_it != bb->stem_blobs.end(), "mp_backbone_forward_xrec: no piece blob for the fp32-kind channel mask 0x%x of this %d-channel stem: "
+               "call mp_backbone_xrec_prepare / mp_backbone_xrec_elements first (it returns 0 if the stem has no exact-piece form)", f32_mask, bb->c_in);
+    const void* d_stem_pieces = blob_it->second;
+    const int n_f32 = __builtin_popcount(f32_mask);
     mp_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.d_x = d_x; d.N = batch; d.H = h; d.W = w; d.C = bb->stem.Cin_p; d.c_real = bb->c_in; d.in_border = bb->in_border;
@@ -384,10 +394,10 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
     static const bool fuse_pool = !(getenv("MP_STEM_POOL") && atoi(getenv("MP_STEM_POOL")) == 0);
     if (!bb->wide && fuse_pool) {
       d.d_y = nullptr;
-      rc = mp_conv_stem_xrec_pool(&d, bb->d_stem_pieces, n_f32, A[0], 1, s);
+      rc = mp_conv_stem_xrec_pool(&d, d_stem_pieces, n_f32, A[0], 1, s);
       stem_pooled = true;
     } else {
-      rc = mp_conv_stem_xrec(&d, bb->d_stem_pieces, n_f32, s);
+      rc = mp_conv_stem_xrec(&d, d_stem_pieces, n_f32, s);
     }
   } else {
     rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
@@ -444,7 +454,13 @@ extern "C" int mp_backbone_forward(mp_backbone* bb, const float* d_x, int batch,
 
 extern "C" int mp_backbone_forward_xrec(mp_backbone* bb, const void* d_xrec, int n_f32, int batch, int h, int w, float* d_out, float* d_sigmoid,
                                         float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
-  return backbone_forward_impl(bb, (const float*)d_xrec, 2, n_f32, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+  MP_REQUIRE(bb && n_f32 >= 0 && n_f32 <= 32, "mp_backbone_forward_xrec: bad arguments");
+  return backbone_forward_impl(bb, (const float*)d_xrec, 2, leading_mask(n_f32), batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+}
+
+extern "C" int mp_backbone_forward_xrec_mask(mp_backbone* bb, const void* d_xrec, uint32_t f32_mask, int batch, int h, int w, float* d_out,
+                                             float* d_sigmoid, float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+  return backbone_forward_impl(bb, (const float*)d_xrec, 2, f32_mask, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
 }
 
 extern "C" int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, int h, int w, float* d_out, float* d_sigmoid,

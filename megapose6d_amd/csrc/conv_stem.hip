@@ -11,12 +11,16 @@
 // Every product k * w_i then has <= 16 significant bits: exact in the MFMA's fp32 accumulator.  The three observation-crop
 // channels (roi_align output: general fp32) are split the same way, x = x1 + x2 + x3, and get all 9 exact piece products.  So
 //     y = sum_taps ( sum_i k w_i  |  sum_{i,j} x_i w_j )      accumulated in fp32
-// differs from the fp32-MFMA convolution only in the ORDER of fp32 additions (same error class as any re-association, far below
-// the Winograd layers' 1e-6) -- but v_mfma_f32_16x16x32_bf16 retires 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32:
-// 3 (9) bf16 products per fp32 product = 3/16 (9/16) of the matrix time.
+// differs from the fp32-MFMA convolution in the ORDER of fp32 additions (same error class as any re-association, far below the
+// Winograd layers' 1e-6) and in ONE rounding per integer-channel weight: the 1/255 of a render value is folded into the weight,
+// fl32(w * scale / 255) (one rounding of the exact product, formed in double), and multiplied with the integer k exactly, where the
+// fp32 path -- like the reference -- multiplies fl32(k / 255) with fl32(w * scale): each such product differs by <= 1 ulp (the record
+// tests bound the whole-network effect at 1e-5 of the feature scale).  v_mfma_f32_16x16x32_bf16 retires 16x the multiply-adds per cycle
+// of v_mfma_f32_32x32x2_f32: 3 (9) bf16 products per fp32 product = 3/16 (9/16) of the matrix time.
 //
-// Input ("xrec", written by raster_tiles with MP_RASTER_XREC): padded NHWC of bf16 RECORDS, R = 8*Q elements per pixel:
-//   [x1,x2,x3 of fp32 channel 0 | ... channel n_f32-1 | k of integer channel 0 | ... | zero padding].
+// Input ("xrec", written by raster_tiles with MP_RASTER_XREC): padded NHWC of bf16 RECORDS, R = 8*Q elements per pixel (Q = 2 .. 6):
+//   [x1,x2,x3 of the first fp32-kind channel | ... of the last | k of the first integer channel | ... | zero padding].
+// fp32-kind = the observation crop and, for RGBD models, every (normalised) depth channel: mp_conv_stem_pack_weights_mask.
 // Structure (MI355X-first, not a GEMM library shape):
 //   * workgroup = 8 x 16 output pixels x 64 output channels, 4 waves, TWO workgroups per CU.  The input patch of the tile
 //     ((2*8+KH-2) x (2*16+KW-2) pixel records, 62 KB at 7x7 / Q = 5) is staged in LDS ONCE; there is no im2col anywhere: a K slice
@@ -64,10 +68,18 @@ struct Params {
   int Hq, Wq, pool_border;
 };
 
+constexpr size_t LDS_PER_WG = 80 * 1024;   // two workgroups per CU share the 160 KB
+
 template <int KS, int Q>
 struct Geo {
   static constexpr int PH = 2 * (TH - 1) + KS, PW = 2 * (TW - 1) + KS;   // patch size in pixels
-  static constexpr int ROW16 = PW * Q;                                    // 16-byte chunks per patch row
+  // LDS pixel pitch in 16-byte chunks.  The 8 lanes a ds_read_b128 serves per clock are 8 consecutive output pixels = input pixels two apart:
+  // their chunk addresses are 2 i QP (+ a common offset) and fall into 8 different 16-byte bank groups iff QP is ODD.  An even record
+  // (Q = 2: the coarse net, Q = 4, Q = 6: RGBD) is therefore staged with one chunk of padding per pixel wherever the patch still fits two
+  // workgroups per CU (round 4's Q = 2 instance ran with 2-way conflicts: SQ_LDS_BANK_CONFLICT 1.9e9 per launch); the 7x7 / Q = 6 patch
+  // does not fit padded and keeps its 2-way conflict.
+  static constexpr int QP = (Q % 2 == 0 && (size_t)(PH + 1) * ((PW * (Q + 1)) | 1) * 16 <= LDS_PER_WG) ? Q + 1 : Q;
+  static constexpr int ROW16 = PW * QP;                                   // 16-byte chunks per patch row (incl. the per-pixel padding)
   static constexpr int PITCH16 = ROW16 | 1;                               // odd pitch (in chunks): row wraps keep the odd slice distance
   static constexpr int PITCH = PITCH16 * 16;
   static constexpr int KWQ = KS * Q;                                      // slices per kernel row
@@ -77,6 +89,7 @@ struct Geo {
   static constexpr size_t OUT_TILE = (size_t)TH * TW * NCO * 4;           // the output tile is staged in the same memory
   static constexpr size_t LDS = PATCH > OUT_TILE ? PATCH : OUT_TILE;
   static_assert(4 * T + 4 - S <= KWQ, "padding slices (and the look-ahead read past the last step) must stay inside the extra row");
+  static_assert(LDS <= LDS_PER_WG, "the patch must leave room for a second workgroup on the CU");
 };
 
 // POOL: the 3x3 / stride-2 / pad-1 max pool that follows the stem (models/torchvision_resnet.py:216) is taken from the tile while it sits in
@@ -102,7 +115,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, p.img_bytes, 0x00020000);
     const int row_bytes = p.Wp * (16 * Q);
     const int org = (2 * ty * TH + p.in_off) * row_bytes + (2 * tx * TW + p.in_off) * (16 * Q);
-    constexpr int N_CH = G::PH * G::ROW16, PER = (N_CH + 255) / 256;
+    constexpr int SRC16 = G::PW * Q;   // chunks per patch row in global memory (records are dense there)
+    constexpr int N_CH = G::PH * SRC16, PER = (N_CH + 255) / 256;
     constexpr int HALF = (PER + 1) / 2;
     u32x4 v[HALF];
 #pragma unroll
@@ -110,16 +124,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int k = 0; k < HALF; ++k) {
         const int c = tid + 256 * (h * HALF + k);
-        const int row = c / G::ROW16, col = c - row * G::ROW16;
+        const int row = c / SRC16, col = c - row * SRC16;
         v[k] = (c < N_CH) ? __builtin_amdgcn_raw_buffer_load_b128(r_x, org + row * row_bytes + col * 16, 0, 0) : u32x4{0, 0, 0, 0};
       }
 #pragma unroll
       for (int k = 0; k < HALF; ++k) {
         const int c = tid + 256 * (h * HALF + k);
-        const int row = c / G::ROW16, col = c - row * G::ROW16;
-        if (c < N_CH) *reinterpret_cast<u32x4*>(lds + row * G::PITCH + col * 16) = v[k];
+        const int row = c / SRC16, col = c - row * SRC16;
+        const int lcol = G::QP == Q ? col : col + (col / Q) * (G::QP - Q);   // pixel * QP + q
+        if (c < N_CH) *reinterpret_cast<u32x4*>(lds + row * G::PITCH + lcol * 16) = v[k];
       }
     }
+    // (the padding chunk of every pixel is never read: a slice's chunk index is q < Q)
     for (int c = tid; c < G::PITCH16; c += 256) *reinterpret_cast<u32x4*>(lds + G::PH * G::PITCH + c * 16) = u32x4{0, 0, 0, 0};
   }
 
@@ -137,11 +153,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- A addressing: lane = (pixel column i, slice group g); slice s = 4 t + g -> (kernel row, chunk in the row run) ----------------
   const int i = lane & 15, g = lane >> 4;
   int s_r = g;                                   // s % KWQ (g < KWQ)
-  int a_off = (2 * i) * (16 * Q) + g * 16;       // pixel (row 0, column i) + the slice's offset
+  int a_row = (2 * i) * (16 * G::QP);            // pixel (kernel row 0, column i); + PITCH per kernel row
+  // slice s_r of a kernel row = (kw, q) = (s_r / Q, s_r % Q) sits at chunk kw * QP + q = s_r + kw * (QP - Q) of the row run
+  auto slice_off = [&](int sr) { return G::QP == Q ? sr * 16 : (sr + (sr / Q) * (G::QP - Q)) * 16; };
+  int a_off = a_row + slice_off(s_r);
   auto advance = [&]() {                         // s += 4
     s_r += 4;
-    a_off += 64;
-    if (s_r >= G::KWQ) { s_r -= G::KWQ; a_off += G::PITCH - G::KWQ * 16; }
+    if (s_r >= G::KWQ) { s_r -= G::KWQ; a_row += G::PITCH; }
+    a_off = a_row + slice_off(s_r);
   };
   f32x4 acc[TH];
 #pragma unroll
@@ -299,7 +318,7 @@ extern "C" int mp_xrec_elements(int n_f32, int n_u8) {
 
 extern "C" int mp_conv_stem_supported(int KS, int n_f32, int n_u8) {
   const int R = mp_xrec_elements(n_f32, n_u8);
-  return (KS == 7 || KS == 5) && R >= 16 && R <= 40 ? 1 : 0;
+  return (KS == 7 || KS == 5) && R >= 16 && R <= 48 ? 1 : 0;
 }
 
 extern "C" size_t mp_conv_stem_packed_bytes(int KS, int n_f32, int n_u8, int Cout) {
@@ -326,9 +345,22 @@ static void split3(float v, unsigned short out[3]) {
 // = (kh, kw, chunk q of the pixel record), element e of the chunk = record slot 8q + e -> input channel; piece = w1 | w2 | w3 of
 // w * scale (* 1/255 for the integer channels, one rounding of the exact product)
 extern "C" int mp_conv_stem_pack_weights(const float* w, int Cout, int Cin, int KS, int n_f32, const float* scale, void* packed) {
-  const int n_u8 = Cin - n_f32;
-  MP_REQUIRE(w && packed && n_f32 >= 0 && n_u8 >= 0 && Cout % stem::NCO == 0 && mp_conv_stem_supported(KS, n_f32, n_u8),
-             "mp_conv_stem_pack_weights: bad arguments (Cout %% 64, KS 5 | 7, 16 <= record <= 40 elements)");
+  MP_REQUIRE(n_f32 >= 0 && n_f32 <= 32 && n_f32 <= Cin, "mp_conv_stem_pack_weights: bad n_f32");
+  return mp_conv_stem_pack_weights_mask(w, Cout, Cin, KS, n_f32 >= 32 ? 0xFFFFFFFFu : (1u << n_f32) - 1u, scale, packed);
+}
+
+// the general record: input channel c is fp32-kind (three pieces) iff bit c of f32_mask is set -- e.g. an RGBD refiner's depth channels
+// (observation depth + one rendered depth per view) -- and sits, in channel order, in front of the integer channels:
+//   [x1,x2,x3 of every fp32-kind channel | k of every integer channel | zero padding]
+extern "C" int mp_conv_stem_pack_weights_mask(const float* w, int Cout, int Cin, int KS, uint32_t f32_mask, const float* scale, void* packed) {
+  MP_REQUIRE(Cin >= 1 && Cin <= 32 && (Cin == 32 || (f32_mask >> Cin) == 0u), "mp_conv_stem_pack_weights_mask: mask names channels >= Cin (<= 32 input channels)");
+  const int n_f32 = __builtin_popcount(f32_mask), n_u8 = Cin - n_f32;
+  MP_REQUIRE(w && packed && n_u8 >= 0 && Cout % stem::NCO == 0 && mp_conv_stem_supported(KS, n_f32, n_u8),
+             "mp_conv_stem_pack_weights: bad arguments (Cout %% 64, KS 5 | 7, 16 <= record <= 48 elements)");
+  int ch_of_f32[32], ch_of_u8[32];
+  for (int c = 0, a = 0, b = 0; c < Cin; ++c) {
+    if ((f32_mask >> c) & 1u) ch_of_f32[a++] = c; else ch_of_u8[b++] = c;
+  }
   const int R = mp_xrec_elements(n_f32, n_u8), Q = R / 8, T = stem::n_steps(KS, Q), S = KS * KS * Q;
   unsigned short* out = (unsigned short*)packed;
   memset(out, 0, mp_conv_stem_packed_bytes(KS, n_f32, n_u8, Cout));
@@ -342,8 +374,8 @@ extern "C" int mp_conv_stem_pack_weights(const float* w, int Cout, int Cin, int 
         const int slot = 8 * q + e;
         int ch;
         double f;
-        if (slot < 3 * n_f32) { ch = slot / 3; f = sc; }
-        else if (slot < 3 * n_f32 + n_u8) { ch = n_f32 + slot - 3 * n_f32; f = sc / 255.0; }
+        if (slot < 3 * n_f32) { ch = ch_of_f32[slot / 3]; f = sc; }
+        else if (slot < 3 * n_f32 + n_u8) { ch = ch_of_u8[slot - 3 * n_f32]; f = sc / 255.0; }
         else continue;
         const float v = (float)((double)w[(((size_t)co * Cin + ch) * KS + kh) * KS + kw] * f);
         unsigned short pc[3];
@@ -364,7 +396,7 @@ static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32
   const int n_u8 = d->c_real - n_f32;
   MP_REQUIRE(d->KH == d->KW && d->stride == 2 && d->Cout % stem::NCO == 0 && !d->d_residual && !d->d_y_act && d->in_border >= d->pad &&
                  mp_conv_stem_supported(d->KH, n_f32, n_u8),
-             "mp_conv_stem_xrec: unsupported layer (square 5x5 / 7x7, stride 2, Cout %% 64, c_real = real channels)");
+             "mp_conv_stem_xrec: unsupported layer (square 5x5 / 7x7, stride 2, Cout %% 64, c_real = real channels, 16 <= record <= 48 elements)");
   const int R = mp_xrec_elements(n_f32, n_u8), Q = R / 8;
   stem::Params p;
   p.x = (const unsigned char*)d->d_x; p.w = (const unsigned char*)d_packed; p.bias = d->d_bias; p.y = d->d_y;
@@ -389,8 +421,8 @@ static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32
   if (d->KH == KSV && Q == QV)                                                                                                     \
     return d_ypool ? stem::launch<KSV, QV, true>(p, s, flops, bytes, "conv_stem_bf16x3+maxpool<" #KSV "x" #KSV ",Q" #QV ">")         \
                    : stem::launch<KSV, QV, false>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");
-  MP_STEM_GO(7, 2) MP_STEM_GO(7, 3) MP_STEM_GO(7, 4) MP_STEM_GO(7, 5)
-  MP_STEM_GO(5, 2) MP_STEM_GO(5, 3) MP_STEM_GO(5, 4) MP_STEM_GO(5, 5)
+  MP_STEM_GO(7, 2) MP_STEM_GO(7, 3) MP_STEM_GO(7, 4) MP_STEM_GO(7, 5) MP_STEM_GO(7, 6)
+  MP_STEM_GO(5, 2) MP_STEM_GO(5, 3) MP_STEM_GO(5, 4) MP_STEM_GO(5, 5) MP_STEM_GO(5, 6)
 #undef MP_STEM_GO
   set_error("mp_conv_stem_xrec: no instance for %dx%d, record of %d elements", d->KH, d->KW, R);
   return MP_ERR_INVALID;

@@ -331,7 +331,10 @@ extern "C" int mp_conv_wino_eligible(const mp_conv_desc* d, int n_cu) {
   // Grid threshold: below it the direct kernel's split-K path takes the layer.  MP_WINO_MIN_WGS overrides it (A/B runs; see DESIGN.md 5:
   // the per-rank refiner batch of an 8-GPU run at the released K = 5 is 40 rows = 200 / 104 workgroups for the 256- / 512-channel layers)
   static const long min_wgs_env = getenv("MP_WINO_MIN_WGS") ? atol(getenv("MP_WINO_MIN_WGS")) : -1;
-  const long min_wgs = min_wgs_env >= 0 ? min_wgs_env : (long)n_cu;
+  // default: a quarter of the CUs.  Measured (profiles/r05_emulated_rank_of_8.txt): the 40-row refiner share of an 8-GPU run at K = 5 has 200 / 104
+  // workgroups on its 256- / 512-channel layers; with the round-4 threshold (one workgroup per CU) they fell to split-K: 27.9 ms per share,
+  // 21.1 ms at n_cu / 2, 18.5 ms at n_cu / 4 -- and the 5-row K = 5 call on one GPU gets SLOWER below that (53.5 ms at 16 vs 50.6 at 64)
+  const long min_wgs = min_wgs_env >= 0 ? min_wgs_env : (long)(n_cu / 4);
   return wgs >= min_wgs ? 1 : 0;
 }
 

@@ -442,7 +442,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
     float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
-    long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop) {
+    long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop, uint32_t xrec_mask,
+    const float* __restrict__ depth_tcr, int depth_mode) {
   // LDS per wave: zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32 | stage [64][run] floats
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // (a readfirstlane'd wave index makes the LDS bases scalar -- and the kernel 4 % slower, measured)
@@ -458,19 +459,22 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   float* my_stage = stage + (size_t)lane * run;
   // OUT_XREC: the staging area holds the pixel records themselves, [64][stride_x] bf16 (never larger than [64][run] floats: the
   // launcher checks); `put` files a channel value into the lane's pixel in whichever form the launch stages
-  const int xrec_nf = crop.C;   // (OUT_XREC) the crop's channels are the fp32-kind ones, 3 record slots each
+  // (OUT_XREC) logical channel c is fp32-kind (three record slots) iff bit c of xrec_mask is set -- the crop's channels and, for RGBD
+  // models, every depth channel --; the fp32-kind channels come first in the record, in channel order, then the integer channels
+  const int xrec_nf = __builtin_popcount(xrec_mask);
   unsigned short* my_rec = reinterpret_cast<unsigned short*>(stage) + (size_t)lane * (int)stride_x;
   auto put = [&](int ch, float v) {   // ch = logical channel number
     if constexpr (OUT == OUT_XREC) {
-      if (ch < xrec_nf) {   // exact truncation split x = x1 + x2 + x3 (three bf16 pieces)
+      const int f_below = __builtin_popcount(xrec_mask & ((1u << ch) - 1u));   // fp32-kind channels in front of ch (ch < 32)
+      if ((xrec_mask >> ch) & 1u) {   // exact truncation split x = x1 + x2 + x3 (three bf16 pieces)
         const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
         const float r1 = v - __uint_as_float(b1);
         const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
         const float r2 = r1 - __uint_as_float(b2);
-        my_rec[3 * ch] = (unsigned short)(b1 >> 16); my_rec[3 * ch + 1] = (unsigned short)(b2 >> 16);
-        my_rec[3 * ch + 2] = (unsigned short)(__float_as_uint(r2) >> 16);
+        my_rec[3 * f_below] = (unsigned short)(b1 >> 16); my_rec[3 * f_below + 1] = (unsigned short)(b2 >> 16);
+        my_rec[3 * f_below + 2] = (unsigned short)(__float_as_uint(r2) >> 16);
       } else {              // an integer 0..255: one bf16, exactly
-        my_rec[2 * xrec_nf + ch] = (unsigned short)(__float_as_uint(v) >> 16);
+        my_rec[3 * xrec_nf + (ch - f_below)] = (unsigned short)(__float_as_uint(v) >> 16);
       }
     } else {
       my_stage[ch - c_lo] = v;
@@ -494,6 +498,20 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   const bool gl_eye = flags & MP_RASTER_NORMALS_GL;
   const bool need_shade = c_rgb >= 0 || do_norm;   // a depth-only render (the depth refiner's) has nothing to shade
+  // (OUT_XREC) depth channels enter the record NORMALISED, with the operations of normalize_depth_kernel (crop.hip; reference
+  // models/pose_rigid.py:466-496) in the same order, so that the three pieces add up to the fp32 tensor path's value bit for bit
+  float depth_zr = 1.f;
+  if constexpr (OUT == OUT_XREC) {
+    if (depth_mode != 0 && depth_tcr) depth_zr = depth_tcr[3 * (size_t)item + 2];
+  }
+  auto nd = [&](float d) {
+    if constexpr (OUT == OUT_XREC) {
+      if (depth_mode == 1) d = d / depth_zr;
+      else if (depth_mode == 2) d = fminf(fmaxf(d / depth_zr, 0.f), 2.f) - 1.f;
+      else if (depth_mode == 3) d = fminf(fmaxf(d - depth_zr, -2.f), 2.f);
+    }
+    return d;
+  };
   // block-visit coverage: the lane's sample position in each block (relative to the tile) and whether its pixel is inside the image
   uint32_t rel[NB];
   unsigned ok_mask = 0;
@@ -588,6 +606,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
         if (c_rgb >= 0) { put(c_rgb + (int)cv, 0.f); put(c_rgb + (int)cv + 1, 0.f); put(c_rgb + (int)cv + 2, 0.f); }
         if (do_norm) { put(c_normals + (int)cv, 0.f); put(c_normals + (int)cv + 1, 0.f); put(c_normals + (int)cv + 2, 0.f); }
         if (do_depth) put(c_depth + (int)cv, 0.f);
+      } else {
+        if (do_depth) put(c_depth + (int)cv, nd(0.f));   // background depth 0 is normalised like any other value (e.g. to -1)
       }
       PROF(0)
       continue;
@@ -742,14 +762,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int c = 0; c < 3; ++c) put(c_normals + (int)cv + c, OUT == OUT_XREC ? rc::resolve_k(acc[3 + c], NS) : rc::resolve_channel(acc[3 + c], NS, false));
     }
-    if (do_depth) put(c_depth + (int)cv, st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f);
+    if (do_depth) put(c_depth + (int)cv, nd(st[0].id >= 0 ? 1.0f / st[0].wsum : 0.f));
     wave_lds_fence();  // the z-buffer / task arrays are reused by the next view
     PROF(6)
   }
   if (crop.images && px < w && py < h) {  // crop role: roi_align of the item's observation for this lane's pixel
     const float4 cv4 = crop_lane(crop, item, h, w, px, py);
     put(crop.c0, cv4.x); put(crop.c0 + 1, cv4.y); put(crop.c0 + 2, cv4.z);
-    if (crop.C == 4) put(crop.c0 + 3, cv4.w);
+    if (crop.C == 4) put(crop.c0 + 3, nd(cv4.w));   // (the observation's depth channel: normalised like the rendered ones)
   }
   wave_lds_fence();
   PROF(7)
@@ -929,7 +949,8 @@ extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views, i
 static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
                               int n_views, int h, int w, uint32_t flags, const mp_lights* lights, float* d_out,
                               int64_t stride_v, int views_per_item, int64_t stride_view, int64_t stride_y, int64_t stride_x,
-                              int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream, const CropArgs& crop) {
+                              int c_rgb, int c_normals, int c_depth, void* d_ws, size_t ws_bytes, mp_stream stream, const CropArgs& crop,
+                              uint32_t f32_mask = 0u, const float* d_tcr = nullptr, int depth_mode = 0) {
   MP_REQUIRE(db && d_mesh_ids && d_TCO && d_K && d_out && lights, "mp_raster_render: null pointer");
   MP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= 1024 && h <= 1024 && views_per_item >= 1 && views_per_item <= 64,
              "mp_raster_render: bad size (h, w <= 1024; 1 <= views_per_item <= 64)");
@@ -989,12 +1010,21 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   // (+ the fused crop role: C output channels written + at most the same-sized source window read per item)
   const bool f16 = (flags & MP_RASTER_F16) != 0, xrec = (flags & MP_RASTER_XREC) != 0;
   if (xrec) {   // stem records: ONE launch writes the whole record of every pixel
-    MP_REQUIRE(!f16 && !do_depth && crop.images && crop.c0 == 0 && c_lo == 0 && mask == (run >= 32 ? 0xFFFFFFFFu : (1u << run) - 1u),
-               "mp_raster_render: MP_RASTER_XREC needs the fused crop at channel 0, no depth channel, and every channel of the record written "
-               "by this launch");
-    MP_REQUIRE(stride_x == mp_xrec_elements(crop.C, run - crop.C) && stride_x <= 40,
-               "mp_raster_render: MP_RASTER_XREC: stride_x (%lld) must be the record length mp_xrec_elements(%d, %d)", (long long)stride_x, crop.C,
-               run - crop.C);
+    MP_REQUIRE(!f16 && crop.images && crop.c0 == 0 && c_lo == 0 && mask == (run >= 32 ? 0xFFFFFFFFu : (1u << run) - 1u),
+               "mp_raster_render: MP_RASTER_XREC needs the fused crop at channel 0 and every channel of the record written by this launch");
+    if (f32_mask == 0u) f32_mask = (1u << crop.C) - 1u;   // mp_raster_render_crop: the crop's channels are the fp32-kind ones
+    // which channels are fp32-kind is the caller's statement; it must agree with what this launch writes where
+    uint32_t want = (1u << crop.C) - 1u;
+    for (int r = 0; r < views_per_item; ++r)
+      if (do_depth) want |= 1u << (c_depth + r * (int)stride_view);
+    MP_REQUIRE(f32_mask == want, "mp_raster_render: MP_RASTER_XREC: fp32-kind channel mask 0x%x, but this launch writes the crop + depth channels 0x%x "
+               "(rgb / normal channels are 8-bit integers, crop and depth channels fp32)", f32_mask, want);
+    MP_REQUIRE(!do_depth || depth_mode == 0 || d_tcr, "mp_raster_render_xrec: depth normalisation needs d_tCR");
+    MP_REQUIRE(depth_mode >= 0 && depth_mode <= 3, "mp_raster_render_xrec: unknown depth mode %d", depth_mode);
+    const int n_f32 = __builtin_popcount(f32_mask);
+    MP_REQUIRE(stride_x == mp_xrec_elements(n_f32, run - n_f32) && stride_x <= 48,
+               "mp_raster_render: MP_RASTER_XREC: stride_x (%lld) must be the record length mp_xrec_elements(%d, %d) <= 48", (long long)stride_x, n_f32,
+               run - n_f32);
   }
   // LDS staging per pixel, in floats: the channel run -- or, for stem records, the record itself if that is longer (a 6-channel model, 3 crop
   // + 3 render channels, has a 16-element = 32-byte record but a run of only 6 floats: the record's zero padding is part of what is staged)
@@ -1010,7 +1040,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
 #define MP_LAUNCH_TILES(NSV, OUTV, FULLV)                                                                                              \
   hipLaunchKernelGGL((raster_tiles<NSV, OUTV, FULLV>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,    \
                      d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,  \
-                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop)
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop,       \
+                     f32_mask, d_tcr, depth_mode)
   const int sel = (ns == 4 ? 8 : 0) | (xrec ? 4 : f16 ? 2 : 0) | (full ? 1 : 0);
   switch (sel) {
     case 0: MP_LAUNCH_TILES(1, OUT_F32, false); break;
@@ -1066,4 +1097,20 @@ extern "C" int mp_raster_render_crop(const mp_mesh_db* db, const int32_t* d_mesh
   crop.C = C; crop.H = H; crop.W = W; crop.c0 = c0_crop; crop.nhwc4 = images_nhwc4 ? 1 : 0;
   return raster_render_impl(db, d_mesh_ids, d_TCO, d_K, n_views, h, w, flags, lights, d_out, stride_v, views_per_item, stride_view, stride_y,
                             stride_x, c_rgb, c_normals, c_depth, d_ws, ws_bytes, stream, crop);
+}
+
+extern "C" int mp_raster_render_xrec(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K, int n_views, int h,
+                                     int w, uint32_t flags, const mp_lights* lights, void* d_out_records, int64_t stride_v, int views_per_item,
+                                     int64_t stride_view, int64_t stride_y, int64_t stride_x, int c_rgb, int c_normals, int c_depth, void* d_ws,
+                                     size_t ws_bytes, const float* d_images, int images_nhwc4, int n_im, int C, int H, int W,
+                                     const int32_t* d_im_ids, const float* d_boxes, uint32_t f32_mask, const float* d_tCR, int depth_mode,
+                                     mp_stream stream) {
+  MP_REQUIRE(d_images && d_im_ids && d_boxes && n_im > 0 && (C == 3 || C == 4) && H > 0 && W > 0, "mp_raster_render_xrec: bad crop arguments");
+  MP_REQUIRE(f32_mask != 0u, "mp_raster_render_xrec: empty fp32-kind channel mask");
+  CropArgs crop;
+  crop.images = d_images; crop.im_ids = d_im_ids; crop.boxes = d_boxes;
+  crop.C = C; crop.H = H; crop.W = W; crop.c0 = 0; crop.nhwc4 = images_nhwc4 ? 1 : 0;
+  return raster_render_impl(db, d_mesh_ids, d_TCO, d_K, n_views, h, w, (flags | MP_RASTER_XREC) & ~MP_RASTER_F16, lights, (float*)d_out_records,
+                            stride_v, views_per_item, stride_view, stride_y, stride_x, c_rgb, c_normals, c_depth, d_ws, ws_bytes, stream, crop,
+                            f32_mask, d_tCR, depth_mode);
 }

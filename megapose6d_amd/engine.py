@@ -196,11 +196,12 @@ class PackedObservation:
 def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, h: int, w: int, flags: int,
                   lights: Lights, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int, c_normals: int,
                   c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0, slot: int = 0,
-                  crop=None) -> None:
+                  crop=None, xrec=None) -> None:
     """Render n views into `out` (float32 or float16 device tensor) at the given ELEMENT strides / offset; a float16 `out`
     selects MP_RASTER_F16 (values rounded to nearest-even binary16 as they are stored -- the "fp16 renders" mode).
     crop = (images [n_im,C,H,W], im_ids [n_items], boxes [n_items,4], c0): also roi_align-crop every item's observation into channels
-    c0.. of its pixels in the same launch (mp_raster_render_crop)."""
+    c0.. of its pixels in the same launch (mp_raster_render_crop).  xrec = (f32_mask, tCR, depth_mode) with a bfloat16 `out`: stem records
+    of a model WITH depth channels, depth normalised in the launch (mp_raster_render_xrec)."""
     lib = _lib.load()
     n = int(TCO.shape[0])
     mesh_ids = _dev_i32(mesh_ids)
@@ -222,6 +223,16 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
             n_im, Cc, H, W = images.shape
         im_ids, boxes = _dev_i32(im_ids), _dev_f32(boxes)
         assert boxes.shape[0] * views_per_item == n and im_ids.shape[0] == boxes.shape[0]
+        if xrec is not None:   # records with depth channels: (f32_mask, tCR [n_items, 3], depth mode) -> mp_raster_render_xrec
+            assert out.dtype == torch.bfloat16 and c0 == 0
+            f32_mask, tCR, depth_mode = xrec
+            tCR = _dev_f32(tCR) if tCR is not None else None
+            check(lib.mp_raster_render_xrec(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags & ~RASTER_XREC,
+                                            C.byref(lights), out.data_ptr() + es * out_offset_floats, stride_v, views_per_item, stride_view,
+                                            stride_y, stride_x, c_rgb, c_normals, c_depth, ws.data_ptr(), ws.numel(), images.data_ptr(), nhwc4,
+                                            n_im, Cc, H, W, im_ids.data_ptr(), boxes.data_ptr(), int(f32_mask) & 0xFFFFFFFF, _ptr(tCR),
+                                            int(depth_mode), _stream()))
+            return
         check(lib.mp_raster_render_crop(db.handle, mesh_ids.data_ptr(), TCO.data_ptr(), K.data_ptr(), n, h, w, flags, C.byref(lights),
                                         out.data_ptr() + es * out_offset_floats, stride_v, views_per_item, stride_view, stride_y, stride_x,
                                         c_rgb, c_normals, c_depth, ws.data_ptr(), ws.numel(), images.data_ptr(), nhwc4, n_im, Cc, H, W,
@@ -358,16 +369,24 @@ def conv_wino_bf16_clock(reset: bool = True) -> Tuple[float, float]:
     return a.value, b.value
 
 
-def conv_stem_pack_weights(w_oihw: np.ndarray, n_f32: int, scale: Optional[np.ndarray] = None) -> np.ndarray:
+def leading_mask(n_f32: int) -> int:
+    """fp32-kind channel mask of a record whose first `n_f32` channels are the fp32-kind ones"""
+    return (1 << int(n_f32)) - 1
+
+
+def conv_stem_pack_weights(w_oihw: np.ndarray, n_f32: int, scale: Optional[np.ndarray] = None, f32_mask: Optional[int] = None) -> np.ndarray:
     """three exact bf16 pieces of every stem weight (BN scale and, for the integer channels, 1/255 folded in) in MFMA fragment order
-    (mp_conv_stem_pack_weights); the first `n_f32` input channels are fp32-kind, the others 8-bit integers.  Returns a uint8 blob."""
+    (mp_conv_stem_pack_weights[_mask]); the first `n_f32` input channels -- or, with `f32_mask`, the channels whose bit is set -- are
+    fp32-kind, the others 8-bit integers.  Returns a uint8 blob."""
     lib = _lib.load()
     w = np.ascontiguousarray(w_oihw, dtype=np.float32)
     Cout, Cin, KH, KW = w.shape
     assert KH == KW
-    out = np.empty(lib.mp_conv_stem_packed_bytes(KH, n_f32, Cin - n_f32, Cout), dtype=np.uint8)
+    mask = leading_mask(n_f32) if f32_mask is None else int(f32_mask)
+    nf = bin(mask).count("1")
+    out = np.empty(lib.mp_conv_stem_packed_bytes(KH, nf, Cin - nf, Cout), dtype=np.uint8)
     sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
-    check(lib.mp_conv_stem_pack_weights(w.ctypes.data, Cout, Cin, KH, n_f32, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    check(lib.mp_conv_stem_pack_weights_mask(w.ctypes.data, Cout, Cin, KH, mask, None if sc is None else sc.ctypes.data, out.ctypes.data))
     return out
 
 
@@ -448,6 +467,7 @@ class Backbone:
         self.c_in_p = lib.mp_backbone_input_channels_padded(h)
         self.in_border = lib.mp_backbone_input_border(h)
         self._ws: Dict[int, torch.Tensor] = {}
+        self._xrec_len: Dict[int, int] = {}   # fp32-kind channel mask -> record length of the prepared stem blob (0: no exact-piece form)
 
     def workspace(self, batch: int, h: int, w: int, device, slot: int = 0) -> torch.Tensor:
         need = _lib.load().mp_backbone_workspace_bytes(self.handle, batch, h, w)
@@ -462,21 +482,32 @@ class Backbone:
     def flops(self, batch: int, h: int, w: int) -> float:
         return _lib.load().mp_backbone_flops(self.handle, batch, h, w)
 
-    def xrec_elements(self, n_f32: int) -> int:
-        """Record length (bf16 elements per pixel) of the exact-piece stem input for `n_f32` leading fp32-kind channels (the observation
-        crop), all other input channels being 8-bit integers (renders); 0 = this stem has no such form (mp_backbone_xrec_elements)."""
-        return int(_lib.load().mp_backbone_xrec_elements(self.handle, int(n_f32)))
+    def xrec_elements(self, n_f32: int = 3, f32_mask: Optional[int] = None) -> int:
+        """Record length (bf16 elements per pixel) of the exact-piece stem input whose fp32-kind channels are the first `n_f32` (the
+        observation crop) or the set bits of `f32_mask` (crop + depth channels of an RGBD model), all other input channels being 8-bit
+        integers (renders); 0 = this stem has no such form.  This is also the PREPARE step (mp_backbone_xrec_prepare): the first call for
+        a mask packs and uploads the stem's piece blob -- host work and a synchronous copy, so call it outside stream capture; `forward`
+        only looks the blob up."""
+        mask = leading_mask(n_f32) if f32_mask is None else int(f32_mask)
+        if mask >> 32 or (self.c_in < 32 and mask >> self.c_in):
+            return 0
+        hit = self._xrec_len.get(mask)
+        if hit is None:
+            hit = self._xrec_len[mask] = int(_lib.load().mp_backbone_xrec_prepare(self.handle, mask))
+        return hit
 
     def forward(self, x: torch.Tensor, batch: int, h: int, w: int, out: torch.Tensor, sigmoid: Optional[torch.Tensor] = None,
-                feat: Optional[torch.Tensor] = None, slot: int = 0, n_f32: int = 3) -> None:
-        """x: fp32 padded NHWC | float16 (same geometry, mp_backbone_forward_f16) | bfloat16 stem records with `n_f32` fp32-kind
-        channels (what the rasteriser writes with MP_RASTER_XREC; mp_backbone_forward_xrec)."""
+                feat: Optional[torch.Tensor] = None, slot: int = 0, n_f32: int = 3, f32_mask: Optional[int] = None) -> None:
+        """x: fp32 padded NHWC | float16 (same geometry, mp_backbone_forward_f16) | bfloat16 stem records whose fp32-kind channels are
+        the first `n_f32` / the bits of `f32_mask` (what the rasteriser writes with MP_RASTER_XREC; mp_backbone_forward_xrec_mask)."""
         ws = self.workspace(batch, h, w, x.device, slot)
         assert x.dtype in (torch.float32, torch.float16, torch.bfloat16)
         lib = _lib.load()
         if x.dtype == torch.bfloat16:
-            check(lib.mp_backbone_forward_xrec(self.handle, x.data_ptr(), int(n_f32), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat),
-                                               ws.data_ptr(), ws.numel(), _stream()))
+            mask = leading_mask(n_f32) if f32_mask is None else int(f32_mask)
+            self.xrec_elements(f32_mask=mask)   # (prepared on first use; the C forward never allocates)
+            check(lib.mp_backbone_forward_xrec_mask(self.handle, x.data_ptr(), mask & 0xFFFFFFFF, batch, h, w, out.data_ptr(), _ptr(sigmoid),
+                                                    _ptr(feat), ws.data_ptr(), ws.numel(), _stream()))
             return
         fn = lib.mp_backbone_forward_f16 if x.dtype == torch.float16 else lib.mp_backbone_forward
         check(fn(self.handle, x.data_ptr(), batch, h, w, out.data_ptr(), _ptr(sigmoid), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()))

@@ -225,8 +225,9 @@ class PosePredictor(nn.Module):
         # Stem records (default ON where they apply: RGB models, <= 32 input channels): the rasteriser launch stores every pixel of the
         # CNN input as a bf16 RECORD -- the 8-bit integer k of each render channel (the reference's renders ARE k / 255,
         # panda3d_batch_renderer.py:261-274) and three exact bf16 pieces of each fp32 crop channel -- and the stem convolution runs on
-        # the bf16 MFMA with the weights split into three exact pieces (csrc/conv_stem.hip): every product is exact, the sum is fp32,
-        # only the order of the fp32 additions differs from the fp32-MFMA stem.  MP_STEM_RECORDS=0 / stem_records=False: fp32 tensor.
+        # the bf16 MFMA with the weights split into three exact pieces (csrc/conv_stem.hip): every product is exact, the sum is fp32;
+        # against the fp32-MFMA stem the order of the fp32 additions differs, and the 1/255 of the integer channels is folded into their
+        # weights (one rounding per weight instead of one per pixel value).  MP_STEM_RECORDS=0 / stem_records=False: fp32 tensor.
         self.stem_records: bool = os.environ.get("MP_STEM_RECORDS", "1") != "0"
         self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
         self._x_rows: Dict[int, int] = {}
@@ -272,12 +273,24 @@ class PosePredictor(nn.Module):
             self._engine_bb = eng.Backbone(self.backbone.backbone_str, self.backbone.n_inputs, head, n_out, self.state_dict())
         return self._engine_bb
 
+    def _f32_mask(self) -> int:
+        """bit c set = logical input channel c is fp32-kind in a stem record (three exact bf16 pieces): the observation crop's channels
+        and, for depth models, the rendered depth of every view (pose_rigid.py:395-408 channel layout); rgb / normals are 8-bit integers"""
+        nin, nper = self._n_input_channels, self._n_single_render_channels
+        mask = (1 << nin) - 1
+        if self.render_depth:
+            d0 = nin + (6 if self.render_normals else 3)
+            for v in range(self.n_rendered_views):
+                mask |= 1 << (d0 + nper * v)
+        return mask
+
     def _record_len(self) -> int:
-        """bf16 elements per pixel if this model's CNN input is staged as stem records (see `stem_records`), else 0."""
-        if (not self.stem_records or self.render_dtype != torch.float32 or self.input_depth or self.render_depth
+        """bf16 elements per pixel if this model's CNN input is staged as stem records (see `stem_records`), else 0.  Depth models too
+        since round 5 (the RGBD refiner's 32 channels = a 48-element record; the launch normalises the depth channels before the split)."""
+        if (not self.stem_records or self.render_dtype != torch.float32
                 or self.backbone.n_inputs > 32):   # (one rasteriser launch must write the whole record: <= 32 channels)
             return 0
-        return self._backbone_engine().xrec_elements(self._n_input_channels)
+        return self._backbone_engine().xrec_elements(f32_mask=self._f32_mask())
 
     def _x_layout(self) -> Tuple[torch.dtype, int]:
         """(element type, elements per pixel) of the CNN input tensor"""
@@ -328,12 +341,18 @@ class PosePredictor(nn.Module):
         Cp = self._x_cp[slot]
         v = eng.padded_view(x, self._x_rows[slot], h, w, Cp, bb.in_border)[:rows]
         if x.dtype == torch.bfloat16:   # stem records -> the fp32 channels they stand for: x1 + x2 + x3 (exact), k / 255
-            nf = self._n_input_channels
+            mask, n_in = self._f32_mask(), self.backbone.n_inputs
+            f_ch = [c for c in range(n_in) if (mask >> c) & 1]
+            u_ch = [c for c in range(n_in) if not (mask >> c) & 1]
+            nf = len(f_ch)
             pieces = v[..., : 3 * nf].float().reshape(rows, h, w, nf, 3)
-            crop = (pieces[..., 0] + pieces[..., 1]) + pieces[..., 2]
+            f32 = (pieces[..., 0] + pieces[..., 1]) + pieces[..., 2]
             # (a tensor divisor: torch's GPU division by a Python scalar multiplies by the reciprocal, which is not k / 255 rounded once)
-            rend = v[..., 3 * nf : 3 * nf + (self.backbone.n_inputs - nf)].float() / torch.full((), 255.0, device=x.device)
-            return torch.cat([crop, rend], dim=-1)[..., c0:c1].permute(0, 3, 1, 2)
+            u8 = v[..., 3 * nf : 3 * nf + len(u_ch)].float() / torch.full((), 255.0, device=x.device)
+            full = torch.empty(rows, h, w, n_in, dtype=torch.float32, device=x.device)
+            full[..., f_ch] = f32
+            full[..., u_ch] = u8
+            return full[..., c0:c1].permute(0, 3, 1, 2)
         v = v[:, :, :, c0:c1].permute(0, 3, 1, 2)
         return v if v.dtype == torch.float32 else v.float()   # (fp16 renders mode: callers always see fp32 crops / renders)
 
@@ -381,6 +400,8 @@ class PosePredictor(nn.Module):
         # one launch writes at most 32 channels per pixel: the released recipes (<= 4 views) need one; longer view lists
         # (sphere_26views) go in groups of views, the observation crop rides with the first
         vg = max(1, (32 - nin) // nper)
+        records = x.dtype == torch.bfloat16
+        mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
         for v0 in range(0, V, vg):
             v1 = min(V, v0 + vg)
             nv = v1 - v0
@@ -389,15 +410,17 @@ class PosePredictor(nn.Module):
             Kg = KV_crop.view(b * V, 3, 3) if whole else KV_crop[:, v0:v1].reshape(b * nv, 3, 3)
             view_ids = ren_ids.repeat_interleave(nv) if nv > 1 else ren_ids
             c0 = nin + nper * v0
+            # stem records of a model with depth channels: the launch normalises them before the exact split (mp_raster_render_xrec)
+            xrec = (self._f32_mask(), tCR, mode) if (records and (self.input_depth or self.render_depth)) else None
             self.renderer.render_into(view_ids, Tg, Kg, self._lights(), (h, w), x, s_row, s_y, s_x, c0,
                                       c0 + 3 if self.render_normals else -1,
                                       c0 + (6 if self.render_normals else 3) if self.render_depth else -1, off,
                                       views_per_item=nv, stride_view=nper, slot=slot,
-                                      crop=((self._packed(images) if packed is None else packed), im_ids, boxes_crop, 0) if v0 == 0 else None)
+                                      crop=((self._packed(images) if packed is None else packed), im_ids, boxes_crop, 0) if v0 == 0 else None,
+                                      xrec=xrec)
         render_time = time.time() - t0
         if ev is not None:
             ev[1].record()
-        mode = eng.DEPTH_NORM_MODES[self.depth_normalization_type]
         bb = self._backbone_engine()
         depth_ch = []
         if self.input_depth:
@@ -405,12 +428,12 @@ class PosePredictor(nn.Module):
         if self.render_depth:
             d0 = nin + (6 if self.render_normals else 3)
             depth_ch += [d0 + nper * v for v in range(V)]
-        if depth_ch and mode:   # (depth models never stage records: _record_len)
+        if depth_ch and mode and not records:   # (records: normalised inside the rasteriser launch)
             eng.normalize_depth(x, b, h, w, bb.in_border, bb.c_in_p, depth_ch, tCR, mode)
         n_out = bb.n_out
         out = torch.empty(b, n_out, dtype=torch.float32, device=device)
         sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
-        bb.forward(x, b, h, w, out, sig, slot=slot, n_f32=nin)
+        bb.forward(x, b, h, w, out, sig, slot=slot, f32_mask=self._f32_mask())
         if ev is not None:
             ev[2].record()
         return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, K_crop=K_main, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,

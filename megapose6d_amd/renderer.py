@@ -100,7 +100,7 @@ class Panda3dBatchRenderer:
     def render_into(self, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor, lights: Sequence[Panda3dLightData],
                     resolution: Resolution, out: torch.Tensor, stride_v: int, stride_y: int, stride_x: int, c_rgb: int,
                     c_normals: int, c_depth: int, out_offset_floats: int = 0, views_per_item: int = 1, stride_view: int = 0,
-                    slot: int = 0, crop=None, msaa: Optional[int] = None) -> None:
+                    slot: int = 0, crop=None, msaa: Optional[int] = None, xrec=None) -> None:
         db = self._ensure_db()
         flags = (eng.RASTER_NORMALS if c_normals >= 0 else 0) | (eng.RASTER_DEPTH if c_depth >= 0 else 0)
         if self._gl_eye:
@@ -109,7 +109,7 @@ class Panda3dBatchRenderer:
             flags |= eng.RASTER_MSAA4
         h, w = resolution
         eng.raster_render(db, mesh_ids, TCO, K, h, w, flags, _to_engine_lights(lights), out, stride_v, stride_y, stride_x, c_rgb,
-                          c_normals, c_depth, out_offset_floats, views_per_item, stride_view, slot, crop)
+                          c_normals, c_depth, out_offset_floats, views_per_item, stride_view, slot, crop, xrec)
 
     # -- reference API -----------------------------------------------------------------------------------
     def render(self, labels: List[str], TCO: torch.Tensor, K: torch.Tensor, light_datas: List[List[Panda3dLightData]],

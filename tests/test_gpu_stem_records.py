@@ -36,21 +36,29 @@ def split3(v: torch.Tensor):
     return h, m, lo
 
 
-def to_records(eng, x_nchw: torch.Tensor, n_f32: int, border: int) -> torch.Tensor:
-    """fp32 [n, c, h, w] whose channels >= n_f32 are k / 255 -> bf16 record tensor (padded NHWC)"""
+def to_records(eng, x_nchw: torch.Tensor, n_f32: int, border: int, f32_mask=None) -> torch.Tensor:
+    """fp32 [n, c, h, w] -> bf16 record tensor (padded NHWC).  The fp32-kind channels (three exact pieces each) are the first `n_f32`
+    or, with `f32_mask`, the channels whose bit is set; every other channel must hold k / 255 and is stored as the integer k."""
     n, c, h, w = x_nchw.shape
-    R = eng.xrec_elements(n_f32, c - n_f32)
+    mask = (1 << n_f32) - 1 if f32_mask is None else f32_mask
+    f_ch = [ch for ch in range(c) if (mask >> ch) & 1]
+    u_ch = [ch for ch in range(c) if not (mask >> ch) & 1]
+    nf = len(f_ch)
+    R = eng.xrec_elements(nf, c - nf)
     buf = eng.padded_nhwc(n, h, w, R, border, "cuda", dtype=torch.bfloat16)
     v = eng.padded_view(buf, n, h, w, R, border)
     xl = x_nchw.permute(0, 2, 3, 1).cpu()
-    k = torch.round(xl[..., n_f32:] * 255.0)
-    assert torch.equal(k / 255.0, xl[..., n_f32:])   # (on the CPU: torch's GPU division by a scalar multiplies by the reciprocal)
+    k = torch.round(xl[..., u_ch] * 255.0)
+    assert torch.equal(k / 255.0, xl[..., u_ch])   # (on the CPU: torch's GPU division by a scalar multiplies by the reciprocal)
     xl, k = xl.cuda(), k.cuda()
-    pieces = torch.stack(split3(xl[..., :n_f32].contiguous()), dim=-1).reshape(n, h, w, 3 * n_f32)
-    v[..., : 3 * n_f32] = pieces.to(torch.bfloat16)
-    v[..., 3 * n_f32 : 3 * n_f32 + (c - n_f32)] = k.to(torch.bfloat16)
-    assert torch.equal(v[..., : 3 * n_f32].float(), pieces)   # the pieces really are bf16 values
+    pieces = torch.stack(split3(xl[..., f_ch].contiguous()), dim=-1).reshape(n, h, w, 3 * nf)
+    v[..., : 3 * nf] = pieces.to(torch.bfloat16)
+    v[..., 3 * nf : 3 * nf + len(u_ch)] = k.to(torch.bfloat16)
+    assert torch.equal(v[..., : 3 * nf].float(), pieces)   # the pieces really are bf16 values
     return buf
+
+
+RGBD_MASK = 0x8102040F   # 32-channel RGBD refiner: crop rgb + depth (0..3), rendered depth of the four views (10, 17, 24, 31)
 
 
 STEM_CASES = [
@@ -61,6 +69,10 @@ STEM_CASES = [
     (1, 3, 12, 24, 40, 7, 64),     # 2 views: record of 24
     (2, 3, 18, 18, 34, 5, 64),     # 3 views: record of 32
     (1, 4, 21, 17, 33, 7, 64),     # four fp32 channels (an RGBD-style crop without depth renders): record of 40
+    (2, 8, 24, 19, 37, 7, 64),     # 48-element record (the RGBD refiner's size), 7x7: the patch only fits unpadded (2-way LDS conflicts)
+    (1, 8, 24, 26, 22, 5, 128),    # 48-element record, WideResNet 5x5 stem: padded pixel pitch
+    (2, 3, 15, 20, 30, 7, 64),     # record of 24 -> Q = 3 (odd: no padding)
+    (1, 3, 21, 16, 34, 5, 64),     # record of 32 -> Q = 4 (padded pitch 5)
 ]
 
 
@@ -91,6 +103,34 @@ def test_stem_conv_on_records_matches_torch_fp32(eng, case, relu):
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
     full = yb[: N * (Ho + 2) * (Wo + 2) * Cout].view(N, Ho + 2, Wo + 2, Cout)
     assert full[:, 0].abs().max() == 0 and full[:, -1].abs().max() == 0 and full[:, :, 0].abs().max() == 0 and full[:, :, -1].abs().max() == 0
+
+
+@pytest.mark.parametrize("K", [7, 5])
+def test_stem_conv_on_rgbd_records_with_scattered_fp32_channels(eng, K):
+    """The RGBD refiner's input (training/pose_models_cfg.py:101-103: 32 channels = crop rgb + depth, 4 x (rgb, normals, depth)): the
+    fp32-kind channels -- the crop and every depth channel, signed after tCR_scale_clamp_center -- are not the leading ones
+    (mp_conv_stem_pack_weights_mask, mask 0x8102040F); 48-element records; vs torch's convolution in float64."""
+    N, C, H, W, Cout = 2, 32, 30, 44, 64
+    g = torch.Generator().manual_seed(40 + K)
+    x = torch.randint(0, 256, (N, C, H, W), generator=g).float() / 255.0
+    f_ch = [c for c in range(C) if (RGBD_MASK >> c) & 1]
+    assert f_ch == [0, 1, 2, 3, 10, 17, 24, 31]
+    x[:, f_ch] = torch.rand(N, len(f_ch), H, W, generator=g) * 2.0 - 1.0
+    x[:, [c for c in range(C) if c not in f_ch], : H // 4] = 0.0
+    w = torch.randn(Cout, C, K, K, generator=g) * (2.0 / (C * K * K)) ** 0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    pad = K // 2
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    rec = to_records(eng, x, 0, pad, f32_mask=RGBD_MASK)
+    assert eng.xrec_elements(8, 24) == 48
+    wp = torch.from_numpy(eng.conv_stem_pack_weights(w.numpy(), 0, scale.numpy(), f32_mask=RGBD_MASK)).cuda()
+    yb = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda")
+    eng.conv_stem_xrec(rec, N, H, W, C, 8, pad, wp, bias.cuda(), Cout, K, pad, yb, 1, relu=False)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride=2, padding=pad)
+    got = eng.padded_view(yb, N, Ho, Wo, Cout, 1).permute(0, 3, 1, 2).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
 
 
 @pytest.mark.parametrize("case", [STEM_CASES[1], STEM_CASES[0], (2, 3, 24, 34, 70, 7, 64), (1, 3, 24, 240, 320, 7, 64)])
@@ -157,25 +197,29 @@ def test_stem_map_of_a_batch_beyond_4_gb_is_addressed_per_image(eng):
     assert eng.padded_view(y2, 2, Ho, Wo, Cout, 1).abs().max() > 0
 
 
-@pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 27)])
+@pytest.mark.parametrize("kind,c_in", [("vanilla_resnet34", 9), ("vanilla_resnet34", 27), ("resnet34", 27), ("resnet34", 32), ("vanilla_resnet34", 32)])
 def test_backbone_forward_on_records_matches_the_fp32_tensor_path(eng, kind, c_in):
+    """c_in = 32: the RGBD refiner's channel layout (fp32-kind channels = RGBD_MASK: crop rgb + depth, one rendered depth per view)"""
     from tests.support import synthetic as syn
 
     sd = syn.make_state_dict(kind, c_in, "pose", 9, seed=4)
     bb = eng.Backbone(kind, c_in, "pose", 9, sd)
-    R = bb.xrec_elements(3)
-    assert R == eng.xrec_elements(3, c_in - 3) and R in (16, 40)
+    mask = RGBD_MASK if c_in == 32 else 0b111
+    f_ch = [c for c in range(c_in) if (mask >> c) & 1]
+    R = bb.xrec_elements(f32_mask=mask)
+    assert R == eng.xrec_elements(len(f_ch), c_in - len(f_ch)) and R in (16, 40, 48)
     b, h, w = 3, 240, 320
     g = torch.Generator().manual_seed(c_in)
-    x = torch.cat([torch.rand(b, 3, h, w, generator=g), torch.randint(0, 256, (b, c_in - 3, h, w), generator=g).float() / 255.0], dim=1)
+    x = torch.randint(0, 256, (b, c_in, h, w), generator=g).float() / 255.0
+    x[:, f_ch] = torch.rand(b, len(f_ch), h, w, generator=g) * (2.0 if c_in == 32 else 1.0) - (1.0 if c_in == 32 else 0.0)
     xb = eng.padded_nhwc(b, h, w, bb.c_in_p, bb.in_border, "cuda")
     eng.padded_view(xb, b, h, w, bb.c_in_p, bb.in_border)[..., :c_in] = x.permute(0, 2, 3, 1).cuda()
-    rec = to_records(eng, x, 3, bb.in_border)
+    rec = to_records(eng, x, 0, bb.in_border, f32_mask=mask)
     nf = 512
     out0, out1 = torch.empty(b, 9, device="cuda"), torch.empty(b, 9, device="cuda")
     f0, f1 = torch.empty(b, nf, device="cuda"), torch.empty(b, nf, device="cuda")
     bb.forward(xb, b, h, w, out0, None, f0)
-    bb.forward(rec, b, h, w, out1, None, f1, n_f32=3)
+    bb.forward(rec, b, h, w, out1, None, f1, f32_mask=mask)
     torch.cuda.synchronize()
     fs = max(1.0, f0.abs().max().item())
     assert (f0 - f1).abs().max().item() < 1e-5 * fs, ((f0 - f1).abs().max().item(), fs)
@@ -190,8 +234,9 @@ def test_rasteriser_record_output_holds_exactly_the_fp32_values(object_dataset):
     from megapose6d_amd.renderer import Panda3dBatchRenderer
     from tests.support import synthetic as syn
 
-    for role in ("refiner", "coarse", "coarse_no_normals"):
-        cfg = syn.make_cfg(role.split("_")[0])
+    for role in ("refiner", "coarse", "coarse_no_normals", "refiner_rgbd", "refiner_rgbd_wide"):
+        cfg = syn.make_cfg(role.split("_")[0], rgbd="rgbd" in role)
+        backbone = "resnet34" if role.endswith("wide") else "vanilla_resnet34"
         if role == "coarse_no_normals":
             # the 6-channel input of the legacy / *-no_normals configs (utils/load_model.py check_update_config_pose defaults: one view,
             # render_normals False): 3 crop + 3 lit render channels = a 16-element record for a 6-float channel run
@@ -199,7 +244,8 @@ def test_rasteriser_record_output_holds_exactly_the_fp32_values(object_dataset):
             assert syn.n_inputs_for(cfg) == 6
         role = role.split("_")[0]
         head, n_out = ("pose", 9) if role == "refiner" else ("logits", 1)
-        sd = syn.make_state_dict("vanilla_resnet34", syn.n_inputs_for(cfg), head, n_out, seed=5)
+        cfg.backbone_str = backbone
+        sd = syn.make_state_dict(backbone, syn.n_inputs_for(cfg), head, n_out, seed=5)
         renderer = Panda3dBatchRenderer(object_dataset, n_workers=1, preload_cache=True)
         model = build_pose_model(cfg, sd, renderer, MeshDataBase.from_object_ds(object_dataset).batched().cuda())
         rng = np.random.RandomState(3)
@@ -208,6 +254,11 @@ def test_rasteriser_record_output_holds_exactly_the_fp32_values(object_dataset):
         T0 = torch.from_numpy(np.stack([syn.random_pose(rng, (0.45, 0.6), 0.1) for _ in labels])).cuda()
         K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None], rows, 0)).float().cuda()
         images = (torch.round(torch.rand(rows, 3, 480, 640, generator=torch.Generator().manual_seed(1)) * 255) / 255).cuda()
+        if cfg.input_depth:   # observation depth (metres) around the objects' distance, 5 % invalid (0): the RGBD validity rule of the crop
+            gd = torch.Generator().manual_seed(2)
+            depth = 0.3 + 0.5 * torch.rand(rows, 1, 480, 640, generator=gd)
+            depth[torch.rand(rows, 1, 480, 640, generator=gd) < 0.05] = 0.0
+            images = torch.cat([images, depth.cuda()], dim=1)
         res = {}
         for records in (True, False):
             model.stem_records = records
@@ -221,14 +272,18 @@ def test_rasteriser_record_output_holds_exactly_the_fp32_values(object_dataset):
             assert (model._x[0].dtype == torch.bfloat16) == records
             n_in = syn.n_inputs_for(cfg)
             res[records] = (model._nchw_view(rows, 0, n_in).clone(), net.clone())
-        assert torch.equal(res[True][0], res[False][0])
+        assert torch.equal(res[True][0], res[False][0]), role
         assert res[False][0][:, 3:].abs().max() > 0.1   # the renders are not empty
+        if cfg.render_depth:   # normalised depth channels (tCR_scale_clamp_center): background = -1, object pixels around 0
+            d = res[True][0][:, 4 + 6]
+            assert d.min().item() == -1.0 and (d > -0.5).float().mean().item() > 0.01
         s = max(1.0, res[False][1].abs().max().item())
         assert (res[True][1] - res[False][1]).abs().max().item() < 1e-5 * s
 
 
 def test_record_mode_is_refused_where_it_does_not_apply(eng):
-    """depth models / records outside 16..40 elements keep the fp32 tensor; the C entry point refuses what it cannot do"""
+    """records outside 16..48 elements keep the fp32 tensor; the C entry point refuses what it cannot do (and never packs a blob inside a
+    forward: mp_backbone_xrec_prepare is the explicit step)"""
     from megapose6d_amd._lib import EngineError
     from tests.support import synthetic as syn
 
