@@ -562,9 +562,14 @@ def main():
                       for k, v in sorted(conv.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
         all_conv_tf = sum(v["flops"] for v in conv.values()) / (sum(v["ms"] for v in conv.values()) * 1e-3) / 1e12
         kernel_ms = {k: round(v["ms"] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-        rb = next((v for k, v in prof.items() if k.startswith("raster_")
-                   and v["ms"] == max(vv["ms"] for kk, vv in prof.items() if kk.startswith("raster_"))), None)
-        rb_name = next((k for k, v in prof.items() if v is rb), None)
+        # the rasteriser's tile pass = raster_classify + raster_tiles (the pairs some view reaches) + raster_tiles_light (the others): one
+        # row, the algorithmic bytes of the launch (attached to raster_tiles) over the summed time of the three kernels
+        rparts = {k: v for k, v in prof.items() if k.startswith(("raster_tiles", "raster_classify"))}
+        rb, rb_name = None, None
+        if rparts:
+            rb_name = max((k for k in rparts if not k.startswith(("raster_tiles_light", "raster_classify"))), key=lambda k: rparts[k]["ms"])
+            rb = {"ms": sum(v["ms"] for v in rparts.values()), "bytes": sum(v["bytes"] for k, v in rparts.items() if k.startswith("raster_tiles")),
+                  "launches": rparts[rb_name]["launches"], "parts_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in rparts.items()}}
         traffic, traffic_src, r_traffic = None, None, None
         tfile = next((f for f in (ROOT / "profiles" / "r04_traffic.json", ROOT / "profiles" / "r03_traffic.json") if f.is_file()), None)
         if tfile is not None:  # PMC cannot be sampled from inside the process: committed rocprofv3 --pmc summary of the same command
@@ -611,7 +616,8 @@ def main():
             "raster": None if rb is None else {"bound": "hbm", "kernel": rb_name, "achieved": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9,
                                                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": rb["bytes"] / (rb["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                                "traffic": r_traffic, "alg_bytes_per_launch": rb["bytes"] / rb["launches"],
-                                               "avg_launch_ms": rb["ms"] / rb["launches"], "ms_per_step": rb["ms"] / a.steps},
+                                               "avg_launch_ms": rb["ms"] / rb["launches"], "ms_per_step": rb["ms"] / a.steps,
+                                               "parts_ms_per_step": rb["parts_ms_per_step"]},
             "kernel_ms_per_step": kernel_ms,
             "stage_s": {"source": "HIP events, one extra call with cuda_timer=True (stages fenced)",
                         **{s: {"time": sd[s]["time"], "render_time": sd[s]["render_time"], "model_time": sd[s]["model_time"]} for s in sd},

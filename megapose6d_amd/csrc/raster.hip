@@ -111,7 +111,7 @@ __device__ __forceinline__ bool tile_touched(const TileTest& t, int tx, int ty) 
 
 __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
                                                           const float* __restrict__ TCO, const float* __restrict__ K, int h, int w, int ns,
-                                                          int* __restrict__ ws, BinLayout lay) {
+                                                          int* __restrict__ ws, BinLayout lay, int* __restrict__ counters) {
   extern __shared__ int counts[];  // [2][n_tiles]: counters of the binned / the large pieces, then (in place) exclusive offsets = fill cursors
   __shared__ int partial[2][BIN_THREADS];
   __shared__ unsigned nearest;     // max over the pieces of (bits of the nearest vertex's 1/z, low bit replaced by the piece's orientation flag)
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
   const float* Kv = K + (size_t)view * 9;
   for (int i = tid; i < 2 * lay.n_tiles; i += BIN_THREADS) counts[i] = 0;
   if (tid == 0) nearest = 0u;
+  if (view == 0 && tid < 4 && counters) counters[tid] = 0;   // counters of the light-job list (raster_classify runs after this kernel)
   __syncthreads();
   const bool finite = rc::view_finite(T, Kv);  // non-finite pose / intrinsics: empty lists -> zero image (panda3d_batch_renderer.py:109-135)
   const int F = finite ? m.n_faces : 0;
@@ -399,7 +400,11 @@ __device__ __noinline__ void sweep_piece(int X0, int Y0, int X1, int Y1, int X2,
 }
 
 // roi_align of one output pixel; one instance for the four (C, layout) cases (code size)
-__device__ __noinline__ float4 crop_lane(CropArgs crop, int item, int h, int w, int px, int py) {
+template <bool INLINE>
+__device__ __forceinline__ float4 crop_lane_body(const CropArgs& crop, int item, int h, int w, int px, int py);
+__device__ __noinline__ float4 crop_lane(CropArgs crop, int item, int h, int w, int px, int py) { return crop_lane_body<false>(crop, item, h, w, px, py); }
+template <bool INLINE>
+__device__ __forceinline__ float4 crop_lane_body(const CropArgs& crop, int item, int h, int w, int px, int py) {
   float cvals[4];   // (arguments and result by value = in registers: references would be built in scratch memory before the call)
   const float* bx = crop.boxes + (size_t)item * 4;
   const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
@@ -437,13 +442,16 @@ struct ViewHdr {   // what a wave needs to know about one view's lists for its t
 // record is staged in LDS in that form and leaves as 16-byte chunks.  Channel numbers (c_rgb, c_normals, stride_view, crop.c0) stay
 // logical channel numbers; stride_v / stride_y / stride_x count bf16 elements.
 constexpr int OUT_F32 = 0, OUT_F16 = 1, OUT_XREC = 2;
-template <int NS, int OUT = OUT_F32, bool FULL = true>
+// DEPTHREC (OUT_XREC only): the record's fp32-kind channels are a general mask and depth channels are normalised here (RGBD models); false =
+// the fp32-kind channels are the crop's leading ones, no depth channel (the RGB models: the round-4 form, free of the extra arithmetic --
+// this kernel sits exactly at its register budget)
+template <int NS, int OUT = OUT_F32, bool FULL = true, bool DEPTHREC = false>
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(MP_RASTER_WAVES, MP_RASTER_WAVES))) void raster_tiles(
     const MeshDev* __restrict__ meshes, const TexDev* __restrict__ texs, const int32_t* __restrict__ mesh_ids, const float* __restrict__ TCO,
     const float* __restrict__ K, const int* __restrict__ ws, BinLayout lay, int h, int w, uint32_t flags, LightsDev lights,
     float* __restrict__ out, long long stride_v, int views_per_item, int n_items, long long stride_view, long long stride_y,
     long long stride_x, int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask, CropArgs crop, uint32_t xrec_mask,
-    const float* __restrict__ depth_tcr, int depth_mode) {
+    const float* __restrict__ depth_tcr, int depth_mode, const unsigned char* __restrict__ job_flags) {
   // LDS per wave: zb [64 * NS] u64 (z-buffer, later the shading results) | tasks [64 * NS] u32 | stage [64][run] floats
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // (a readfirstlane'd wave index makes the LDS bases scalar -- and the kernel 4 % slower, measured)
@@ -461,12 +469,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   // launcher checks); `put` files a channel value into the lane's pixel in whichever form the launch stages
   // (OUT_XREC) logical channel c is fp32-kind (three record slots) iff bit c of xrec_mask is set -- the crop's channels and, for RGBD
   // models, every depth channel --; the fp32-kind channels come first in the record, in channel order, then the integer channels
-  const int xrec_nf = __builtin_popcount(xrec_mask);
+  const int xrec_nf = DEPTHREC ? __builtin_popcount(xrec_mask) : crop.C;
   unsigned short* my_rec = reinterpret_cast<unsigned short*>(stage) + (size_t)lane * (int)stride_x;
   auto put = [&](int ch, float v) {   // ch = logical channel number
     if constexpr (OUT == OUT_XREC) {
-      const int f_below = __builtin_popcount(xrec_mask & ((1u << ch) - 1u));   // fp32-kind channels in front of ch (ch < 32)
-      if ((xrec_mask >> ch) & 1u) {   // exact truncation split x = x1 + x2 + x3 (three bf16 pieces)
+      const int f_below = DEPTHREC ? __builtin_popcount(xrec_mask & ((1u << ch) - 1u)) : min(ch, xrec_nf);   // fp32-kind channels in front of ch (ch < 32)
+      if (DEPTHREC ? (bool)((xrec_mask >> ch) & 1u) : ch < xrec_nf) {   // exact truncation split x = x1 + x2 + x3 (three bf16 pieces)
         const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
         const float r1 = v - __uint_as_float(b1);
         const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -493,6 +501,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   if (tx >= lay.tiles_x) return;   // (no workgroup-level barrier below: waves are independent)
   const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
   const int tile = ty * lay.tiles_x + tx;
+  // Compacted launch form (round 5): raster_classify marked the (item, tile) pairs that no view reaches -- 65 % of a pose-pipeline launch --
+  // and raster_tiles_light writes those (background + crop).  A wave of such a pair leaves here, after one byte load, instead of waiting
+  // for four list headers and running the crop under this kernel's register budget.  Which kernel writes a tile does not enter the
+  // arithmetic: the pixels are the same bit for bit (test_raster_compacted_launch_equals_the_direct_form).
+  if (job_flags && job_flags[(size_t)item * lay.n_tiles + tile] == 0) return;
   const int px = tile_x0 + (lane & 7), py = tile_y0 + (lane >> 3);
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0;
   const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
@@ -501,11 +514,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   // (OUT_XREC) depth channels enter the record NORMALISED, with the operations of normalize_depth_kernel (crop.hip; reference
   // models/pose_rigid.py:466-496) in the same order, so that the three pieces add up to the fp32 tensor path's value bit for bit
   float depth_zr = 1.f;
-  if constexpr (OUT == OUT_XREC) {
+  if constexpr (OUT == OUT_XREC && DEPTHREC) {
     if (depth_mode != 0 && depth_tcr) depth_zr = depth_tcr[3 * (size_t)item + 2];
   }
   auto nd = [&](float d) {
-    if constexpr (OUT == OUT_XREC) {
+    if constexpr (OUT == OUT_XREC && DEPTHREC) {
       if (depth_mode == 1) d = d / depth_zr;
       else if (depth_mode == 2) d = fminf(fmaxf(d / depth_zr, 0.f), 2.f) - 1.f;
       else if (depth_mode == 3) d = fminf(fmaxf(d - depth_zr, -2.f), 2.f);
@@ -808,6 +821,139 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
   PROF_FLUSH
 }
 
+// ---- compacted launch form: classification of the (item, tile) pairs and the kernel for the pairs no view reaches --------------------------
+// one thread per pair: heavy iff some view of the item has a piece (binned or large) in the tile, or a view's lists overflowed;
+// flags[pair] = 1 | 0, the light pairs are appended to a list (order arbitrary: every job is independent)
+__global__ __launch_bounds__(256) void raster_classify(const int* __restrict__ ws, BinLayout lay, int views_per_item, int n_items,
+                                                       unsigned char* __restrict__ flags, int* __restrict__ counters, int* __restrict__ light_list) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)n_items * lay.n_tiles;
+  const bool valid = idx < total;
+  bool heavy = false;
+  if (valid) {
+    const int item = (int)(idx / lay.n_tiles), tile = (int)(idx - (long)item * lay.n_tiles);
+    for (int r = 0; r < views_per_item; ++r) {
+      const int* hdr = ws + (size_t)(item * views_per_item + r) * lay.view_ints;
+      heavy = heavy || hdr[2] != 0 || hdr[HDR_INTS + tile + 1] != hdr[HDR_INTS + tile] || hdr[lay.off_tl + tile + 1] != hdr[lay.off_tl + tile];
+    }
+    flags[idx] = heavy ? 1 : 0;
+  }
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ml = __ballot(valid && !heavy);
+  int base = 0;
+  if (lane == 0 && ml) base = atomicAdd(counters, __popcll(ml));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (valid && !heavy) light_list[base + __popcll(ml & ((1ull << lane) - 1ull))] = (int)idx;
+}
+
+// A light job: the tile of an item that no view reaches = background in every view channel + the observation crop, stored exactly as
+// raster_tiles stores a tile (same staging layout, same `put` forms).  One wave per job, strided over the list; no list headers, no mesh,
+// four waves per SIMD (the unrolled roi_align taps want 127 registers; the 80 of six waves spill): one more than raster_tiles, and no list headers to wait for.
+template <int OUT, bool DEPTHREC>
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_tiles_light(const int* __restrict__ counters, const int* __restrict__ light_list, BinLayout lay,
+                                                                     int h, int w, uint32_t flags, float* __restrict__ out, long long stride_v,
+                                                                     int views_per_item, long long stride_view, long long stride_y, long long stride_x,
+                                                                     int c_rgb, int c_normals, int c_depth, int c_lo, int run, uint32_t run_mask,
+                                                                     CropArgs crop, uint32_t xrec_mask, const float* __restrict__ depth_tcr, int depth_mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t per_wave = ((size_t)64 * run * sizeof(float) + 15) & ~(size_t)15;
+  float* stage = (float*)(lds_raw + (size_t)wave * per_wave);
+  float* my_stage = stage + (size_t)lane * run;
+  unsigned short* my_rec = reinterpret_cast<unsigned short*>(stage) + (size_t)lane * (int)stride_x;
+  const int xrec_nf = DEPTHREC ? __builtin_popcount(xrec_mask) : crop.C;
+  const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0;
+  const bool do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
+  auto put = [&](int ch, float v) {   // (raster_tiles' `put`, verbatim)
+    if constexpr (OUT == OUT_XREC) {
+      const int f_below = DEPTHREC ? __builtin_popcount(xrec_mask & ((1u << ch) - 1u)) : min(ch, xrec_nf);
+      if (DEPTHREC ? (bool)((xrec_mask >> ch) & 1u) : ch < xrec_nf) {
+        const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(b1);
+        const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(b2);
+        my_rec[3 * f_below] = (unsigned short)(b1 >> 16); my_rec[3 * f_below + 1] = (unsigned short)(b2 >> 16);
+        my_rec[3 * f_below + 2] = (unsigned short)(__float_as_uint(r2) >> 16);
+      } else {
+        my_rec[3 * xrec_nf + (ch - f_below)] = (unsigned short)(__float_as_uint(v) >> 16);
+      }
+    } else {
+      my_stage[ch - c_lo] = v;
+    }
+  };
+  const int n_jobs = counters[0];
+  const int stride = gridDim.x * TILE_WAVES;
+  for (int j = blockIdx.x * TILE_WAVES + wave; j < n_jobs; j += stride) {
+    const int idx = light_list[j];
+    const int item = idx / lay.n_tiles, tile = idx - item * lay.n_tiles;
+    const int tx = tile % lay.tiles_x, ty = tile / lay.tiles_x;
+    const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
+    const int px = tile_x0 + (lane & 7), py = tile_y0 + (lane >> 3);
+    float depth_zr = 1.f;
+    if constexpr (OUT == OUT_XREC && DEPTHREC) {
+      if (depth_mode != 0 && depth_tcr) depth_zr = depth_tcr[3 * (size_t)item + 2];
+    }
+    auto nd = [&](float d) {   // (raster_tiles' `nd`, verbatim)
+      if constexpr (OUT == OUT_XREC && DEPTHREC) {
+        if (depth_mode == 1) d = d / depth_zr;
+        else if (depth_mode == 2) d = fminf(fmaxf(d / depth_zr, 0.f), 2.f) - 1.f;
+        else if (depth_mode == 3) d = fminf(fmaxf(d - depth_zr, -2.f), 2.f);
+      }
+      return d;
+    };
+    if constexpr (OUT == OUT_XREC) {
+      uint4* z = reinterpret_cast<uint4*>(my_rec);
+      for (int q = 0; q < (int)stride_x / 8; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int r = 0; r < views_per_item; ++r) {
+      const int cv = (int)((long long)r * stride_view);
+      if constexpr (OUT != OUT_XREC) {
+        if (c_rgb >= 0) { put(c_rgb + cv, 0.f); put(c_rgb + cv + 1, 0.f); put(c_rgb + cv + 2, 0.f); }
+        if (do_norm) { put(c_normals + cv, 0.f); put(c_normals + cv + 1, 0.f); put(c_normals + cv + 2, 0.f); }
+        if (do_depth) put(c_depth + cv, 0.f);
+      } else {
+        if (do_depth) put(c_depth + cv, nd(0.f));
+      }
+    }
+    if (crop.images && px < w && py < h) {
+      const float4 cv4 = crop_lane_body<true>(crop, item, h, w, px, py);   // (inlined: the shared out-of-line copy would impose raster_tiles' register count)
+      put(crop.c0, cv4.x); put(crop.c0 + 1, cv4.y); put(crop.c0 + 2, cv4.z);
+      if (crop.C == 4) put(crop.c0 + 3, nd(cv4.w));
+    }
+    wave_lds_fence();
+    const int cols = min(TILE, w - tile_x0), rows = min(TILE, h - tile_y0);
+    const int per_row = cols * run;
+    if constexpr (OUT == OUT_XREC) {
+      const int rowlen = cols * ((int)stride_x / 8);
+      unsigned short* out_item = reinterpret_cast<unsigned short*>(out) + (size_t)item * stride_v;
+      const uint4* recs = reinterpret_cast<const uint4*>(stage);
+      if (lane < rowlen)
+        for (int row = 0; row < rows; ++row)
+          *reinterpret_cast<uint4*>(out_item + (size_t)(tile_y0 + row) * stride_y + (size_t)tile_x0 * stride_x + (size_t)lane * 8) =
+              recs[row * 8 * ((int)stride_x / 8) + lane];
+    } else if constexpr (OUT == OUT_F16) {
+      _Float16* out_item = reinterpret_cast<_Float16*>(out) + (size_t)item * stride_v + c_lo;
+      for (int i = lane; i < per_row; i += 64) {
+        const int x = i / run, c = i - x * run;
+        if (!((run_mask >> c) & 1u)) continue;
+        _Float16* o = out_item + (size_t)tile_y0 * stride_y + (size_t)(tile_x0 + x) * stride_x + c;
+        const float* sp = stage + (size_t)x * run + c;
+        for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = (_Float16)sp[(size_t)row * 8 * run];
+      }
+    } else {
+      float* out_item = out + (size_t)item * stride_v + c_lo;
+      for (int i = lane; i < per_row; i += 64) {
+        const int x = i / run, c = i - x * run;
+        if (!((run_mask >> c) & 1u)) continue;
+        float* o = out_item + (size_t)tile_y0 * stride_y + (size_t)(tile_x0 + x) * stride_x + c;
+        const float* sp = stage + (size_t)x * run + c;
+        for (int row = 0; row < rows; ++row) o[(size_t)row * stride_y] = sp[(size_t)row * 8 * run];
+      }
+    }
+    wave_lds_fence();   // the next job restages
+  }
+}
+
 }  // namespace mp
 
 using namespace mp;
@@ -941,9 +1087,14 @@ static BinLayout bin_layout(const mp_mesh_db* db, int h, int w) {
   return lay;
 }
 
+// behind the per-view blocks: [4 counters][light job list: one int per (view, tile)][job flags: one byte per (view, tile)] (items <= views)
+static size_t job_tail_offset_ints(const BinLayout& lay, int n_views) { return ((size_t)n_views * (size_t)lay.view_ints + 3) & ~(size_t)3; }
+
 extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views, int h, int w) {
   if (!db || n_views <= 0 || h <= 0 || w <= 0) return 0;
-  return (size_t)n_views * (size_t)bin_layout(db, h, w).view_ints * sizeof(int);
+  const BinLayout lay = bin_layout(db, h, w);
+  const size_t pairs = (size_t)n_views * lay.n_tiles;
+  return (job_tail_offset_ints(lay, n_views) + 4 + pairs) * sizeof(int) + ((pairs + 15) & ~(size_t)15);
 }
 
 static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
@@ -969,6 +1120,13 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   memcpy(L.offset, lights->point_offset, sizeof(L.offset));
   const BinLayout lay = bin_layout(db, h, w);
   const int ns = (flags & MP_RASTER_MSAA4) ? 4 : 1;
+  const int n_items = n_views / views_per_item;
+  // compacted launch form (light-job list + per-pair flags behind the view blocks) unless MP_RASTER_COMPACT=0 (read per launch: the A/B test flips it)
+  int* const counters = (int*)d_ws + job_tail_offset_ints(lay, n_views);
+  int* const light_list = counters + 4;
+  unsigned char* const job_flags = (unsigned char*)(light_list + (size_t)n_views * lay.n_tiles);
+  const char* compact_env = getenv("MP_RASTER_COMPACT");
+  const bool compact = !(compact_env && atoi(compact_env) == 0);
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0, do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   // channel run [c_lo, c_hi) one pixel record of this launch spans, and which of its channels are written
   int c_lo = 1 << 30, c_hi = -1;
@@ -999,9 +1157,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
       attr_set = true;
     }
     ProfScope prof("raster_bin", 0.0, (double)n_views * (12.0 * db->max_faces + 12.0 * db->max_verts + 4.0 * lay.n_tiles), s);
-    hipLaunchKernelGGL(raster_bin, dim3(n_views), dim3(BIN_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, h, w, ns, (int*)d_ws, lay);
+    hipLaunchKernelGGL(raster_bin, dim3(n_views), dim3(BIN_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, h, w, ns, (int*)d_ws, lay, counters);
   }
-  const int n_items = n_views / views_per_item;
   const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
   const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
   MP_REQUIRE(n_wg < (1LL << 31), "mp_raster_render: grid too large");
@@ -1031,19 +1188,43 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   const int run_lds = xrec ? std::max(run, ((int)stride_x + 1) / 2) : run;
   const size_t lds = (size_t)TILE_WAVES * (tiles_zt_bytes(ns) + (((size_t)64 * run_lds * sizeof(float) + 15) & ~(size_t)15) + HDR_LDS_BYTES);
   const double out_es = f16 ? 2.0 : 4.0;   // bytes per output element
-  ProfScope prof(f16 ? "raster_tiles/f16" : xrec ? "raster_tiles/xrec" : "raster_tiles", 0.0,
-                 xrec ? (double)n_views * (32.0 * db->max_verts + 12.0 * db->max_faces) + (double)n_items * (2.0 * stride_x + 4.0 * crop.C) * h * w :
-                 (double)n_views * ((double)n_ch * out_es * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) +
-                     (crop.images ? (double)n_items * crop.C * (out_es + 4.0) * h * w : 0.0), s);   // crop: C channels written + <= the same-sized fp32 source window read
+  const double alg_bytes = xrec ? (double)n_views * (32.0 * db->max_verts + 12.0 * db->max_faces) + (double)n_items * (2.0 * stride_x + 4.0 * crop.C) * h * w :
+                           (double)n_views * ((double)n_ch * out_es * h * w + 32.0 * db->max_verts + 12.0 * db->max_faces) +
+                               (crop.images ? (double)n_items * crop.C * (out_es + 4.0) * h * w : 0.0);   // crop: C channels written + <= the same-sized fp32 source window read
   // FULL = texture + point-light code compiled in; the pose networks' renders (vertex colours, ambient light) take the lean instance
   const bool full = db->any_texture || L.n_point > 0;
 #define MP_LAUNCH_TILES(NSV, OUTV, FULLV)                                                                                              \
   hipLaunchKernelGGL((raster_tiles<NSV, OUTV, FULLV>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,    \
                      d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,  \
                      (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop,       \
-                     f32_mask, d_tcr, depth_mode)
-  const int sel = (ns == 4 ? 8 : 0) | (xrec ? 4 : f16 ? 2 : 0) | (full ? 1 : 0);
+                     f32_mask, d_tcr, depth_mode, compact ? job_flags : (const unsigned char*)nullptr)
+  const bool depthrec = xrec && (do_depth || f32_mask != (1u << crop.C) - 1u);
+  if (compact) {
+    ProfScope prof_c("raster_classify", 0.0, (double)n_views * lay.n_tiles * 16.0, s);
+    const long total = (long)n_items * lay.n_tiles;
+    hipLaunchKernelGGL(raster_classify, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const int*)d_ws, lay, views_per_item, n_items, job_flags,
+                       counters, light_list);
+  }
+  const int sel = depthrec ? (ns == 4 ? 16 : 17) + (full ? 2 : 0) : (ns == 4 ? 8 : 0) | (xrec ? 4 : f16 ? 2 : 0) | (full ? 1 : 0);
+  {
+  ProfScope prof(f16 ? "raster_tiles/f16" : xrec ? "raster_tiles/xrec" : "raster_tiles", 0.0, alg_bytes, s);
   switch (sel) {
+    case 16: hipLaunchKernelGGL((raster_tiles<4, OUT_XREC, false, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,
+                     d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop,
+                     f32_mask, d_tcr, depth_mode, compact ? job_flags : (const unsigned char*)nullptr); break;
+    case 17: hipLaunchKernelGGL((raster_tiles<1, OUT_XREC, false, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,
+                     d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop,
+                     f32_mask, d_tcr, depth_mode, compact ? job_flags : (const unsigned char*)nullptr); break;
+    case 18: hipLaunchKernelGGL((raster_tiles<4, OUT_XREC, true, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,
+                     d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop,
+                     f32_mask, d_tcr, depth_mode, compact ? job_flags : (const unsigned char*)nullptr); break;
+    case 19: hipLaunchKernelGGL((raster_tiles<1, OUT_XREC, true, true>), dim3((unsigned)n_wg), dim3(64 * TILE_WAVES), lds, s, db->d_meshes, db->d_texs,
+                     d_mesh_ids, d_TCO, d_K, (const int*)d_ws, lay, h, w, flags, L, d_out, (long long)stride_v, views_per_item, n_items,
+                     (long long)stride_view, (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop,
+                     f32_mask, d_tcr, depth_mode, compact ? job_flags : (const unsigned char*)nullptr); break;
     case 0: MP_LAUNCH_TILES(1, OUT_F32, false); break;
     case 1: MP_LAUNCH_TILES(1, OUT_F32, true); break;
     case 2: MP_LAUNCH_TILES(1, OUT_F16, false); break;
@@ -1057,7 +1238,28 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
     case 12: MP_LAUNCH_TILES(4, OUT_XREC, false); break;
     default: MP_LAUNCH_TILES(4, OUT_XREC, true); break;
   }
+  }
 #undef MP_LAUNCH_TILES
+  if (compact) {   // the pairs no view reaches: background + crop, strided over the light list, four waves per SIMD
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      MP_CHECK_HIP(hipGetDevice(&dev));
+      MP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const size_t lds_l = (size_t)TILE_WAVES * (((size_t)64 * run_lds * sizeof(float) + 15) & ~(size_t)15);
+    const long long n_res = std::min<long long>((long long)n_cu * 8, std::max<long long>(1, ((long long)n_items * lay.n_tiles + TILE_WAVES - 1) / TILE_WAVES));
+    ProfScope prof_l(f16 ? "raster_tiles_light/f16" : xrec ? "raster_tiles_light/xrec" : "raster_tiles_light", 0.0, 0.0, s);
+#define MP_LAUNCH_LIGHT(OUTV, DR)                                                                                                              \
+    hipLaunchKernelGGL((raster_tiles_light<OUTV, DR>), dim3((unsigned)n_res), dim3(64 * TILE_WAVES), lds_l, s, (const int*)counters,           \
+                       (const int*)light_list, lay, h, w, flags, d_out, (long long)stride_v, views_per_item, (long long)stride_view,           \
+                       (long long)stride_y, (long long)stride_x, c_rgb, c_normals, c_depth, c_lo, run_lds, mask, crop, f32_mask, d_tcr, depth_mode)
+    if (depthrec) MP_LAUNCH_LIGHT(OUT_XREC, true);
+    else if (xrec) MP_LAUNCH_LIGHT(OUT_XREC, false);
+    else if (f16) MP_LAUNCH_LIGHT(OUT_F16, false);
+    else MP_LAUNCH_LIGHT(OUT_F32, false);
+#undef MP_LAUNCH_LIGHT
+  }
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

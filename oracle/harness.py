@@ -113,6 +113,15 @@ def sampled_rows_parity(oest: "op.OraclePoseEstimator", db, images: torch.Tensor
         res["feature_max"] = max(res.get("feature_max", 0.0), max(o["net"]["features"].abs().max().item() for o in outs_s))
         res["score_logit_max_err"] = (sg - sl.flatten()).abs().max().item()
         res["score_logit_errs"] = (sg - sl.flatten()).abs().tolist()
+        # The comparison above is CHAINED: the oracle scores ITS final pose, the HIP call its own -- after n_iterations refiner steps the two
+        # poses differ by up to the pose tolerance, and a pose difference moves silhouette samples (a logit difference that is the
+        # refiner's, not the scoring stage's).  Teacher-forced: the oracle scores the HIP call's final pose of the same rows -- the scoring
+        # stage alone (render + crop + coarse network at one given pose), what the 1e-4 logit bound is about.
+        T_hip = preds[f"iteration={n_iterations}"].poses[rows].cpu()
+        outs_tf = [cpred.forward_coarse(images, im[s], K_im[im[s]], labels[s], T_hip[s]) for s in batches(len(rows), oest.bsz)]
+        sl_tf = torch.cat([o["logits"] for o in outs_tf])
+        res["score_logit_errs_teacher_forced"] = (sg - sl_tf.flatten()).abs().tolist()
+        res["final_pose_max_err"] = (T_hip - T_ref).abs().max().item()
     return res
 
 

@@ -744,3 +744,65 @@ def test_fused_crop_in_raster_launch_equals_standalone_crop(eng, engine_meshes, 
     eng.raster_render(db, ids, T, K, h, w, 1, eng.make_lights(), x, h * w * Cp, w * Cp, Cp, nin, nin + 3, -1, views_per_item=V,
                       stride_view=6, crop=(eng.PackedObservation(images), im_ids, boxes, 0))
     assert torch.equal(x, outs[0])
+
+
+@pytest.mark.parametrize("mode", ["fp32_crop", "fp32_plain", "f16_crop", "records_rgb", "records_rgbd"])
+def test_raster_compacted_launch_equals_the_direct_form(eng, engine_meshes, monkeypatch, mode):
+    """Round 5: raster_classify marks the (item, tile) pairs no view reaches; raster_tiles' waves of those pairs leave after one byte load
+    and raster_tiles_light writes them (background + crop).  Which kernel writes a tile must not change a bit: the same launch with
+    MP_RASTER_COMPACT=0 (every pair through raster_tiles, the form of rounds 2-4) and in the compacted form, NaN / sentinel-poisoned
+    outputs (every pixel of every written channel must be written by exactly the same values), for the fp32, binary16 and record outputs,
+    with and without the fused crop, small objects (most tiles empty), an item whose views are ALL empty (non-finite pose) and an object
+    filling its crop."""
+    from tests.support import synthetic as syn
+
+    db = _mesh_db(eng, engine_meshes)
+    rng = np.random.RandomState(17)
+    n_items, V, h, w = 4, 4, 240, 320
+    rgbd = mode == "records_rgbd"
+    C = 4 if rgbd else 3
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(2, C, 480, 640, generator=g).cuda()
+    if rgbd:
+        images[:, 3] = torch.where(images[:, 3] < 0.1, torch.zeros_like(images[:, 3]), 0.3 + images[:, 3])
+    im_ids = torch.tensor([1, 0, 1, 0], dtype=torch.int32).cuda()
+    boxes = torch.tensor([[100.0, 80, 400, 305], [-40.0, -30, 300, 225], [500.0, 300, 700, 450], [200.0, 100, 420, 265]]).cuda()
+    T = np.stack([syn.random_pose(rng, z_range=(0.9, 1.6) if i // V != 3 else (0.2, 0.25)) for i in range(n_items * V)])   # far = small; item 3 fills the crop
+    T[1 * V:2 * V, 0, 3] = np.nan                                                                                     # item 1: every view empty
+    T = torch.from_numpy(T).cuda()
+    K = torch.from_numpy(np.repeat(syn.K_EXAMPLE[None].astype(np.float32), n_items * V, 0)).cuda()
+    K[:, :2] *= 0.5
+    ids = torch.tensor([0, 1, 2, 0], dtype=torch.int32).repeat_interleave(V).cuda()
+    tCR = torch.tensor([[0.0, 0.0, 1.2], [0.0, 0.0, 1.0], [0.1, 0.0, 0.9], [0.0, 0.0, 0.22]]).cuda()
+    nper = 7 if rgbd else 6
+    n_in = C + nper * V
+    outs = {}
+    for compact in ("0", "1"):
+        monkeypatch.setenv("MP_RASTER_COMPACT", compact)
+        if mode.startswith("records"):
+            mask = (1 << C) - 1
+            if rgbd:
+                for v in range(V):
+                    mask |= 1 << (C + 6 + nper * v)
+            R = eng.xrec_elements(bin(mask).count("1"), n_in - bin(mask).count("1"))
+            x = torch.full((n_items, h, w, R), 7.0, device="cuda", dtype=torch.bfloat16)
+            eng.raster_render(db, ids, T, K, h, w, 1 | 16 | (2 if rgbd else 0), eng.make_lights(), x, h * w * R, w * R, R, C, C + 3, C + 6 if rgbd else -1,
+                              views_per_item=V, stride_view=nper, crop=(eng.PackedObservation(images), im_ids, boxes, 0),
+                              xrec=(mask, tCR, 2) if rgbd else None)
+            assert not (x == 7.0).all(dim=-1).any()   # every pixel record written
+        else:
+            Cp = 32
+            dt = torch.float16 if mode == "f16_crop" else torch.float32
+            x = torch.full((n_items, h, w, Cp), float("nan"), device="cuda", dtype=dt)
+            crop = (eng.PackedObservation(images), im_ids, boxes, 0) if mode != "fp32_plain" else None
+            eng.raster_render(db, ids, T, K, h, w, 1 | 16, eng.make_lights(), x, h * w * Cp, w * Cp, Cp, 3, 6, -1, views_per_item=V, stride_view=6, crop=crop)
+            c_first = 0 if crop is not None else 3
+            assert torch.isfinite(x[..., c_first:3 + 6 * V].float()).all()     # every written channel of every pixel written
+            assert torch.isnan(x[..., 3 + 6 * V:].float()).all()                # nothing else touched
+            x = torch.nan_to_num(x.float(), nan=-5.0)
+        outs[compact] = x
+    torch.cuda.synchronize()
+    assert torch.equal(outs["0"], outs["1"])
+    if not mode.startswith("records"):
+        img = outs["1"][..., 3:3 + 6 * V]
+        assert (img[1] == 0).all() and (img[0] > 0).float().mean() < 0.2 and (img[3] > 0).float().mean() > 0.3   # empty item, small object, filled crop
