@@ -476,6 +476,7 @@ def main():
         mpd.init_from_env("gloo" if shared_gpu else "nccl")
         mpd.stats.timing = True
     n_cu, lds, arch = eng.device_info()
+    eng.conv_wino_bf16_telemetry(True)   # the K-loop clock / cycles-per-step figures of the roofline block (off in the product path)
 
     tmp = tempfile.mkdtemp(prefix=f"mp_bench_r{rank}_")
     k_hyp = a.k_hyp or (N_HYP if a.config in (2, 3) else 5)

@@ -271,6 +271,9 @@ int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int res
 /* shader cycles a sampled workgroup of those launches spent before its K loop (requests, first transform) and after it (output transform,
  * exchange, stores), averaged since the last mp_conv_wino_bf16_clock reset; call BEFORE the resetting clock read */
 int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogue_cycles);
+/* switches the in-kernel clock telemetry behind the two calls above on / off (default OFF: the pose pipeline does not pay the six global
+ * atomics of every 64th workgroup; bench.py and the microbenchmarks switch it on); returns the previous setting */
+int mp_conv_wino_bf16_telemetry(int on);
 
 /* Stem convolution on the bf16 MFMA through EXACT operand pieces (csrc/conv_stem.hip; same call site as mp_conv2d_nhwc for the first
  * layer: models/torchvision_resnet.py:213-216, models/wide_resnet.py:65-67).  The render channels of the CNN input are 8-bit integers

@@ -124,6 +124,7 @@ SIGNATURES = {
     "mp_conv_wino_bf16_stats": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
     "mp_conv_wino_bf16_clock": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
     "mp_conv_wino_bf16_phases": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mp_conv_wino_bf16_telemetry": (_i, [_i]),
     "mp_xrec_elements": (_i, [_i, _i]),
     "mp_conv_stem_supported": (_i, [_i, _i, _i]),
     "mp_conv_stem_packed_bytes": (_sz, [_i, _i, _i, _i]),

@@ -19,7 +19,9 @@
 // is followed by <= 6 instructions of other work -- the split of the NEXT point's fragments (half an element pair per slot), the next
 // step's input-transform planes, patch / weight requests, fragment reads -- so that the matrix pipe never waits for the vector pipe.
 // Roofline: bf16 MFMA; algorithmic work = 2 * MACs of the direct convolution; executed = 9 x 16/36 of that in bf16 FLOPs.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "wino_common.h"
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //      fragments split during point f-1 (raw fp32 read during point f-2) with the weights requested during point f-1.  ONE barrier per
   //      step, between points 1 and 2: V of this step is last read in point 1 (for point 3), V of the next step is complete after point 1
   //      (its transform rides in points 0 and 1) and first read in point 2.
-  const bool clk_sample = (blockIdx.x & 63) == 0 && tid == 0;
+  const bool clk_sample = p.telemetry != 0 && (blockIdx.x & 63) == 0 && tid == 0;
   unsigned long long clk_c0 = 0, clk_r0 = 0;
   if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_wb_clk[3], clk_c0 - clk_start); }
   for (int st = 0; st < ns; ++st) {
@@ -465,13 +467,21 @@ extern "C" int mp_conv_wino_bf16_pack_weights(const float* w, int Cout, int Cin,
   return MP_OK;
 }
 
+// host-side totals over the launches since the last reset (launches may come from several threads: one lock, taken once per launch)
+static std::mutex g_wb_mu;
 static double g_wb_direct = 0.0, g_wb_executed = 0.0;
+static std::atomic<int> g_wb_telemetry{0};
 extern "C" int mp_conv_wino_bf16_stats(double* direct_flops, double* executed_bf16_flops, int reset) {
+  std::lock_guard<std::mutex> lock(g_wb_mu);
   if (direct_flops) *direct_flops = g_wb_direct;
   if (executed_bf16_flops) *executed_bf16_flops = g_wb_executed;
   if (reset) g_wb_direct = g_wb_executed = 0.0;
   return MP_OK;
 }
+
+// In-kernel clock telemetry (s_memtime / s_memrealtime of every 64th workgroup, six global atomics each): OFF unless switched on here --
+// bench.py and the microbenchmarks do; the pose pipeline never pays for it.  Returns the previous setting.
+extern "C" int mp_conv_wino_bf16_telemetry(int on) { return g_wb_telemetry.exchange(on ? 1 : 0); }
 
 extern "C" int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogue_cycles) {   // per workgroup, since the last clock reset
   unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
@@ -538,8 +548,12 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   const double c_real = d->c_real > 0 ? d->c_real : d->C;
   const double direct = 2.0 * 9.0 * (double)d->N * d->H * d->W * c_real * d->Cout;
   const double executed = 9.0 * 2.0 * 16.0 * (double)n_tiles * c_real * d->Cout;   // bf16 FLOPs: nine piece products per Winograd multiplication
-  g_wb_direct += direct;
-  g_wb_executed += executed;
+  {
+    std::lock_guard<std::mutex> lock(g_wb_mu);
+    g_wb_direct += direct;
+    g_wb_executed += executed;
+  }
+  p.telemetry = g_wb_telemetry.load(std::memory_order_relaxed);
   ProfScope prof("conv3x3_wino_bf16x9<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout)) + 6.0 * 16.0 * d->C * d->Cout, s, executed, 2500.0);
 #ifdef MP_CONV_EXPERIMENTS
   const int diag = getenv("MP_WINO_DIAG") ? atoi(getenv("MP_WINO_DIAG")) : 0;

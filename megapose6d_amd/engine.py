@@ -355,6 +355,12 @@ def conv_wino_bf16_pack_weights(w_oihw: np.ndarray, cin_p: int, scale: Optional[
     return out
 
 
+def conv_wino_bf16_telemetry(on: bool) -> bool:
+    """in-kernel clock telemetry of the bf16 Winograd kernel (every 64th workgroup, six global atomics): off by default; returns the
+    previous setting (mp_conv_wino_bf16_telemetry)"""
+    return bool(_lib.load().mp_conv_wino_bf16_telemetry(int(bool(on))))
+
+
 def conv_wino_bf16_stats(reset: bool = True) -> Tuple[float, float]:
     """(algorithmic = direct-convolution FLOPs, executed bf16 FLOPs) of the bf16x9 Winograd launches since the last reset"""
     a, b = C.c_double(0), C.c_double(0)

@@ -216,6 +216,7 @@ static int run_case(const Case& s, int* n_bad) {
 }
 
 int main(int argc, char** argv) {
+  mp_conv_wino_bf16_telemetry(1);   // the CLK lines below read the in-kernel clock counters (off by default in the library)
   static const Case CASES[] = {
       {"3x 64->64 @12x16 plain", 3, 64, 12, 16, 64, 0, 0, 0, 0},
       {"5x 64->128 @15x20 res+relu (odd H)", 5, 64, 15, 20, 128, 1, 1, 0, 0},

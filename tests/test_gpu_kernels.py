@@ -805,4 +805,4 @@ def test_raster_compacted_launch_equals_the_direct_form(eng, engine_meshes, monk
     assert torch.equal(outs["0"], outs["1"])
     if not mode.startswith("records"):
         img = outs["1"][..., 3:3 + 6 * V]
-        assert (img[1] == 0).all() and (img[0] > 0).float().mean() < 0.2 and (img[3] > 0).float().mean() > 0.3   # empty item, small object, filled crop
+        assert (img[1] == 0).all() and (img[0] > 0).float().mean() < 0.1 and (img[3] > 0).float().mean() > 0.15   # empty item, small object, object filling its crop

@@ -23,10 +23,18 @@ def _check(res):
     # logits: 1e-4 x max(1, |logit|), flipped-silhouette rows counted (<= 1 per 64 sampled rows, each <= 2e-4): oracle.harness.logit_flip_rule
     from oracle.harness import logit_flip_rule
 
-    for key in ("coarse_logit_errs", "score_logit_errs"):
+    from oracle.harness import chained_score_rule
+
+    # the scoring stage alone: the oracle scores the DEVICE's final pose of the sampled rows (teacher-forced) -- the strict rule
+    for key in ("coarse_logit_errs", "score_logit_errs_teacher_forced"):
         if key in res:
             r = logit_flip_rule(res[key], scale, TOL)
             assert r["ok"], (key, r)
+    # chained (each side scores its own final pose): the strict bound + what the refiner's pose difference (itself < TOL, asserted below)
+    # moves the re-render -- oracle.harness.chained_score_rule
+    if "score_logit_errs" in res:
+        r = chained_score_rule(res, TOL)
+        assert r["ok"], ("score_logit_errs (chained)", r, res.get("final_pose_errs"))
     for n, e in enumerate(res.get("pose_max_err_per_iter", [])):
         assert e < TOL, (n, res)
     for n, e in enumerate(res.get("pose_out_max_err_per_iter", [])):
