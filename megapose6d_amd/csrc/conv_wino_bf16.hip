@@ -45,38 +45,53 @@ constexpr int UB_STEP_BYTES = 16 * UB_F_BYTES;    // 96 KB per 16-channel step
 __device__ unsigned long long g_wb_clk[6];   // K-loop cycles, K-loop 100 MHz ticks, steps | prologue cycles, epilogue cycles, sampled workgroups
 
 // DIAG (timing experiments only, wrong results; MP_WINO_DIAG): 1 = no split work, 2 = no patch requests / transform, 4 = no weight requests
-template <int DIAG>
+// PERSIST (round 5): one workgroup per CU walks the units u = blockIdx.x, + gridDim.x, ... (a unit = what a workgroup of the one-unit form
+// does: 64 tiles x 64 output channels).  The K loop is the SAME code; what changes is around it: while the epilogue of unit u runs its
+// second half (the accumulators are already in LDS), the step-0 patch and the first weight fragments of unit u + 1 are requested, so that
+// the next prologue starts with its operands in registers instead of waiting a memory round trip with nothing else resident on the CU
+// (the prologue is 7.9 k of a C = 64 workgroup's 46 k cycles).  Only the step-0 patch and six weight fragments are carried (88 registers
+// next to the epilogue's ~140): nothing extra is live across the K loop.
+template <int DIAG, bool PERSIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_bf16x9(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;
   int* tile_tab = (int*)(smem + 4 * 2 * WT * WCOUT);   // [64][2]: output element offset of pixel (2ty, 2tx) (-1: no such tile), validity bits
 
-  const unsigned long long clk_start = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int cb = wg % p.n_cblocks;      // channel block fastest: the workgroups that share an input tile set run together
-  const int tg = wg / p.n_cblocks;
-  const int tile0 = tg * WT;
-
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, -1, 0x00020000);
   const int row_bytes = p.Wp * p.C * 4, pix_bytes = p.C * 4;
-  // weights: [cb][step][f][j][piece][lane][8 bf16]; this wave's four frequency points of a step are 24 KB contiguous
-  const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.u) + (size_t)cb * p.n_steps * UB_STEP_BYTES + (size_t)(4 * wave) * UB_F_BYTES;
-  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, -1, 0x00020000);
   const int u_voff = lane * 16;
-
-  float4 patch[4][4];
   const int ptile = tid >> 2, pc4 = tid & 3;
-  int x_voff;
-  {
-    int t = tile0 + ptile;
+  const int n_units = PERSIST ? p.n_units : (int)gridDim.x;
+  // byte offset of the lane's patch corner for the unit's tile group
+  auto patch_voff = [&](int tile0_) {
+    int t = tile0_ + ptile;
     t = t < p.n_tiles ? t : p.n_tiles - 1;
     const int tx = t % p.tiles_x, r = t / p.tiles_x;
     const int ty = r % p.tiles_y, n = r / p.tiles_y;
     const size_t pix = ((size_t)n * p.Hp + (size_t)(2 * ty + p.in_off)) * p.Wp + (size_t)(2 * tx + p.in_off);
-    x_voff = (int)((pix * p.C + pc4 * 4) * sizeof(float));
-  }
+    return (int)((pix * p.C + pc4 * 4) * sizeof(float));
+  };
+  // weights: [cb][step][f][j][piece][lane][8 bf16]; this wave's four frequency points of a step are 24 KB contiguous
+  auto weights_of = [&](int cb_) {
+    return reinterpret_cast<const unsigned char*>(p.u) + (size_t)cb_ * p.n_steps * UB_STEP_BYTES + (size_t)(4 * wave) * UB_F_BYTES;
+  };
+  // (PERSIST) operands of the NEXT unit's prologue, requested during this unit's epilogue
+  u32x4 pfU[6];
+  float4 pfP[4][4];
+  bool have_pf = false;
+  int unit = blockIdx.x;
+  do {
+  const unsigned long long clk_start = __builtin_readcyclecounter();
+  const int wg = xcd_remap(unit, n_units);
+  const int cb = wg % p.n_cblocks;      // channel block fastest: the workgroups that share an input tile set run together
+  const int tg = wg / p.n_cblocks;
+  const int tile0 = tg * WT;
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)weights_of(cb), 0, -1, 0x00020000);
+
+  float4 patch[4][4];
+  const int x_voff = patch_voff(tile0);
   // V[stage][f][tile][16 floats], 16-byte slot s of a row holds channels 4s..4s+3, slots XOR-swizzled by (tile >> 2) & 3 (as conv_wino.hip)
   float* vw = Vs + ptile * WCK + ((pc4 ^ ((ptile >> 2) & 3)) * 4);
 
@@ -235,9 +250,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float4 pnext[4][4];
   {
     const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
-    _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)
-      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
+    if (PERSIST && have_pf) {   // requested during the previous unit's epilogue
+      _Pragma("unroll") for (int k = 0; k < 6; ++k) Ua[k / 3][k % 3] = pfU[k];
+      _Pragma("unroll") for (int a = 0; a < 4; ++a)
+        _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = pfP[a][bb];
+    } else {
+      _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
+      _Pragma("unroll") for (int a = 0; a < 4; ++a)
+        _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
+    }
     _Pragma("unroll") for (int a = 0; a < 4; ++a)
       _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) pnext[a][bb] = buf4(x_rsrc, x_voff, cs1 + a * row_bytes + bb * pix_bytes);
   }
@@ -372,6 +393,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
   }
   __syncthreads();
+  const int unit_next = unit + (int)gridDim.x;
+  if (PERSIST && unit_next < n_units) {   // the next unit's step-0 operands: in flight while this unit's outputs are finished and stored
+    const int wg_n = xcd_remap(unit_next, n_units);
+    const __amdgpu_buffer_rsrc_t u_rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void*)weights_of(wg_n % p.n_cblocks), 0, -1, 0x00020000);
+    const int x_voff_n = patch_voff((wg_n / p.n_cblocks) * WT);
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) pfU[k] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc_n, u_voff, k * 1024, 0);
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) pfP[a][bb] = buf4(x_rsrc, x_voff_n, a * row_bytes + bb * pix_bytes);
+    have_pf = true;
+  }
   const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
   const bool has_res = p.residual != nullptr, relu = p.relu != 0, has_act = p.y_act != nullptr;
@@ -413,10 +444,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
   }
   if (clk_sample) {
-    __builtin_amdgcn_s_waitcnt(0);   // the stores are out
+    if (!PERSIST) __builtin_amdgcn_s_waitcnt(0);   // the stores are out (the persistent form keeps its prefetch in flight: its epilogue ends at the last store's issue)
     atomicAdd(&g_wb_clk[4], __builtin_readcyclecounter() - clk_epi);
     atomicAdd(&g_wb_clk[5], 1ull);
   }
+  if (PERSIST) {
+    unit = unit_next;
+    if (unit < n_units) __syncthreads();   // the next prologue writes the V stage (and the tile table) this epilogue read
+  }
+  } while (PERSIST && unit < n_units);
 }
 
 }  // namespace mp
@@ -533,6 +569,7 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   static int attr_dev = -1;
   if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
 #ifdef MP_CONV_EXPERIMENTS
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
@@ -544,6 +581,7 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
     attr_dev = dev;
   }
   const long n_wg = ((n_tiles + WT - 1) / WT) * p.n_cblocks;
+  p.n_units = (int)n_wg;
   hipStream_t s = (hipStream_t)stream;
   const double c_real = d->c_real > 0 ? d->c_real : d->C;
   const double direct = 2.0 * 9.0 * (double)d->N * d->H * d->W * c_real * d->Cout;
@@ -565,7 +603,17 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   else if (diag == 16) hipLaunchKernelGGL(conv3x3_wino_bf16x9<16>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   else
 #endif
-  hipLaunchKernelGGL(conv3x3_wino_bf16x9<0>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  {
+    // MP_WINO_PERSIST=1: the persistent form (one resident workgroup per CU walks the units, next unit's first operands requested under the
+    // epilogue); default: one workgroup per unit.  Read once: a process measures one form.
+    static const int persist = getenv("MP_WINO_PERSIST") ? atoi(getenv("MP_WINO_PERSIST")) : 0;
+    static int n_cu = 0;
+    if (persist && n_cu == 0) MP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (persist && n_wg > n_cu)
+      hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true>), dim3((unsigned)n_cu), dim3(256), WINO_LDS_BYTES, s, p);
+    else
+      hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false>), dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  }
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
