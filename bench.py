@@ -572,15 +572,17 @@ def main():
             rb = {"ms": sum(v["ms"] for v in rparts.values()), "bytes": sum(v["bytes"] for k, v in rparts.items() if k.startswith("raster_tiles")),
                   "launches": rparts[rb_name]["launches"], "parts_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in rparts.items()}}
         traffic, traffic_src, r_traffic = None, None, None
-        tfile = next((f for f in (ROOT / "profiles" / "r04_traffic.json", ROOT / "profiles" / "r03_traffic.json") if f.is_file()), None)
+        tfile = next((f for f in (ROOT / "profiles" / "r05_traffic.json", ROOT / "profiles" / "r04_traffic.json", ROOT / "profiles" / "r03_traffic.json")
+                      if f.is_file()), None)
         if tfile is not None:  # PMC cannot be sampled from inside the process: committed rocprofv3 --pmc summary of the same command
             tj = json.loads(tfile.read_text())
             k = tj["kernels"].get(dom_name.replace(" ", ""))
             if k:
                 traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], tj["source"]
             k = tj["kernels"].get((rb_name or "").replace(" ", ""))
-            if k:
-                r_traffic = k["hbm_bytes_per_launch_corrected"]
+            if k:   # the tile pass = raster_tiles + (compacted form) raster_tiles_light + raster_classify, one launch each per raster call
+                r_traffic = k["hbm_bytes_per_launch_corrected"] + sum(
+                    tj["kernels"][n]["hbm_bytes_per_launch_corrected"] for n in ("raster_tiles_light", "raster_classify") if n in tj["kernels"])
         bf16 = dom["peak_tflops"] > 1000.0
         dom_mhz = wb_mhz if dom_name.startswith("conv3x3_wino_bf16") and wb_mhz > 0 else conv_mhz
         rows_per_obj = N_HYP + k_hyp * N_ITERS + k_hyp
