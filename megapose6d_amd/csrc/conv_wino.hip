@@ -398,7 +398,6 @@ extern "C" int mp_conv3x3_wino_nhwc(const mp_conv_desc* d, const float* d_u, mp_
   p.n_steps = d->C / WCK;
   p.relu = d->relu;
   p.telemetry = 0;
-  p.prefetch_stride = 0;
   p.n_cblocks = d->Cout / WCOUT;
   int dev = 0;
   MP_CHECK_HIP(hipGetDevice(&dev));

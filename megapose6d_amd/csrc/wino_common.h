@@ -31,7 +31,6 @@ struct WinoParams {
   int relu;
   int n_cblocks;        // Cout / 64
   int out_bytes;        // size of the output tensor (range check of the epilogue's buffer accesses)
-  int prefetch_stride;  // > 0: the epilogue touches the step-0 patch lines of workgroup blockIdx.x + prefetch_stride (the one that follows on this XCD)
   int telemetry;        // != 0: every 64th workgroup adds its clock readings to the kernel's telemetry counters (mp_conv_wino_bf16_telemetry)
 };
 
