@@ -67,7 +67,41 @@ def digest(src: str, extra):
     return out
 
 
+def kloop_digest(src: str, kernel_substr: str, n_mfma: int, extra=()):
+    """The innermost loop of the kernel whose mangled name contains `kernel_substr` that holds exactly `n_mfma` v_mfma instructions: its
+    instruction list with scalar register NAMES normalised away (they do not affect timing or the VALU -> MFMA distances), sha1 + counts.
+    Used to pin the hand-scheduled K loop of conv3x3_wino_bf16x9: its split / transform arithmetic is inline asm, the schedule was tuned and
+    validated for ONE vector-register assignment, and an edit elsewhere in the kernel can permute that assignment without changing the
+    opcode sequence -- measured in round 5 to turn the results into inf / NaN (profiles/r05_wino_persist_ab.txt)."""
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-S", "--cuda-device-only", "-o", "-", src], capture_output=True,
+                         text=True, check=True).stdout
+    parts = re.split(r"\n(_Z\w+):[^\n]*\n", asm)
+    for i in range(1, len(parts), 2):
+        if kernel_substr not in parts[i]:
+            continue
+        lines = parts[i + 1].split("s_endpgm")[0].splitlines()
+        labels = {m.group(1): n for n, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        best = None
+        for n, l in enumerate(lines):
+            m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < n:
+                a = labels[m.group(1)]
+                if sum("v_mfma" in x for x in lines[a:n]) == n_mfma and (best is None or n - a < best[1] - best[0]):
+                    best = (a, n)
+        if best is None:
+            continue
+        body = [re.sub(r"\.LBB\d+_\d+", "L", x.split(";")[0].strip()) for x in lines[best[0]: best[1] + 1]]
+        body = [re.sub(r"\bs\d+\b|s\[\d+:\d+\]", "S", x) for x in body if x]
+        ops = [x.split()[0] for x in body]
+        return {"kernel": parts[i], "instructions": len(body), "mfma": n_mfma, "sha1": hashlib.sha1("\n".join(body).encode()).hexdigest(),
+                "opcode_sha1": hashlib.sha1("\n".join(ops).encode()).hexdigest()}
+    return None
+
+
 def main():
+    if sys.argv[1] == "--kloop":   # --kloop file.hip kernel-substring n_mfma
+        print(json.dumps(kloop_digest(sys.argv[2], sys.argv[3], int(sys.argv[4])), indent=1))
+        return
     if sys.argv[1] == "--diff":
         a, b = (json.loads(Path(p).read_text()) for p in sys.argv[2:4])
         rc = 0
