@@ -296,3 +296,43 @@ def test_record_mode_is_refused_where_it_does_not_apply(eng):
     out = torch.empty(1, 9, device="cuda")
     with pytest.raises(EngineError):
         bb.forward(rec, 1, 240, 320, out, None, None, n_f32=32)
+
+
+def test_record_launch_refuses_inconsistent_channel_masks(eng, object_dataset):
+    """mp_raster_render_xrec: which channels are fp32-kind is the caller's statement and must agree with what the launch writes where --
+    crop + depth channels fp32-kind, rgb / normals integers; the record length must be mp_xrec_elements of that split; depth
+    normalisation needs tCR.  Error behaviour only (the values are covered by the record-output test above)."""
+    from megapose6d_amd import mesh_io
+    from megapose6d_amd._lib import EngineError
+
+    db = eng.MeshDB([mesh_io.load_rigid_object(o) for o in object_dataset.list_objects])
+    V, h, w, C, nper = 4, 240, 320, 4, 7
+    mask = RGBD_MASK
+    R = 48
+    T = torch.eye(4, device="cuda").repeat(V, 1, 1)
+    T[:, 2, 3] = 0.5
+    K = torch.tensor([[500.0, 0, 160], [0, 500.0, 120], [0, 0, 1]], device="cuda").repeat(V, 1, 1)
+    ids = torch.zeros(V, dtype=torch.int32, device="cuda")
+    images = eng.PackedObservation(torch.rand(1, C, 480, 640, device="cuda"))
+    im_ids = torch.zeros(1, dtype=torch.int32, device="cuda")
+    boxes = torch.tensor([[100.0, 80, 400, 305]], device="cuda")
+    tCR = torch.tensor([[0.0, 0.0, 0.5]], device="cuda")
+
+    def launch(mask_, R_, tcr_, mode=2):
+        x = torch.zeros(1, h, w, R_, device="cuda", dtype=torch.bfloat16)
+        eng.raster_render(db, ids, T, K, h, w, 1 | 2 | 16, eng.make_lights(), x, h * w * R_, w * R_, R_, C, C + 3, C + 6, views_per_item=V,
+                          stride_view=nper, crop=(images, im_ids, boxes, 0), xrec=(mask_, tcr_, mode))
+        torch.cuda.synchronize()
+        return x
+
+    assert launch(mask, R, tCR).abs().sum() > 0                      # the consistent call goes through
+    with pytest.raises(EngineError, match="fp32-kind channel mask"):
+        launch(mask & ~(1 << 10), R, tCR)                            # a depth channel not marked fp32-kind
+    with pytest.raises(EngineError, match="fp32-kind channel mask"):
+        launch(mask | (1 << 5), R, tCR)                              # an rgb channel marked fp32-kind
+    with pytest.raises(EngineError, match="record length"):
+        launch(mask, 40, tCR)                                        # wrong record length for 8 fp32-kind + 24 integer channels
+    with pytest.raises(EngineError, match="d_tCR"):
+        launch(mask, R, None)                                        # depth normalisation without the reference depths
+    with pytest.raises(EngineError):
+        launch(mask, R, tCR, mode=7)                                 # unknown normalisation mode
