@@ -513,6 +513,7 @@ def main():
     mpd.stats.timing = world > 1
     eng.conv_clock(reset=True)
     eng.conv_wino_bf16_clock(reset=True)
+    eng.conv_stem_bg_stats(reset=True)
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -520,6 +521,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
+    stem_bg, stem_wgs = eng.conv_stem_bg_stats(reset=True)   # stem workgroups that took the background-tile walk / all, of the refiner-stem launches
     conv_mhz = eng.conv_clock(reset=True)   # shader clock INSIDE the (direct fp32) conv kernels of the timed steps
     wb_mhz, wb_cps = eng.conv_wino_bf16_clock(reset=True)   # ... and inside the K loops of the bf16x9 Winograd launches (+ cycles per step)
     gather_ms = mpd.stats.ms() if world > 1 else 0.0
@@ -626,6 +628,14 @@ def main():
                         **{s: {"time": sd[s]["time"], "render_time": sd[s]["render_time"], "model_time": sd[s]["model_time"]} for s in sd},
                         "total": extra_t["time"]},
         }
+        if stem_wgs > 0:
+            f_bg = stem_bg / stem_wgs
+            out["stem_background"] = {
+                "workgroups_short_walk_fraction": f_bg, "workgroups_per_step": stem_wgs / a.steps,
+                "executed_flops_factor": 1.0 - f_bg * (1.0 - 26.0 / 62.0),
+                "note": "refiner-stem workgroups (8 x 16 output pixels) whose input patch no rendered view reaches walk 26 of the 62 K steps "
+                        "(only the observation crop's record chunks; the skipped products are exact zeros).  The per_kernel `executed_tflops` / "
+                        "`mfma_utilisation` of that stem row are computed from the DENSE step count: multiply them by executed_flops_factor"}
         out["host"] = {"replicated_topk_ms_per_step": host_topk_ms,
                        "share_of_step": host_topk_ms / (dt / a.steps * 1e3),
                        "projected_share_at_8_gpus_same_total_work": host_topk_ms / (dt / a.steps * 1e3 / 8.0 + host_topk_ms * 7.0 / 8.0),

@@ -40,6 +40,7 @@ const char* mp_last_error(void);
  * ALGORITHMIC flops / bytes of those launches (DESIGN.md states each kernel's per-unit figures).  Returns 1 past the end. */
 int mp_profile_begin(void);
 int mp_profile_end(void);
+int mp_profile_active(void); /* 1 between begin and end */
 int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
                      double* total_bytes);
 /* the same + the FLOPs the launches EXECUTED on the matrix pipe (= the algorithmic figure for the direct kernels; 16/36 of it for the
@@ -173,6 +174,11 @@ int mp_raster_render_xrec(const mp_mesh_db* db, const int32_t* d_mesh_ids, const
                           int c_normals, int c_depth, void* d_workspace, size_t workspace_bytes,
                           const float* d_images, int images_nhwc4, int n_im, int C, int H, int W, const int32_t* d_im_ids,
                           const float* d_boxes, uint32_t f32_mask, const float* d_tCR, int depth_mode, mp_stream stream);
+/* The job flags of the LAST mp_raster_render* launch on `d_workspace` in its compacted form (default; NULL with MP_RASTER_COMPACT=0 is the
+ * caller's business: the bytes are then stale): device pointer to [n_items][tiles_y = ceil(h / 8)][tiles_x = ceil(w / 8)] bytes, 0 = no
+ * view of the item reaches that 8x8-pixel tile (its render channels are all background).  Consumer: mp_conv_stem_xrec_sparse /
+ * mp_backbone_forward_xrec_sparse on the same stream, before the next raster launch on this workspace. */
+const unsigned char* mp_raster_job_flags(const mp_mesh_db* db, const void* d_workspace, int n_views, int h, int w);
 /* observation frames [n_im,C,H,W] (C = 3 | 4) -> [n_im,H,W,4] (4th channel 0 for RGB): one 16-byte load per roi_align tap in the
  * fused crop; done once per observation, not per step */
 int mp_pack_observation_nhwc4(const float* d_images, int n_im, int C, int H, int W, float* d_out, mp_stream stream);
@@ -302,6 +308,21 @@ int mp_conv_stem_xrec(const mp_conv_desc* desc, const void* d_packed, int n_f32,
  * float bits: deterministic. */
 int mp_conv_stem_xrec_pool(const mp_conv_desc* desc, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream);
 
+/* Background tiles (round 5).  A stem workgroup (8 x 16 output pixels) whose input patch holds no rendered geometry -- every integer
+ * channel of every pixel 0: 55 % of a refiner step's tiles -- needs only the record chunks that hold fp32-kind pieces:
+ * mp_conv_stem_sparse_chunks = ceil(3 n_f32 / 8) if that is fewer than the record's chunks and the fp32-kind channels are the leading
+ * ones (no depth channels), else 0.  mp_conv_stem_xrec_sparse = mp_conv_stem_xrec[_pool] (d_ypool may be NULL) that takes, besides the
+ * dense blob, the blob packed for that short walk and the rasteriser's job flags of the launch that wrote the records
+ * (mp_raster_job_flags): such workgroups run 26 instead of 62 steps (7x7, 40-element records) and stage 2 of 5 chunks.  Skipped products
+ * are exact zeros; the evaluated ones are grouped into MFMAs differently from the dense walk (order of the fp32 additions).
+ * mp_conv_stem_bg_stats: workgroups that took the short walk / all workgroups of such launches, counted while the event profiler runs. */
+int mp_conv_stem_sparse_chunks(int KS, int n_f32, int n_u8);
+size_t mp_conv_stem_sparse_packed_bytes(int KS, int n_f32, int n_u8, int Cout);
+int mp_conv_stem_pack_weights_sparse(const float* h_w_oihw, int Cout, int Cin, int KS, int n_f32, const float* h_scale, void* h_packed);
+int mp_conv_stem_xrec_sparse(const mp_conv_desc* desc, const void* d_packed, const void* d_packed_sparse, int n_f32,
+                             const unsigned char* d_tile_flags, float* d_ypool, int pool_border, mp_stream stream);
+int mp_conv_stem_bg_stats(double* background_wgs, double* total_wgs, int reset);
+
 /* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
 int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,
                     int out_border, float* d_y_act, const float* d_act_scale, const float* d_act_shift,
@@ -370,6 +391,11 @@ int mp_backbone_xrec_prepare(mp_backbone* bb, uint32_t f32_mask);
 int mp_backbone_forward_xrec_mask(mp_backbone* bb, const void* d_xrec, uint32_t f32_mask, int batch, int h, int w, float* d_out,
                                   float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,
                                   mp_stream stream);
+/* ... with the rasteriser's job flags of the launch that wrote the records (mp_raster_job_flags; NULL = dense): the stem takes the
+ * background-tile walk where it applies (mp_conv_stem_xrec_sparse; the blob for it is packed by mp_backbone_xrec_prepare) */
+int mp_backbone_forward_xrec_sparse(mp_backbone* bb, const void* d_xrec, uint32_t f32_mask, const unsigned char* d_tile_flags, int batch,
+                                    int h, int w, float* d_out, float* d_sigmoid, float* d_feat, void* d_workspace,
+                                    size_t workspace_bytes, mp_stream stream);
 /* algorithmic conv+fc FLOPs of one forward at this batch (2*MACs, real channels only)       */
 double mp_backbone_flops(const mp_backbone* bb, int batch, int h, int w);
 

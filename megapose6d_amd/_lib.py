@@ -88,6 +88,7 @@ SIGNATURES = {
     "mp_clock_probe": (_i, [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "mp_profile_begin": (_i, []),
     "mp_profile_end": (_i, []),
+    "mp_profile_active": (_i, []),
     "mp_profile_query": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mp_profile_query_ex": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -104,6 +105,7 @@ SIGNATURES = {
                                    _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mp_raster_render_xrec": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, C.POINTER(Lights), _vp, _i64, _i, _i64, _i64, _i64, _i, _i, _i,
                                    _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _vp, _u32, _vp, _i, _vp]),
+    "mp_raster_job_flags": (_vp, [_vp, _vp, _i, _i, _i]),
     "mp_pack_observation_nhwc4": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mp_crop_roi_align": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _i, _vp]),
     "mp_normalize_depth": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _i, _vp]),
@@ -130,6 +132,11 @@ SIGNATURES = {
     "mp_conv_stem_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "mp_conv_stem_pack_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mp_conv_stem_pack_weights_mask": (_i, [_vp, _i, _i, _i, _u32, _vp, _vp]),
+    "mp_conv_stem_sparse_chunks": (_i, [_i, _i, _i]),
+    "mp_conv_stem_sparse_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "mp_conv_stem_pack_weights_sparse": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mp_conv_stem_xrec_sparse": (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "mp_conv_stem_bg_stats": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
     "mp_conv_stem_xrec": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
     "mp_conv_stem_xrec_pool": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -147,6 +154,7 @@ SIGNATURES = {
     "mp_backbone_forward_xrec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_xrec_prepare": (_i, [_vp, _u32]),
     "mp_backbone_forward_xrec_mask": (_i, [_vp, _vp, _u32, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mp_backbone_forward_xrec_sparse": (_i, [_vp, _vp, _u32, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mp_backbone_flops": (C.c_double, [_vp, _i, _i, _i]),
     "mp_normalize_T": (_i, [_vp, _i, _vp, _vp]),
     "mp_init_extents": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

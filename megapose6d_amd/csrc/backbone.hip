@@ -53,6 +53,7 @@ struct mp_backbone {
   // packed for the record layout (number of fp32-kind channels) the caller's rasteriser launch writes
   std::vector<float> stem_w_host, stem_scale_host;
   std::map<uint32_t, void*> stem_blobs;   // f32-kind channel mask -> device blob (mp_backbone_xrec_prepare); never freed before destroy
+  std::map<uint32_t, void*> stem_blobs_sparse;   // ... -> blob of the background-tile walk (leading-channel masks with something to skip)
   // workspace bookkeeping: borders are zeroed once per (pointer, batch, h, w); several workspaces may be live at once
   // (one per HIP stream when half-batches are interleaved on two streams)
   struct WsKey { void* ptr; int batch, h, w; };
@@ -333,6 +334,21 @@ extern "C" int mp_backbone_xrec_prepare(mp_backbone* bb, uint32_t f32_mask) {
     if (hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return 0; }
     bb->allocs.push_back(d);
     bb->stem_blobs[f32_mask] = d;
+    // the background-tile walk: only for leading-channel masks (no depth channels) with fewer fp32-kind chunks than the record has
+    if (f32_mask == (n_f32 >= 32 ? 0xFFFFFFFFu : (1u << n_f32) - 1u) && mp_conv_stem_sparse_chunks(bb->stem.K, n_f32, n_u8) > 0) {
+      std::vector<unsigned char> sb(mp_conv_stem_sparse_packed_bytes(bb->stem.K, n_f32, n_u8, bb->stem.Cout));
+      void* ds = nullptr;
+      if (mp_conv_stem_pack_weights_sparse(bb->stem_w_host.data(), bb->stem.Cout, bb->c_in, bb->stem.K, n_f32,
+                                           bb->stem_scale_host.empty() ? nullptr : bb->stem_scale_host.data(), sb.data()) == MP_OK &&
+          hipMalloc(&ds, sb.size()) == hipSuccess) {
+        if (hipMemcpy(ds, sb.data(), sb.size(), hipMemcpyHostToDevice) == hipSuccess) {
+          bb->allocs.push_back(ds);
+          bb->stem_blobs_sparse[f32_mask] = ds;
+        } else {
+          (void)hipFree(ds);
+        }
+      }
+    }
   }
   return mp_xrec_elements(n_f32, n_u8);
 }
@@ -346,7 +362,7 @@ extern "C" int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32) {
 
 // x_mode: 0 = fp32 padded NHWC, 1 = binary16 elements (MP_RASTER_F16), 2 = bf16 stem records whose fp32-kind channels are f32_mask (MP_RASTER_XREC)
 static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, uint32_t f32_mask, int batch, int h, int w, float* d_out, float* d_sigmoid,
-                                 float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
+                                 float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream, const unsigned char* d_tile_flags = nullptr) {
   const bool x_f16 = x_mode == 1;
   MP_REQUIRE(bb && d_x && d_out && d_ws, "mp_backbone_forward: null pointer");
   if (batch == 0) return MP_OK;
@@ -392,12 +408,16 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
     // vanilla ResNet: the max pool rides in the stem's epilogue and the stem map is never written (MP_STEM_POOL=0: separate kernels);
     // the pre-activation WideResNets need relu(bn1(pooled)) as a second output of the pool, which takes the complete maximum
     static const bool fuse_pool = !(getenv("MP_STEM_POOL") && atoi(getenv("MP_STEM_POOL")) == 0);
+    const auto sp_it = d_tile_flags ? bb->stem_blobs_sparse.find(f32_mask) : bb->stem_blobs_sparse.end();
+    const void* d_sparse = sp_it != bb->stem_blobs_sparse.end() ? sp_it->second : nullptr;   // background-tile walk where it applies
     if (!bb->wide && fuse_pool) {
       d.d_y = nullptr;
-      rc = mp_conv_stem_xrec_pool(&d, d_stem_pieces, n_f32, A[0], 1, s);
+      rc = d_sparse ? mp_conv_stem_xrec_sparse(&d, d_stem_pieces, d_sparse, n_f32, d_tile_flags, A[0], 1, s)
+                    : mp_conv_stem_xrec_pool(&d, d_stem_pieces, n_f32, A[0], 1, s);
       stem_pooled = true;
     } else {
-      rc = mp_conv_stem_xrec(&d, d_stem_pieces, n_f32, s);
+      rc = d_sparse ? mp_conv_stem_xrec_sparse(&d, d_stem_pieces, d_sparse, n_f32, d_tile_flags, nullptr, 0, s)
+                    : mp_conv_stem_xrec(&d, d_stem_pieces, n_f32, s);
     }
   } else {
     rc = run_conv(bb, bb->stem, d_x, batch, h, w, bb->in_border, S, 1, nullptr, 1, nullptr, nullptr, s, SK, x_f16);
@@ -461,6 +481,12 @@ extern "C" int mp_backbone_forward_xrec(mp_backbone* bb, const void* d_xrec, int
 extern "C" int mp_backbone_forward_xrec_mask(mp_backbone* bb, const void* d_xrec, uint32_t f32_mask, int batch, int h, int w, float* d_out,
                                              float* d_sigmoid, float* d_feat, void* d_ws, size_t ws_bytes, mp_stream stream) {
   return backbone_forward_impl(bb, (const float*)d_xrec, 2, f32_mask, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream);
+}
+
+extern "C" int mp_backbone_forward_xrec_sparse(mp_backbone* bb, const void* d_xrec, uint32_t f32_mask, const unsigned char* d_tile_flags, int batch,
+                                               int h, int w, float* d_out, float* d_sigmoid, float* d_feat, void* d_ws, size_t ws_bytes,
+                                               mp_stream stream) {
+  return backbone_forward_impl(bb, (const float*)d_xrec, 2, f32_mask, batch, h, w, d_out, d_sigmoid, d_feat, d_ws, ws_bytes, stream, d_tile_flags);
 }
 
 extern "C" int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, int h, int w, float* d_out, float* d_sigmoid,

@@ -66,7 +66,16 @@ struct Params {
   // fused 3x3 / stride-2 / pad-1 max pool (POOL instances): pooled output, padded NHWC with border pool_border
   float* __restrict__ ypool;
   int Hq, Wq, pool_border;
+  // background tiles (SP instances): the rasteriser's per-(item, 8x8-pixel tile) job flags (0 = no view reaches the tile: every integer
+  // channel of its pixels is 0) and the piece blob of the slices that hold fp32-kind pieces only (record chunks q < q_use)
+  const unsigned char* __restrict__ tile_flags;   // [N][fl_ty][fl_tx]
+  const unsigned char* __restrict__ w_sparse;
+  int fl_tx, fl_ty, q_use, n_steps_sparse;
+  int H, W, pad;         // input size in pixels, convolution padding (to place the patch in the flag grid)
+  int count_bg;          // != 0: one atomic per background workgroup into g_stem_bg (mp_conv_stem_bg_stats; only while the event profiler runs)
 };
+
+__device__ unsigned long long g_stem_bg[2];   // workgroups that took the background-tile walk | workgroups of SP launches (counted launches only)
 
 constexpr size_t LDS_PER_WG = 80 * 1024;   // two workgroups per CU share the 160 KB
 
@@ -97,7 +106,14 @@ struct Geo {
 // is combined with unsigned atomicMax on the float bits (the values are post-ReLU, >= 0: the integer order IS the float order; max is
 // associative and commutative, so the result is deterministic) into a position that pool_zero_kernel cleared beforehand.  The stem map
 // itself is then never written (y may be NULL) and the separate pool kernel + its 2.9-GB read at 576 rows disappear.
-template <int KS, int Q, bool POOL>
+// SP (round 5): BACKGROUND TILES.  55 % of a refiner step's stem tiles see no rendered geometry in any view (the object fills ~30 % of its
+// crop): every integer (render) channel of every pixel of their input patch is 0, and 3 of the 5 record chunks contribute exact zeros.
+// The rasteriser already knows which 8x8-pixel tiles no view reaches (raster_classify's job flags); a workgroup whose whole patch lies in
+// such tiles walks only the slices of the chunks that hold fp32-kind pieces (q < q_use: 2 of 5 for the RGB refiner) with a piece blob
+// packed for that walk: 26 instead of 62 steps, and it stages only those chunks.  Every product that is evaluated is exact and every
+// skipped one is an exact zero; the grouping of the remaining products into MFMAs differs from the dense walk, i.e. the order of the fp32
+// additions (the error class of every other launch-shape difference, bounded by the record tests at 1e-5 of the feature scale).
+template <int KS, int Q, bool POOL, bool SP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem_bf16x3(Params p) {
   using G = Geo<KS, Q>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -108,6 +124,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tx = wg % p.tiles_x; wg /= p.tiles_x;
   const int ty = wg % p.tiles_y;
   const int n = wg / p.tiles_y;
+  bool sparse = false;
+  if constexpr (SP) {   // does any 8x8-pixel tile under the input patch hold geometry?  (<= 4 x 6 flag bytes, one per lane; wave-uniform result)
+    const int r0 = max(2 * ty * TH - p.pad, 0) >> 3, r1 = min(2 * ty * TH - p.pad + G::PH - 1, p.H - 1) >> 3;
+    const int c0 = max(2 * tx * TW - p.pad, 0) >> 3, c1 = min(2 * tx * TW - p.pad + G::PW - 1, p.W - 1) >> 3;
+    const int nc = c1 - c0 + 1, cnt = (r1 - r0 + 1) * nc;
+    unsigned char f = 0;
+    if (lane < cnt) f = p.tile_flags[((size_t)n * p.fl_ty + r0 + lane / nc) * p.fl_tx + c0 + lane % nc];
+    sparse = cnt <= 64 && __ballot(f != 0) == 0ull;
+  }
+  if constexpr (SP) {
+    if (p.count_bg && tid == 0) {
+      if (sparse) atomicAdd(&g_stem_bg[0], 1ull);
+      if (blockIdx.x == 0) atomicAdd(&g_stem_bg[1], (unsigned long long)gridDim.x);
+    }
+  }
+  const int QU = SP && sparse ? p.q_use : Q;                       // record chunks walked per pixel
+  const int n_steps = SP && sparse ? p.n_steps_sparse : p.n_steps;
 
   // ---- patch: PH rows of ROW16 16-byte chunks, global -> registers -> LDS (rows beyond the image: range-checked to zero) ------------
   {
@@ -125,14 +158,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int k = 0; k < HALF; ++k) {
         const int c = tid + 256 * (h * HALF + k);
         const int row = c / SRC16, col = c - row * SRC16;
-        v[k] = (c < N_CH) ? __builtin_amdgcn_raw_buffer_load_b128(r_x, org + row * row_bytes + col * 16, 0, 0) : u32x4{0, 0, 0, 0};
+        const bool want = c < N_CH && (!SP || col % Q < QU);   // (background tile: only the chunks that are walked)
+        v[k] = want ? __builtin_amdgcn_raw_buffer_load_b128(r_x, org + row * row_bytes + col * 16, 0, 0) : u32x4{0, 0, 0, 0};
       }
 #pragma unroll
       for (int k = 0; k < HALF; ++k) {
         const int c = tid + 256 * (h * HALF + k);
         const int row = c / SRC16, col = c - row * SRC16;
         const int lcol = G::QP == Q ? col : col + (col / Q) * (G::QP - Q);   // pixel * QP + q
-        if (c < N_CH) *reinterpret_cast<u32x4*>(lds + row * G::PITCH + lcol * 16) = v[k];
+        if (c < N_CH && (!SP || col % Q < QU)) *reinterpret_cast<u32x4*>(lds + row * G::PITCH + lcol * 16) = v[k];
       }
     }
     // (the padding chunk of every pixel is never read: a slice's chunk index is q < Q)
@@ -140,8 +174,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   // ---- weights: this wave's stream [step][piece][lane][16 B] ----------------------------------------------------------------------
-  const size_t w_wave = ((size_t)cb * 4 + wave) * p.n_steps * 3072;
-  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + w_wave), 0, (unsigned)p.n_steps * 3072u, 0x00020000);
+  const size_t w_wave = ((size_t)cb * 4 + wave) * n_steps * 3072;
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((SP && sparse ? p.w_sparse : p.w) + w_wave), 0, (unsigned)n_steps * 3072u, 0x00020000);
   const int w_voff = lane * 16;
   u32x4 b0[3], b1[3];
 #pragma unroll
@@ -155,11 +189,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int s_r = g;                                   // s % KWQ (g < KWQ)
   int a_row = (2 * i) * (16 * G::QP);            // pixel (kernel row 0, column i); + PITCH per kernel row
   // slice s_r of a kernel row = (kw, q) = (s_r / Q, s_r % Q) sits at chunk kw * QP + q = s_r + kw * (QP - Q) of the row run
-  auto slice_off = [&](int sr) { return G::QP == Q ? sr * 16 : (sr + (sr / Q) * (G::QP - Q)) * 16; };
+  // (SP: QU chunks per pixel are walked: kw = sr / QU by a multiply-shift that is exact for sr < 64, QU <= 6)
+  const int kwq = SP ? KS * QU : G::KWQ;
+  const int qu_m = 1024 / QU + 1;
+  auto slice_off = [&](int sr) {
+    if constexpr (SP) {
+      const int kw = (sr * qu_m) >> 10;
+      return (kw * G::QP + (sr - kw * QU)) * 16;
+    } else {
+      return G::QP == Q ? sr * 16 : (sr + (sr / Q) * (G::QP - Q)) * 16;
+    }
+  };
   int a_off = a_row + slice_off(s_r);
   auto advance = [&]() {                         // s += 4
     s_r += 4;
-    if (s_r >= G::KWQ) { s_r -= G::KWQ; a_row += G::PITCH; }
+    if (s_r >= kwq) { s_r -= kwq; a_row += G::PITCH; }
     a_off = a_row + slice_off(s_r);
   };
   f32x4 acc[TH];
@@ -172,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int j = 0; j < TH; ++j) a0[j] = *reinterpret_cast<const u32x4*>(lds + a_off + j * 2 * G::PITCH);
   advance();
 
-  const int n_pairs = p.n_steps >> 1;
+  const int n_pairs = n_steps >> 1;
   for (int tp = 0; tp < n_pairs; ++tp) {
     const int w_next = (2 * tp + 2) * 3072;   // (past the end in the last pair: range-checked, never used)
     // even step: fragments a0 / b0; read a1 for the odd step
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(256) void pool_zero_kernel(float* __restrict__ y, i
       make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int KS, int Q, bool POOL = false>
+template <int KS, int Q, bool POOL = false, bool SP = false>
 int launch(const Params& p, hipStream_t s, double flops, double bytes, const char* name) {
   // executed on the bf16 pipe: every 16x16x32 MFMA of every step, three weight pieces (this counts the record padding, the step padding
   // and the nine products of the fp32-kind channels as what they cost)
@@ -290,7 +334,7 @@ int launch(const Params& p, hipStream_t s, double flops, double bytes, const cha
   int dev = 0;
   MP_CHECK_HIP(hipGetDevice(&dev));
   if (attr_dev != dev) {
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_bf16x3<KS, Q, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_bf16x3<KS, Q, POOL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
     attr_dev = dev;
   }
   if (POOL) {
@@ -299,7 +343,7 @@ int launch(const Params& p, hipStream_t s, double flops, double bytes, const cha
     hipLaunchKernelGGL(pool_zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.ypool, p.N, p.Hq, p.Wq, p.Cout, p.pool_border);
   }
   ProfScope prof(name, flops, bytes, s, executed, 2500.0);
-  hipLaunchKernelGGL((conv_stem_bf16x3<KS, Q, POOL>), dim3((unsigned)((long)p.N * p.tiles_y * p.tiles_x * p.n_cb)), dim3(256), G::LDS, s, p);
+  hipLaunchKernelGGL((conv_stem_bf16x3<KS, Q, POOL, SP>), dim3((unsigned)((long)p.N * p.tiles_y * p.tiles_x * p.n_cb)), dim3(256), G::LDS, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }
@@ -352,7 +396,33 @@ extern "C" int mp_conv_stem_pack_weights(const float* w, int Cout, int Cin, int 
 // the general record: input channel c is fp32-kind (three pieces) iff bit c of f32_mask is set -- e.g. an RGBD refiner's depth channels
 // (observation depth + one rendered depth per view) -- and sits, in channel order, in front of the integer channels:
 //   [x1,x2,x3 of every fp32-kind channel | k of every integer channel | zero padding]
+// q_walk = record chunks per pixel the kernel's slice walk visits: Q for the dense walk; the chunks that hold fp32-kind pieces for the
+// background-tile walk (mp_conv_stem_sparse_*)
+static int pack_weights_walk(const float* w, int Cout, int Cin, int KS, uint32_t f32_mask, const float* scale, void* packed, int q_walk);
+
 extern "C" int mp_conv_stem_pack_weights_mask(const float* w, int Cout, int Cin, int KS, uint32_t f32_mask, const float* scale, void* packed) {
+  return pack_weights_walk(w, Cout, Cin, KS, f32_mask, scale, packed, 0);
+}
+
+// Background-tile form: a workgroup whose input patch holds no rendered geometry (all integer channels 0) walks only the record chunks
+// that hold fp32-kind pieces: q_use = ceil(3 n_f32 / 8) of the Q chunks.  Defined only when the fp32-kind channels are the leading ones
+// (no depth channels: a normalised background depth is not 0); 0 = no such form (nothing to skip, or not applicable).
+extern "C" int mp_conv_stem_sparse_chunks(int KS, int n_f32, int n_u8) {
+  if (!mp_conv_stem_supported(KS, n_f32, n_u8) || n_f32 <= 0) return 0;
+  const int Q = mp_xrec_elements(n_f32, n_u8) / 8, q_use = (3 * n_f32 + 7) / 8;
+  return q_use < Q ? q_use : 0;
+}
+extern "C" size_t mp_conv_stem_sparse_packed_bytes(int KS, int n_f32, int n_u8, int Cout) {
+  const int q_use = mp_conv_stem_sparse_chunks(KS, n_f32, n_u8);
+  return q_use ? (size_t)(Cout / stem::NCO) * 4 * stem::n_steps(KS, q_use) * 3072 : 0;
+}
+extern "C" int mp_conv_stem_pack_weights_sparse(const float* w, int Cout, int Cin, int KS, int n_f32, const float* scale, void* packed) {
+  const int q_use = mp_conv_stem_sparse_chunks(KS, n_f32, Cin - n_f32);
+  MP_REQUIRE(q_use > 0, "mp_conv_stem_pack_weights_sparse: this record has no background-tile form");
+  return pack_weights_walk(w, Cout, Cin, KS, n_f32 >= 32 ? 0xFFFFFFFFu : (1u << n_f32) - 1u, scale, packed, q_use);
+}
+
+static int pack_weights_walk(const float* w, int Cout, int Cin, int KS, uint32_t f32_mask, const float* scale, void* packed, int q_walk) {
   MP_REQUIRE(Cin >= 1 && Cin <= 32 && (Cin == 32 || (f32_mask >> Cin) == 0u), "mp_conv_stem_pack_weights_mask: mask names channels >= Cin (<= 32 input channels)");
   const int n_f32 = __builtin_popcount(f32_mask), n_u8 = Cin - n_f32;
   MP_REQUIRE(w && packed && n_u8 >= 0 && Cout % stem::NCO == 0 && mp_conv_stem_supported(KS, n_f32, n_u8),
@@ -361,9 +431,10 @@ extern "C" int mp_conv_stem_pack_weights_mask(const float* w, int Cout, int Cin,
   for (int c = 0, a = 0, b = 0; c < Cin; ++c) {
     if ((f32_mask >> c) & 1u) ch_of_f32[a++] = c; else ch_of_u8[b++] = c;
   }
-  const int R = mp_xrec_elements(n_f32, n_u8), Q = R / 8, T = stem::n_steps(KS, Q), S = KS * KS * Q;
+  const int Q = q_walk > 0 ? q_walk : mp_xrec_elements(n_f32, n_u8) / 8;   // chunks walked per pixel (slot 8 q + e names the same channel either way)
+  const int T = stem::n_steps(KS, Q), S = KS * KS * Q;
   unsigned short* out = (unsigned short*)packed;
-  memset(out, 0, mp_conv_stem_packed_bytes(KS, n_f32, n_u8, Cout));
+  memset(out, 0, (size_t)(Cout / stem::NCO) * 4 * T * 3072);
   for (int co = 0; co < Cout; ++co) {
     const int cb = co / stem::NCO, wave = (co % stem::NCO) / 16, i = co % 16;
     const double sc = scale ? (double)scale[co] : 1.0;
@@ -390,7 +461,8 @@ extern "C" int mp_conv_stem_pack_weights_mask(const float* w, int Cout, int Cin,
 
 // d_x = xrec tensor (bf16 records, padded NHWC with border in_border); the other fields as mp_conv2d_nhwc; KH = KW in {5, 7},
 // stride 2, Cout % 64 == 0, no residual / second output
-static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream) {
+static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream,
+                          const void* d_packed_sparse = nullptr, const unsigned char* d_tile_flags = nullptr) {
   MP_REQUIRE(d && d->d_x && d_packed && (d->d_y || d_ypool), "mp_conv_stem_xrec: null pointer");
   MP_REQUIRE(!d_ypool || (d->relu && pool_border >= 0), "mp_conv_stem_xrec_pool: the fused max pool needs the ReLU (its atomicMax orders non-negative floats)");
   const int n_u8 = d->c_real - n_f32;
@@ -412,15 +484,29 @@ static int stem_xrec_impl(const mp_conv_desc* d, const void* d_packed, int n_f32
   p.img_bytes = (unsigned)img; p.out_bytes = (unsigned)outb;
   p.ypool = d_ypool; p.pool_border = pool_border;
   p.Hq = (p.Ho + 2 - 3) / 2 + 1; p.Wq = (p.Wo + 2 - 3) / 2 + 1;
+  p.H = d->H; p.W = d->W; p.pad = d->pad;
+  p.tile_flags = nullptr; p.w_sparse = nullptr; p.fl_tx = p.fl_ty = 0; p.q_use = Q; p.n_steps_sparse = p.n_steps;
+  const int q_use = mp_conv_stem_sparse_chunks(d->KH, n_f32, n_u8);
+  const bool sp = d_packed_sparse && d_tile_flags && q_use > 0;
+  p.count_bg = 0;
+  if (sp) {   // the rasteriser's job flags of the launch that wrote these records: one byte per (image, 8x8-pixel tile)
+    p.count_bg = mp_profile_active();
+    p.tile_flags = d_tile_flags; p.w_sparse = (const unsigned char*)d_packed_sparse;
+    p.fl_tx = ceil_div(d->W, 8); p.fl_ty = ceil_div(d->H, 8); p.q_use = q_use; p.n_steps_sparse = stem::n_steps(d->KH, q_use);
+  }
   const double M = (double)d->N * p.Ho * p.Wo;
   const double flops = 2.0 * M * d->Cout * d->KH * d->KW * d->c_real;
   const double bytes = (double)d->N * img + (d->d_y ? 4.0 * M * d->Cout : 0.0) + (d_ypool ? 4.0 * (double)d->N * p.Hq * p.Wq * d->Cout : 0.0) +
                        (double)mp_conv_stem_packed_bytes(d->KH, n_f32, n_u8, d->Cout);
   hipStream_t s = (hipStream_t)stream;
 #define MP_STEM_GO(KSV, QV)                                                                                                          \
-  if (d->KH == KSV && Q == QV)                                                                                                     \
+  if (d->KH == KSV && Q == QV) {                                                                                                   \
+    if (sp)                                                                                                                        \
+      return d_ypool ? stem::launch<KSV, QV, true, true>(p, s, flops, bytes, "conv_stem_bf16x3+maxpool<" #KSV "x" #KSV ",Q" #QV ">")   \
+                     : stem::launch<KSV, QV, false, true>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");       \
     return d_ypool ? stem::launch<KSV, QV, true>(p, s, flops, bytes, "conv_stem_bf16x3+maxpool<" #KSV "x" #KSV ",Q" #QV ">")         \
-                   : stem::launch<KSV, QV, false>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");
+                   : stem::launch<KSV, QV, false>(p, s, flops, bytes, "conv_stem_bf16x3<" #KSV "x" #KSV ",Q" #QV ">");               \
+  }
   MP_STEM_GO(7, 2) MP_STEM_GO(7, 3) MP_STEM_GO(7, 4) MP_STEM_GO(7, 5) MP_STEM_GO(7, 6)
   MP_STEM_GO(5, 2) MP_STEM_GO(5, 3) MP_STEM_GO(5, 4) MP_STEM_GO(5, 5) MP_STEM_GO(5, 6)
 #undef MP_STEM_GO
@@ -438,4 +524,28 @@ extern "C" int mp_conv_stem_xrec(const mp_conv_desc* d, const void* d_packed, in
 extern "C" int mp_conv_stem_xrec_pool(const mp_conv_desc* d, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream) {
   MP_REQUIRE(d_ypool, "mp_conv_stem_xrec_pool: null pooled output");
   return stem_xrec_impl(d, d_packed, n_f32, d_ypool, pool_border, stream);
+}
+
+// mp_conv_stem_xrec[_pool] with the background-tile form: d_packed_sparse = the blob of mp_conv_stem_pack_weights_sparse, d_tile_flags =
+// the job flags of the rasteriser launch that wrote the records (mp_raster_job_flags: one byte per (image, 8x8-pixel tile), 0 = no view
+// reaches the tile).  d_ypool may be NULL (then desc->d_y must be set).
+extern "C" int mp_conv_stem_xrec_sparse(const mp_conv_desc* d, const void* d_packed, const void* d_packed_sparse, int n_f32,
+                                        const unsigned char* d_tile_flags, float* d_ypool, int pool_border, mp_stream stream) {
+  MP_REQUIRE(d && (d->d_y || d_ypool), "mp_conv_stem_xrec_sparse: null output");
+  return stem_xrec_impl(d, d_packed, n_f32, d_ypool, pool_border, stream, d_packed_sparse, d_tile_flags);
+}
+
+// background-tile statistics of the SP launches issued while the event profiler was active: workgroups that took the short walk, all
+// workgroups of those launches (synchronises the device)
+extern "C" int mp_conv_stem_bg_stats(double* background_wgs, double* total_wgs, int reset) {
+  unsigned long long h[2] = {0, 0};
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(stem::g_stem_bg), sizeof(h)));
+  if (background_wgs) *background_wgs = (double)h[0];
+  if (total_wgs) *total_wgs = (double)h[1];
+  if (reset) {
+    const unsigned long long z[2] = {0, 0};
+    MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(stem::g_stem_bg), z, sizeof(z)));
+  }
+  return MP_OK;
 }

@@ -60,6 +60,7 @@ extern "C" int mp_profile_end(void) {
   mp::g_prof_on = false;
   return MP_OK;
 }
+extern "C" int mp_profile_active(void) { return mp::g_prof_on ? 1 : 0; }
 // Aggregated by kernel name.  idx enumerates distinct names; returns 1 when idx is past the end.
 extern "C" int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
                                 double* total_bytes) {

@@ -1072,6 +1072,15 @@ extern "C" float mp_mesh_db_radius(const mp_mesh_db* db, int i) {
   return (db && i >= 0 && i < db->n) ? db->h_meshes[i].radius : 0.f;
 }
 
+static BinLayout bin_layout(const mp_mesh_db* db, int h, int w);
+static size_t job_tail_offset_ints(const BinLayout& lay, int n_views);
+extern "C" const unsigned char* mp_raster_job_flags(const mp_mesh_db* db, const void* d_ws, int n_views, int h, int w) {
+  if (!db || !d_ws || n_views <= 0 || h <= 0 || w <= 0) return nullptr;
+  const BinLayout lay = bin_layout(db, h, w);
+  const int* counters = (const int*)d_ws + job_tail_offset_ints(lay, n_views);
+  return (const unsigned char*)(counters + 4 + (size_t)n_views * lay.n_tiles);
+}
+
 static BinLayout bin_layout(const mp_mesh_db* db, int h, int w) {
   BinLayout lay;
   lay.tiles_x = ceil_div(w, TILE);

@@ -243,6 +243,14 @@ def raster_render(db: MeshDB, mesh_ids: torch.Tensor, TCO: torch.Tensor, K: torc
                                c_normals, c_depth, ws.data_ptr(), ws.numel(), _stream()))
 
 
+def raster_job_flags(db: MeshDB, n_views: int, h: int, w: int, device, slot: int = 0) -> int:
+    """Device address of the job flags the LAST compacted raster launch on this database's workspace (`slot`) wrote: one byte per
+    (item, 8x8-pixel tile), 0 = no view of the item reaches the tile (mp_raster_job_flags).  Valid on the same stream until the next
+    raster launch on that slot; 0 if unavailable."""
+    ws = db.workspace(n_views, h, w, device, slot)
+    return int(_lib.load().mp_raster_job_flags(db.handle, ws.data_ptr(), n_views, h, w) or 0)
+
+
 def crop_roi_align(images: torch.Tensor, im_ids: torch.Tensor, boxes: torch.Tensor, out_h: int, out_w: int, out: torch.Tensor,
                    stride_b: int, stride_y: int, stride_x: int, c0: int, out_offset_floats: int = 0) -> None:
     lib = _lib.load()
@@ -400,17 +408,46 @@ def xrec_elements(n_f32: int, n_u8: int) -> int:
     return int(_lib.load().mp_xrec_elements(n_f32, n_u8))
 
 
+def conv_stem_pack_weights_sparse(w_oihw: np.ndarray, n_f32: int, scale: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+    """the piece blob of the stem's BACKGROUND-TILE walk (only the record chunks that hold fp32-kind pieces; mp_conv_stem_pack_weights_sparse);
+    None if this record has no such form (nothing to skip)"""
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin, KH, KW = w.shape
+    n = lib.mp_conv_stem_sparse_packed_bytes(KH, n_f32, Cin - n_f32, Cout)
+    if n == 0:
+        return None
+    out = np.empty(n, dtype=np.uint8)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    check(lib.mp_conv_stem_pack_weights_sparse(w.ctypes.data, Cout, Cin, KH, n_f32, None if sc is None else sc.ctypes.data, out.ctypes.data))
+    return out
+
+
+def conv_stem_bg_stats(reset: bool = True) -> Tuple[float, float]:
+    """(workgroups that took the background-tile walk, all workgroups of such launches) counted while the event profiler was active"""
+    a, b = C.c_double(), C.c_double()
+    check(_lib.load().mp_conv_stem_bg_stats(C.byref(a), C.byref(b), int(reset)))
+    return a.value, b.value
+
+
 def conv_stem_xrec(xrec: torch.Tensor, N: int, H: int, W: int, c_real: int, n_f32: int, in_border: int, w_pieces: torch.Tensor,
                    bias: Optional[torch.Tensor], Cout: int, K: int, pad: int, y: Optional[torch.Tensor], out_border: int, relu: bool = False,
-                   y_pool: Optional[torch.Tensor] = None, pool_border: int = 1) -> None:
+                   y_pool: Optional[torch.Tensor] = None, pool_border: int = 1, w_sparse: Optional[torch.Tensor] = None,
+                   tile_flags: Optional[torch.Tensor] = None) -> None:
     """stride-2 stem convolution of a bfloat16 record tensor (mp_conv_stem_xrec); with `y_pool` the 3x3 / stride-2 / pad-1 max pool of its
-    output is written too (mp_conv_stem_xrec_pool; `y` may then be None)"""
+    output is written too (mp_conv_stem_xrec_pool; `y` may then be None); with `w_sparse` + `tile_flags` (uint8 [N, ceil(H/8), ceil(W/8)],
+    0 = the tile's integer channels are all 0) workgroups over background take the short walk (mp_conv_stem_xrec_sparse)"""
     assert xrec.dtype == torch.bfloat16 and w_pieces.dtype == torch.uint8
     d = ConvDesc()
     d.d_x, d.N, d.H, d.W, d.C, d.c_real, d.in_border = xrec.data_ptr(), N, H, W, (c_real + 3) // 4 * 4, c_real, in_border
     d.d_bias = _ptr(bias)
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, K, K, 2, pad
     d.d_y, d.out_border, d.relu = _ptr(y), out_border, int(relu)
+    if w_sparse is not None and tile_flags is not None:
+        assert tile_flags.dtype == torch.uint8 and tile_flags.is_cuda and w_sparse.dtype == torch.uint8
+        check(_lib.load().mp_conv_stem_xrec_sparse(C.byref(d), w_pieces.data_ptr(), w_sparse.data_ptr(), n_f32, tile_flags.data_ptr(),
+                                                   _ptr(y_pool), pool_border, _stream()))
+        return
     if y_pool is not None:
         check(_lib.load().mp_conv_stem_xrec_pool(C.byref(d), w_pieces.data_ptr(), n_f32, y_pool.data_ptr(), pool_border, _stream()))
         return
@@ -503,15 +540,22 @@ class Backbone:
         return hit
 
     def forward(self, x: torch.Tensor, batch: int, h: int, w: int, out: torch.Tensor, sigmoid: Optional[torch.Tensor] = None,
-                feat: Optional[torch.Tensor] = None, slot: int = 0, n_f32: int = 3, f32_mask: Optional[int] = None) -> None:
+                feat: Optional[torch.Tensor] = None, slot: int = 0, n_f32: int = 3, f32_mask: Optional[int] = None,
+                tile_flags: int = 0) -> None:
         """x: fp32 padded NHWC | float16 (same geometry, mp_backbone_forward_f16) | bfloat16 stem records whose fp32-kind channels are
-        the first `n_f32` / the bits of `f32_mask` (what the rasteriser writes with MP_RASTER_XREC; mp_backbone_forward_xrec_mask)."""
+        the first `n_f32` / the bits of `f32_mask` (what the rasteriser writes with MP_RASTER_XREC; mp_backbone_forward_xrec_mask).
+        `tile_flags` = device address of the job flags of the raster launch that wrote the records (`raster_job_flags`): the stem takes
+        the background-tile walk where it applies (mp_backbone_forward_xrec_sparse)."""
         ws = self.workspace(batch, h, w, x.device, slot)
         assert x.dtype in (torch.float32, torch.float16, torch.bfloat16)
         lib = _lib.load()
         if x.dtype == torch.bfloat16:
             mask = leading_mask(n_f32) if f32_mask is None else int(f32_mask)
             self.xrec_elements(f32_mask=mask)   # (prepared on first use; the C forward never allocates)
+            if tile_flags:
+                check(lib.mp_backbone_forward_xrec_sparse(self.handle, x.data_ptr(), mask & 0xFFFFFFFF, tile_flags, batch, h, w, out.data_ptr(),
+                                                          _ptr(sigmoid), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()))
+                return
             check(lib.mp_backbone_forward_xrec_mask(self.handle, x.data_ptr(), mask & 0xFFFFFFFF, batch, h, w, out.data_ptr(), _ptr(sigmoid),
                                                     _ptr(feat), ws.data_ptr(), ws.numel(), _stream()))
             return

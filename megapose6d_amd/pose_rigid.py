@@ -229,6 +229,10 @@ class PosePredictor(nn.Module):
         # against the fp32-MFMA stem the order of the fp32 additions differs, and the 1/255 of the integer channels is folded into their
         # weights (one rounding per weight instead of one per pixel value).  MP_STEM_RECORDS=0 / stem_records=False: fp32 tensor.
         self.stem_records: bool = os.environ.get("MP_STEM_RECORDS", "1") != "0"
+        # Background tiles (round 5): the rasteriser's compacted launch knows which 8x8-pixel tiles of a row's crop no view reaches; the
+        # stem's workgroups over such tiles walk only the record chunks of the observation crop (csrc/conv_stem.hip, SP instances).  RGB
+        # models on records, one raster launch per step.  MP_STEM_SPARSE=0 / stem_sparse=False: every workgroup takes the dense walk.
+        self.stem_sparse: bool = os.environ.get("MP_STEM_SPARSE", "1") != "0"
         self._x: Dict[int, torch.Tensor] = {}      # CNN input buffer per slot (= concurrent HIP stream)
         self._x_rows: Dict[int, int] = {}
         self._x_cp: Dict[int, int] = {}
@@ -433,7 +437,12 @@ class PosePredictor(nn.Module):
         n_out = bb.n_out
         out = torch.empty(b, n_out, dtype=torch.float32, device=device)
         sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
-        bb.forward(x, b, h, w, out, sig, slot=slot, f32_mask=self._f32_mask())
+        tile_flags = 0
+        if (records and self.stem_sparse and vg >= V and not (self.input_depth or self.render_depth)
+                and os.environ.get("MP_RASTER_COMPACT", "1") != "0"):
+            # the job flags of THIS step's (single) raster launch: same stream, consumed before the next launch on this slot's workspace
+            tile_flags = eng.raster_job_flags(self.renderer._ensure_db(), b * V, h, w, device, slot)
+        bb.forward(x, b, h, w, out, sig, slot=slot, f32_mask=self._f32_mask(), tile_flags=tile_flags)
         if ev is not None:
             ev[2].record()
         return dict(TCO_n=TCO_n, tCR=tCR, TCV_O=TCV_O, KV_crop=KV_crop, K_crop=K_main, boxes_rend=boxes_rend, boxes_crop=boxes_crop, out=out,

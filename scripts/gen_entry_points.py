@@ -22,7 +22,7 @@ DOC = ROOT / "INTEGRATION.md"
 BEGIN = "<!-- BEGIN ENTRY POINTS (generated from include/mp_engine.h by scripts/gen_entry_points.py -- do not edit by hand) -->"
 END = "<!-- END ENTRY POINTS -->"
 
-_DECL = re.compile(r"^(?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?\s*(mp_[A-Za-z0-9_]+)\s*\(")
+_DECL = re.compile(r"^(?:const\s+)?(?:[A-Za-z_][A-Za-z0-9_]*\s+)*[A-Za-z_][A-Za-z0-9_]*\s*\*?\s*(mp_[A-Za-z0-9_]+)\s*\(")
 
 
 def _clean(comment: str) -> str:

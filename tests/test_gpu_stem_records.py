@@ -336,3 +336,58 @@ def test_record_launch_refuses_inconsistent_channel_masks(eng, object_dataset):
         launch(mask, R, None)                                        # depth normalisation without the reference depths
     with pytest.raises(EngineError):
         launch(mask, R, tCR, mode=7)                                 # unknown normalisation mode
+
+
+@pytest.mark.parametrize("K,pool", [(7, True), (7, False), (5, False)])
+def test_stem_background_tiles_take_the_short_walk(eng, K, pool):
+    """Round 5: a stem workgroup whose input patch lies in 8x8-pixel tiles no view reaches (the rasteriser's job flags) walks only the
+    record chunks of the observation crop (mp_conv_stem_xrec_sparse).  Refiner-shaped records (3 fp32-kind + 24 integer channels = 40
+    elements, q_use = 2 of 5 chunks), an "object" blob in the middle of every image, flags derived from the data.  Against the dense walk
+    (same products, the evaluated ones grouped into MFMAs differently: fp32 round-off), against float64, bit-identical when every flag
+    says "geometry", and the background workgroups are counted."""
+    N, nf, nu, H, W, Cout = 3, 3, 24, 96, 128, 64
+    g = torch.Generator().manual_seed(70 + K)
+    x = torch.cat([torch.rand(N, nf, H, W, generator=g), torch.randint(0, 256, (N, nu, H, W), generator=g).float() / 255.0], dim=1)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    for n in range(N):   # geometry only inside an ellipse; image 2 is all background
+        inside = ((yy - 48 - 6 * n) / 22.0) ** 2 + ((xx - 60 + 9 * n) / 30.0) ** 2 < 1.0 if n < 2 else torch.zeros(H, W, dtype=torch.bool)
+        x[n, nf:] *= inside
+    flags = (x[:, nf:] != 0).any(dim=1).view(N, H // 8, 8, W // 8, 8).any(dim=4).any(dim=2).to(torch.uint8).cuda().contiguous()
+    assert 0.05 < flags.float().mean().item() < 0.5 and flags[2].sum().item() == 0
+    w = torch.randn(Cout, nf + nu, K, K, generator=g) * (2.0 / ((nf + nu) * K * K)) ** 0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    pad = K // 2
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    rec = to_records(eng, x, nf, pad)
+    wp = torch.from_numpy(eng.conv_stem_pack_weights(w.numpy(), nf, scale.numpy())).cuda()
+    ws = torch.from_numpy(eng.conv_stem_pack_weights_sparse(w.numpy(), nf, scale.numpy())).cuda()
+    assert ws.numel() < wp.numel() // 2
+    assert eng.conv_stem_pack_weights_sparse(torch.randn(64, 9, K, K).numpy(), 3) is None   # coarse records (16 elements): nothing to skip
+
+    def run(w_sparse, fl):
+        y = eng.padded_nhwc(N, Ho, Wo, Cout, 1, "cuda")
+        q = eng.padded_nhwc(N, Hq, Wq, Cout, 1, "cuda") if pool else None
+        eng.conv_stem_xrec(rec, N, H, W, nf + nu, nf, pad, wp, bias.cuda(), Cout, K, pad, y, 1, relu=True, y_pool=q, pool_border=1,
+                           w_sparse=w_sparse, tile_flags=fl)
+        torch.cuda.synchronize()
+        return y, q
+
+    y_dense, q_dense = run(None, None)
+    eng.profile_begin()
+    eng.conv_stem_bg_stats(reset=True)
+    y_sp, q_sp = run(ws, flags)
+    eng.profile_end()
+    bg, total = eng.conv_stem_bg_stats(reset=True)
+    assert total > 0 and 0.2 * total < bg < total, (bg, total)          # a good part of the workgroups took the short walk, not all
+    y_all, q_all = run(ws, torch.ones_like(flags))                       # every tile "has geometry": the dense walk, bit for bit
+    assert torch.equal(y_all, y_dense) and (not pool or torch.equal(q_all, q_dense))
+    ref = F.relu(F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride=2, padding=pad))
+    sc = max(1.0, ref.abs().max().item())
+    got = eng.padded_view(y_sp, N, Ho, Wo, Cout, 1).permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref).abs().max().item() < 1e-5 * sc
+    assert (y_sp - y_dense).abs().max().item() < 2e-6 * sc              # same exact products, another grouping of the fp32 additions
+    if pool:
+        assert (q_sp - q_dense).abs().max().item() < 2e-6 * sc
+        pref = F.max_pool2d(ref, 3, 2, 1)
+        assert (eng.padded_view(q_sp, N, Hq, Wq, Cout, 1).permute(0, 3, 1, 2).cpu().double() - pref).abs().max().item() < 1e-5 * sc
