@@ -309,17 +309,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // clears the pooled positions that more than one tile contributes to (every pooled row 4k and pooled column 8k: the windows that straddle
-// the 8 x 16 stem tiles), one thread per (position, 4 channels)
+// the 8 x 16 stem tiles), one thread per (such position, 4 channels): the grid enumerates only those positions -- first the rows 4k in
+// full, then column 8k of the other rows (a third of the pooled map; round 4 launched a thread per position and returned from two thirds)
+__host__ __device__ inline int pool_zero_positions(int Hq, int Wq) {
+  const int rows4 = (Hq + TH / 2 - 1) / (TH / 2), cols8 = (Wq + TW / 2 - 1) / (TW / 2);
+  return rows4 * Wq + (Hq - rows4) * cols8;
+}
 __global__ __launch_bounds__(256) void pool_zero_kernel(float* __restrict__ y, int N, int Hq, int Wq, int C, int border) {
   const int c4n = C / 4;
+  const int P = pool_zero_positions(Hq, Wq);
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)N * Hq * Wq * c4n) return;
+  if (idx >= (long)N * P * c4n) return;
   const int c4 = (int)(idx % c4n);
   long t = idx / c4n;
-  const int px = (int)(t % Wq);
-  t /= Wq;
-  const int py = (int)(t % Hq), n = (int)(t / Hq);
-  if ((py % (TH / 2)) != 0 && (px % (TW / 2)) != 0) return;
+  const int pos = (int)(t % P), n = (int)(t / P);
+  const int rows4 = (Hq + TH / 2 - 1) / (TH / 2), cols8 = (Wq + TW / 2 - 1) / (TW / 2);
+  int py, px;
+  if (pos < rows4 * Wq) {
+    py = (pos / Wq) * (TH / 2);
+    px = pos % Wq;
+  } else {   // the k-th row that is not a multiple of 4: k + k / 3 + 1
+    const int q = pos - rows4 * Wq, k = q / cols8;
+    py = k + k / (TH / 2 - 1) + 1;
+    px = (q % cols8) * (TW / 2);
+  }
   *reinterpret_cast<float4*>(y + ((((size_t)n * (Hq + 2 * border) + py + border) * (Wq + 2 * border) + px + border) * C + c4 * 4)) =
       make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -339,7 +352,7 @@ int launch(const Params& p, hipStream_t s, double flops, double bytes, const cha
   }
   if (POOL) {
     ProfScope prof0("pool_zero", 0.0, 16.0 * p.N * (p.Hq / 4 + 1) * p.Wq * p.Cout, s);
-    const long total = (long)p.N * p.Hq * p.Wq * (p.Cout / 4);
+    const long total = (long)p.N * pool_zero_positions(p.Hq, p.Wq) * (p.Cout / 4);
     hipLaunchKernelGGL(pool_zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.ypool, p.N, p.Hq, p.Wq, p.Cout, p.pool_border);
   }
   ProfScope prof(name, flops, bytes, s, executed, 2500.0);

@@ -111,7 +111,8 @@ __device__ __forceinline__ bool tile_touched(const TileTest& t, int tx, int ty) 
 
 __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restrict__ meshes, const int32_t* __restrict__ mesh_ids,
                                                           const float* __restrict__ TCO, const float* __restrict__ K, int h, int w, int ns,
-                                                          int* __restrict__ ws, BinLayout lay, int* __restrict__ counters) {
+                                                          int* __restrict__ ws, BinLayout lay, int* __restrict__ counters,
+                                                          unsigned char* __restrict__ view_flags) {
   extern __shared__ int counts[];  // [2][n_tiles]: counters of the binned / the large pieces, then (in place) exclusive offsets = fill cursors
   __shared__ int partial[2][BIN_THREADS];
   __shared__ unsigned nearest;     // max over the pieces of (bits of the nearest vertex's 1/z, low bit replaced by the piece's orientation flag)
@@ -179,6 +180,9 @@ __global__ __launch_bounds__(BIN_THREADS) void raster_bin(const MeshDev* __restr
     counts_l[i] = run_l;
     tile_off_l[i] = run_l;
     run_l += cl;
+    // does this view reach the tile?  (one byte per (view, tile): what raster_classify ORs over an item's views; an overflowed view's tiles
+    // all count as reached -- its tiles walk every piece)
+    if (view_flags) view_flags[(size_t)view * lay.n_tiles + i] = (c + cl > 0 || overflow) ? 1 : 0;
   }
   if (tid == 0) {
     tile_off[lay.n_tiles] = total;
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
 // ---- compacted launch form: classification of the (item, tile) pairs and the kernel for the pairs no view reaches --------------------------
 // one thread per pair: heavy iff some view of the item has a piece (binned or large) in the tile, or a view's lists overflowed;
 // flags[pair] = 1 | 0, the light pairs are appended to a list (order arbitrary: every job is independent)
-__global__ __launch_bounds__(256) void raster_classify(const int* __restrict__ ws, BinLayout lay, int views_per_item, int n_items,
+__global__ __launch_bounds__(256) void raster_classify(const unsigned char* __restrict__ view_flags, BinLayout lay, int views_per_item, int n_items,
                                                        unsigned char* __restrict__ flags, int* __restrict__ counters, int* __restrict__ light_list) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)n_items * lay.n_tiles;
@@ -832,10 +836,7 @@ __global__ __launch_bounds__(256) void raster_classify(const int* __restrict__ w
   bool heavy = false;
   if (valid) {
     const int item = (int)(idx / lay.n_tiles), tile = (int)(idx - (long)item * lay.n_tiles);
-    for (int r = 0; r < views_per_item; ++r) {
-      const int* hdr = ws + (size_t)(item * views_per_item + r) * lay.view_ints;
-      heavy = heavy || hdr[2] != 0 || hdr[HDR_INTS + tile + 1] != hdr[HDR_INTS + tile] || hdr[lay.off_tl + tile + 1] != hdr[lay.off_tl + tile];
-    }
+    for (int r = 0; r < views_per_item; ++r) heavy = heavy || view_flags[(size_t)(item * views_per_item + r) * lay.n_tiles + tile] != 0;
     flags[idx] = heavy ? 1 : 0;
   }
   const int lane = threadIdx.x & 63;
@@ -1096,14 +1097,15 @@ static BinLayout bin_layout(const mp_mesh_db* db, int h, int w) {
   return lay;
 }
 
-// behind the per-view blocks: [4 counters][light job list: one int per (view, tile)][job flags: one byte per (view, tile)] (items <= views)
+// behind the per-view blocks: [4 counters][light job list: one int per (view, tile)][job flags: one byte per (item, tile), sized for items =
+// views][per-view tile flags: one byte per (view, tile)]
 static size_t job_tail_offset_ints(const BinLayout& lay, int n_views) { return ((size_t)n_views * (size_t)lay.view_ints + 3) & ~(size_t)3; }
 
 extern "C" size_t mp_raster_workspace_bytes(const mp_mesh_db* db, int n_views, int h, int w) {
   if (!db || n_views <= 0 || h <= 0 || w <= 0) return 0;
   const BinLayout lay = bin_layout(db, h, w);
   const size_t pairs = (size_t)n_views * lay.n_tiles;
-  return (job_tail_offset_ints(lay, n_views) + 4 + pairs) * sizeof(int) + ((pairs + 15) & ~(size_t)15);
+  return (job_tail_offset_ints(lay, n_views) + 4 + pairs) * sizeof(int) + 2 * ((pairs + 15) & ~(size_t)15);   // + job flags + per-view tile flags
 }
 
 static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, const float* d_TCO, const float* d_K,
@@ -1134,6 +1136,7 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   int* const counters = (int*)d_ws + job_tail_offset_ints(lay, n_views);
   int* const light_list = counters + 4;
   unsigned char* const job_flags = (unsigned char*)(light_list + (size_t)n_views * lay.n_tiles);
+  unsigned char* const view_flags = job_flags + (((size_t)n_views * lay.n_tiles + 15) & ~(size_t)15);
   const char* compact_env = getenv("MP_RASTER_COMPACT");
   const bool compact = !(compact_env && atoi(compact_env) == 0);
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0, do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
@@ -1166,7 +1169,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
       attr_set = true;
     }
     ProfScope prof("raster_bin", 0.0, (double)n_views * (12.0 * db->max_faces + 12.0 * db->max_verts + 4.0 * lay.n_tiles), s);
-    hipLaunchKernelGGL(raster_bin, dim3(n_views), dim3(BIN_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, h, w, ns, (int*)d_ws, lay, counters);
+    hipLaunchKernelGGL(raster_bin, dim3(n_views), dim3(BIN_THREADS), lds, s, db->d_meshes, d_mesh_ids, d_TCO, d_K, h, w, ns, (int*)d_ws, lay, counters,
+                       compact ? view_flags : (unsigned char*)nullptr);
   }
   const int groups_x = ceil_div(lay.tiles_x, TILE_WAVES);
   const long long n_wg = (long long)n_items * lay.tiles_y * groups_x;
@@ -1211,8 +1215,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   if (compact) {
     ProfScope prof_c("raster_classify", 0.0, (double)n_views * lay.n_tiles * 16.0, s);
     const long total = (long)n_items * lay.n_tiles;
-    hipLaunchKernelGGL(raster_classify, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const int*)d_ws, lay, views_per_item, n_items, job_flags,
-                       counters, light_list);
+    hipLaunchKernelGGL(raster_classify, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const unsigned char*)view_flags, lay, views_per_item,
+                       n_items, job_flags, counters, light_list);
   }
   const int sel = depthrec ? (ns == 4 ? 16 : 17) + (full ? 2 : 0) : (ns == 4 ? 8 : 0) | (xrec ? 4 : f16 ? 2 : 0) | (full ? 1 : 0);
   {
