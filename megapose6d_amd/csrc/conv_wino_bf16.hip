@@ -29,6 +29,11 @@
 namespace mp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef MP_WINO_PK
+#define MP_WINO_PK 1   // packed-fp32 transform / split arithmetic in the K loop (0: the round-4/5 scalar form, for A/B builds)
+#endif
 
 // v_perm_b32 selector 0x07060302: {hi16(second arg) in the low half, hi16(first arg) in the high half}
 __device__ __forceinline__ unsigned pack_hi16(unsigned e1, unsigned e0) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
@@ -103,15 +108,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (!(DIAG & 4)) DST[(K) / 3][(K) % 3] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (ST) * UB_STEP_BYTES + (FI) * UB_F_BYTES + (K) * 1024, 0);
 #define WB_LOAD_PATCH1(A, B, CS) if (!(DIAG & 2)) patch[A][B] = buf4(x_rsrc, x_voff, (CS) + (A) * row_bytes + (B) * pix_bytes);
   // transform row A of the patch in registers: T(A, b) forms the row combination (B^T d)[A][b]; O(A, col) one frequency plane -> LDS
+#if MP_WINO_PK
+  // packed fp32 (v_pk_add_f32: two lanes of fp32 per instruction, IEEE, same results): half the VALU issue slots of the transform
+#define WB_F4ASM(OP, D, X, Y)                                                                             \
+  {                                                                                                       \
+    f32x2 dlo_, dhi_;                                                                                     \
+    asm volatile("v_pk_add_f32 %0, %2, %4 " OP "\n\tv_pk_add_f32 %1, %3, %5 " OP                          \
+                 : "=&v"(dlo_), "=&v"(dhi_)                                                               \
+                 : "v"(f32x2{X.x, X.y}), "v"(f32x2{X.z, X.w}), "v"(f32x2{Y.x, Y.y}), "v"(f32x2{Y.z, Y.w}));  \
+    D = make_float4(dlo_.x, dlo_.y, dhi_.x, dhi_.y);                                                      \
+  }
+#define WB_OP_SUB "neg_lo:[0,1] neg_hi:[0,1]"
+#define WB_OP_ADD ""
+#else
 #define WB_F4ASM(OP, D, X, Y)                                                                             \
   asm volatile(OP " %0, %4, %8\n\t" OP " %1, %5, %9\n\t" OP " %2, %6, %10\n\t" OP " %3, %7, %11"           \
                : "=&v"(D.x), "=&v"(D.y), "=&v"(D.z), "=&v"(D.w)                                            \
                : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
+#define WB_OP_SUB "v_sub_f32"
+#define WB_OP_ADD "v_add_f32"
+#endif
 #define WB_TR_T(A, B)                                                                                    \
-  if (DIAG & 2) {} else if ((A) == 0) { WB_F4ASM("v_sub_f32", trw[B], patch[0][B], patch[2][B]) }                              \
-  else if ((A) == 1) { WB_F4ASM("v_add_f32", trw[B], patch[1][B], patch[2][B]) }                         \
-  else if ((A) == 2) { WB_F4ASM("v_sub_f32", trw[B], patch[2][B], patch[1][B]) }                         \
-  else { WB_F4ASM("v_sub_f32", trw[B], patch[1][B], patch[3][B]) }
+  if (DIAG & 2) {} else if ((A) == 0) { WB_F4ASM(WB_OP_SUB, trw[B], patch[0][B], patch[2][B]) }                              \
+  else if ((A) == 1) { WB_F4ASM(WB_OP_ADD, trw[B], patch[1][B], patch[2][B]) }                         \
+  else if ((A) == 2) { WB_F4ASM(WB_OP_SUB, trw[B], patch[2][B], patch[1][B]) }                         \
+  else { WB_F4ASM(WB_OP_SUB, trw[B], patch[1][B], patch[3][B]) }
   // Exact truncation split of the four elements of raw[I][H] (elements 4H .. 4H+3 of fragment I) into the three pieces of AN, spread over
   // four slots so that no instruction of a slot depends on another one of the same slot (one wave per SIMD issues in order: a dependent
   // VALU pair stalls for the pipeline latency, and that stall comes straight out of the MFMA shadow):
@@ -128,10 +149,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w), "s"(0x07060302u));                     \
     AN[I][0][2 * (H)] = p0_; AN[I][0][2 * (H) + 1] = p1_;                                               \
   }
+#if MP_WINO_PK
+#define WB_SP1(I, H)                                                                                     \
+  if (!(DIAG & 1)) {                                                                                     \
+    f32x2 lo_, hi_;                                                                                      \
+    asm volatile("v_pk_add_f32 %0, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %3, %5 neg_lo:[0,1] neg_hi:[0,1]"   \
+                 : "=&v"(lo_), "=&v"(hi_)                                                                \
+                 : "v"(f32x2{raw[I][H].x, raw[I][H].y}), "v"(f32x2{raw[I][H].z, raw[I][H].w}),           \
+                   "v"(f32x2{__uint_as_float(sm0), __uint_as_float(sm1)}), "v"(f32x2{__uint_as_float(sm2), __uint_as_float(sm3)}));  \
+    sr0 = lo_.x; sr1 = lo_.y; sr2 = hi_.x; sr3 = hi_.y;                                                  \
+  }
+#else
 #define WB_SP1(I, H)                                                                                     \
   if (!(DIAG & 1)) asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11"                    \
                : "=&v"(sr0), "=&v"(sr1), "=&v"(sr2), "=&v"(sr3)                                                                   \
                : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w), "v"(sm0), "v"(sm1), "v"(sm2), "v"(sm3));
+#endif
 #define WB_SP2(AN, I, H)                                                                                 \
   if (!(DIAG & 1)) {                                                                                                     \
     unsigned p0_, p1_;                                                                                  \
@@ -141,10 +174,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3), "s"(0x07060302u));                                                     \
     AN[I][1][2 * (H)] = p0_; AN[I][1][2 * (H) + 1] = p1_;                                               \
   }
+#if MP_WINO_PK
+#define WB_SP3()                                                                                         \
+  if (!(DIAG & 1)) {                                                                                     \
+    f32x2 lo_, hi_;                                                                                      \
+    asm volatile("v_pk_add_f32 %0, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %3, %5 neg_lo:[0,1] neg_hi:[0,1]"   \
+                 : "=&v"(lo_), "=&v"(hi_)                                                                \
+                 : "v"(f32x2{sr0, sr1}), "v"(f32x2{sr2, sr3}),                                           \
+                   "v"(f32x2{__uint_as_float(sm0), __uint_as_float(sm1)}), "v"(f32x2{__uint_as_float(sm2), __uint_as_float(sm3)}));  \
+    sq0 = lo_.x; sq1 = lo_.y; sq2 = hi_.x; sq3 = hi_.y;                                                  \
+  }
+#else
 #define WB_SP3()                                                                                         \
   if (!(DIAG & 1)) asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11"                    \
                : "=&v"(sq0), "=&v"(sq1), "=&v"(sq2), "=&v"(sq3)                                                                   \
                : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3), "v"(sm0), "v"(sm1), "v"(sm2), "v"(sm3));
+#endif
 #define WB_SP4(AN, I, H)                                                                                 \
   if (!(DIAG & 1)) {                                                                                                     \
     unsigned p0_, p1_;                                                                                  \
@@ -179,10 +224,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   WB_M(15, AC, UC) WB_SB WB_SP3() WB_SB
   // one frequency plane of the transform row in flight -> tplane (written to LDS one slot later: the store does not wait for its data)
 #define WB_TR_P(COL)                                                                                     \
-  if (DIAG & 2) {} else if ((COL) == 0) { WB_F4ASM("v_sub_f32", tplane, trw[0], trw[2]) }                                      \
-  else if ((COL) == 1) { WB_F4ASM("v_add_f32", tplane, trw[1], trw[2]) }                                 \
-  else if ((COL) == 2) { WB_F4ASM("v_sub_f32", tplane, trw[2], trw[1]) }                                 \
-  else { WB_F4ASM("v_sub_f32", tplane, trw[1], trw[3]) }
+  if (DIAG & 2) {} else if ((COL) == 0) { WB_F4ASM(WB_OP_SUB, tplane, trw[0], trw[2]) }                                      \
+  else if ((COL) == 1) { WB_F4ASM(WB_OP_ADD, tplane, trw[1], trw[2]) }                                 \
+  else if ((COL) == 2) { WB_F4ASM(WB_OP_SUB, tplane, trw[2], trw[1]) }                                 \
+  else { WB_F4ASM(WB_OP_SUB, tplane, trw[1], trw[3]) }
 #define WB_TR_W(A, COL, VW) if (!(DIAG & 2)) *reinterpret_cast<float4*>((VW) + ((A) * 4 + (COL)) * (WT * WCK)) = tplane;
   // slots 16..35, transform kind: rows R0, R1 of the next step's input transform, then the raw fragment reads of the point after next
 #define WB_TAIL_TR(AC, AN, UC, R0, R1, VW, VBN, N2FI)                                                    \
@@ -256,12 +301,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   {   // accumulator reset by the matrix pipe itself (0 x 0 + 0: 16 instructions instead of 256 register writes right before the loop;
-      // asm volatile: as a builtin the 16 identical products are merged into one and copied)
+      // asm volatile: as a builtin the 16 identical products are merged into one and copied).
+      // `s_nop 1` INSIDE the string: the compiler materialises z4 with v_mov right in front of the statement, and a VALU write of a register
+      // an MFMA reads as A / B needs two wait states that the hazard recogniser does not insert for a consumer inside inline asm.  Without
+      // them the first MFMA multiplies whatever the registers held BEFORE the v_mov -- rounds 4 / 5 shipped that way and were right only
+      // because the allocator happened to pick registers that held small integers (bf16 pairs whose products underflow to 0); any edit that
+      // moved z4 to never-written registers (stale data of the previous kernel) gave inf / NaN on every shape: DESIGN.md 3.1.1, round 6.
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     _Pragma("unroll") for (int fi = 0; fi < 4; ++fi)
       _Pragma("unroll") for (int i = 0; i < 2; ++i)
         _Pragma("unroll") for (int j = 0; j < 2; ++j)
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4));
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4));
   }
   WB_SB
 #define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
@@ -274,6 +324,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   WB_SPLIT4(AA, 0, 0) WB_SPLIT4(AA, 0, 1) WB_SPLIT4(AA, 1, 0) WB_SPLIT4(AA, 1, 1)
   WB_READ_RAW1(vr, 1, 0) WB_READ_RAW1(vr, 1, 1) WB_READ_RAW1(vr, 1, 2) WB_READ_RAW1(vr, 1, 3)
 
+#ifdef MP_WINO_PERMUTE
+  // TEST BUILD ONLY (tests/test_gpu_wino_permuted.py): MP_WINO_PERMUTE extra values are kept live across the K loop (read from the bias
+  // vector before it, folded into a never-taken store after it), so that the register allocator lays the loop's vector registers out
+  // differently from the product build -- same opcodes, another assignment.  The kernel must not care: the parity tests run on this build too.
+  u32x4 perm_live[MP_WINO_PERMUTE];
+  {
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 4096, 0x00020000);
+    _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) perm_live[k] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, lane * 16, k * 1024, 0);
+  }
+#endif
   // ---- K loop: 16 input channels per step, four frequency points per wave and step, 36 MFMAs per point.  Point f multiplies the
   //      fragments split during point f-1 (raw fp32 read during point f-2) with the weights requested during point f-1.  ONE barrier per
   //      step, between points 1 and 2: V of this step is last read in point 1 (for point 3), V of the next step is complete after point 1
@@ -288,6 +348,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* vwn = vw + (buf ^ 1) * WV_STAGE;
     const int cs_patch = (st + 2 < ns ? st + 2 : ns - 1) * (WCK * 4);
     const int st_next = st + 1 < ns ? st + 1 : st;   // (the last step harmlessly re-requests its own first weights)
+#ifdef MP_WINO_PERMUTE
+    _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) asm volatile("" : "+v"(perm_live[k]));   // (in registers, not in scratch)
+#endif
     { constexpr int fi = 0; WB_HEAD(AA, AB, Ua, Ub, st, 1) WB_TAIL_TR(AA, AB, Ua, 0, 1, vwn, vb, 2) }
     { constexpr int fi = 1; WB_HEAD(AB, AA, Ub, Ua, st, 2) WB_TAIL_TR(AB, AA, Ub, 2, 3, vwn, vb, 3) }
     __syncthreads();
@@ -304,6 +367,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     atomicAdd(&g_wb_clk[2], (unsigned long long)ns);
   }
   const unsigned long long clk_epi = __builtin_readcyclecounter();
+#ifdef MP_WINO_PERMUTE
+  {
+    unsigned fold = 0;
+    _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) fold |= perm_live[k].x ^ perm_live[k].y ^ perm_live[k].z ^ perm_live[k].w;
+    if (p.n_steps < 0) tile_tab[tid & 127] = (int)fold;   // never taken (n_steps >= 1): keeps the values alive to here
+  }
+#endif
   __syncthreads();   // (the epilogue reuses the V stages)
 #undef WB_TAIL_PL
 #undef WB_TAIL_TR
@@ -321,6 +391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WB_TR_ROW
 #undef WB_TR_T
 #undef WB_F4ASM
+#undef WB_OP_SUB
+#undef WB_OP_ADD
 #undef WB_LOAD_PATCH1
 #undef WB_LOAD_U1
 #undef WB_SB

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Variant builds of libmp_engine.so that differ ONLY in conv_wino_bf16.o (the other objects are the product build's), for the round-6
+# root-cause experiment on the bf16x9 Winograd kernel and for tests/test_gpu_wino_permuted.py:
+#   _build/wperm3, wperm8   product source + -DMP_WINO_PERMUTE=3 / 8 (deliberately different vector-register assignment in the K loop)
+#   _build/r5bad            the archived round-5 "L2 prefetch" source exactly as it failed (profiles/r05_wino_prefetch_ab.hip.txt)
+#   _build/r5badfix         the same source + the two wait states in front of the accumulator-reset MFMAs (the round-6 fix), nothing else
+# Usage: bash scripts/microbench/build_wino_variants.sh   (after make -C megapose6d_amd/csrc)
+set -e
+cd "$(dirname "$0")/../.."
+C=megapose6d_amd/csrc
+B=scripts/microbench/_build
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -Wall -Wno-unused-function"
+OTHERS=$(ls $C/*.o | grep -v conv_wino_bf16.o)
+link() { mkdir -p $B/$1; /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/$1/libmp_engine.so $OTHERS $B/$1/conv_wino_bf16.o; }
+for n in 3 8; do
+  mkdir -p $B/wperm$n
+  /opt/rocm/bin/hipcc $F -DMP_WINO_PERMUTE=$n -c $C/conv_wino_bf16.hip -o $B/wperm$n/conv_wino_bf16.o
+  link wperm$n
+done
+if [ "$1" = "r5" ]; then
+  for v in r5bad r5badfix; do
+    mkdir -p $B/$v/src
+    cp $C/*.h $B/$v/src/
+    sed -i 's/int telemetry; /int telemetry; int prefetch_stride; /' $B/$v/src/wino_common.h
+    cp profiles/r05_wino_prefetch_ab.hip.txt $B/$v/src/conv_wino_bf16.hip
+    if [ $v = r5badfix ]; then
+      sed -i 's/asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0"/asm volatile("s_nop 1\\n\\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0"/' $B/$v/src/conv_wino_bf16.hip
+      grep -c 's_nop 1\\n\\tv_mfma' $B/$v/src/conv_wino_bf16.hip
+    fi
+    /opt/rocm/bin/hipcc $F -c $B/$v/src/conv_wino_bf16.hip -o $B/$v/conv_wino_bf16.o
+    link $v
+  done
+fi
+ls -la $B/*/libmp_engine.so

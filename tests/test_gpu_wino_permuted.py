@@ -1,0 +1,33 @@
+"""GPU: conv3x3_wino_bf16x9 gives the same (tested) results when the register allocator lays its K loop out differently.
+
+Round 5's only evidence for the kernel was "passes with the register assignment it was tuned with" (any other one returned inf / NaN);
+round 6 found and fixed the cause (an unpadded VALU -> MFMA-operand hazard in the accumulator reset, tests/test_wino_isa_hazards_cpu.py).
+This test is the permutation test the kernel previously could not pass: the Winograd parity tests of tests/test_gpu_kernels.py -- every
+shape / epilogue against a float64 convolution at 2e-5, and the operands at the ends of the fp32 range -- run again in a child process on
+libmp_engine builds compiled with -DMP_WINO_PERMUTE=3 / 8 (extra values held in vector registers across the loop: another assignment,
+`test_permuted_builds_really_have_another_k_loop_register_assignment`)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+BUILD = ROOT / "scripts" / "microbench" / "_build"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 8])
+def test_winograd_parity_holds_under_a_permuted_register_assignment(n):
+    lib = BUILD / f"wperm{n}" / "libmp_engine.so"
+    if not lib.exists():   # (normally built by __graft_entry__.build(); hipcc is on the GPU box too)
+        subprocess.run(["bash", str(ROOT / "scripts" / "microbench" / "build_wino_variants.sh")], check=True, cwd=ROOT)
+    assert lib.exists(), lib
+    env = dict(os.environ, MP_ENGINE_LIB=str(lib))
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "(winograd_conv_matches_torch_fp32 and bf16x9) or (exact_piece and bf16x9)"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
