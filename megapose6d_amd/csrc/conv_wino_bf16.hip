@@ -32,7 +32,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef MP_WINO_PK
-#define MP_WINO_PK 1   // packed-fp32 transform / split arithmetic in the K loop (0: the round-4/5 scalar form, for A/B builds)
+#define MP_WINO_PK 0   // 1: packed-fp32 (v_pk_add_f32) transform / split arithmetic in the K loop -- measured SLOWER (round 6: 7.5 k vs 6.4 k cycles per step, profiles/r06_wino_kloop_experiments.txt): a pk op costs more than the two scalar ops it replaces
 #endif
 
 // v_perm_b32 selector 0x07060302: {hi16(second arg) in the low half, hi16(first arg) in the high half}
@@ -48,6 +48,16 @@ constexpr int UB_STEP_BYTES = 16 * UB_F_BYTES;    // 96 KB per 16-channel step
 // Clock telemetry (as conv.hip's): every 64th workgroup adds the shader cycles (s_memtime), the 100 MHz real-time ticks (s_memrealtime)
 // and the number of steps of its K loop: mp_conv_wino_bf16_clock reports the effective shader clock and the cycles per 16-channel step.
 __device__ unsigned long long g_wb_clk[6];   // K-loop cycles, K-loop 100 MHz ticks, steps | prologue cycles, epilogue cycles, sampled workgroups
+#ifdef MP_WINO_PHASES
+// Profiling build only (scripts/microbench/build_wino_variants.sh phases): cycle stamps inside the prologue and the epilogue of every 64th
+// workgroup, relative to the workgroup's start / the end of its K loop: [0..4] prologue (requests issued, first patch row transformed,
+// V of step 0 written, barrier passed, first fragments split = loop entry), [5..8] epilogue (exchange written, barrier passed, stores
+// issued, stores retired), [9] samples.
+__device__ unsigned long long g_wb_phase[10];
+#define WB_PHASE(K, T0) if (ph_sample) atomicAdd(&g_wb_phase[K], __builtin_readcyclecounter() - (T0));
+#else
+#define WB_PHASE(K, T0)
+#endif
 
 // DIAG (timing experiments only, wrong results; MP_WINO_DIAG): 1 = no split work, 2 = no patch requests / transform, 4 = no weight requests
 template <int DIAG>
@@ -58,6 +68,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const unsigned long long clk_start = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef MP_WINO_PHASES
+  const bool ph_sample = (blockIdx.x & 63) == 0 && threadIdx.x == 0;
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int cb = wg % p.n_cblocks;      // channel block fastest: the workgroups that share an input tile set run together
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   unsigned sm0, sm1, sm2, sm3;            // the split in flight: masked values,
   float sr0, sr1, sr2, sr3, sq0, sq1, sq2, sq3;   // first and second remainders of the four elements
   float4 trw[4], tplane;      // row combination of the transform row in flight, the plane on its way to LDS
-  if (DIAG & 7) {   // (timing experiments: whatever the skipped work would have produced just has to be defined)
+  if (DIAG & (7 | 32 | 64 | 128)) {   // (timing experiments: whatever the skipped work would have produced just has to be defined)
     _Pragma("unroll") for (int i = 0; i < 2; ++i)
       _Pragma("unroll") for (int q = 0; q < 3; ++q) { AA[i][q] = AB[i][q] = Ua[i][q] = Ub[i][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }
     _Pragma("unroll") for (int a = 0; a < 4; ++a) { trw[a] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WB_SB __builtin_amdgcn_sched_barrier(0);
 #define WB_LOAD_U1(DST, ST, FI, K) \
   if (!(DIAG & 4)) DST[(K) / 3][(K) % 3] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (ST) * UB_STEP_BYTES + (FI) * UB_F_BYTES + (K) * 1024, 0);
-#define WB_LOAD_PATCH1(A, B, CS) if (!(DIAG & 2)) patch[A][B] = buf4(x_rsrc, x_voff, (CS) + (A) * row_bytes + (B) * pix_bytes);
+#define WB_LOAD_PATCH1(A, B, CS) if (!(DIAG & (2 | 128))) patch[A][B] = buf4(x_rsrc, x_voff, (CS) + (A) * row_bytes + (B) * pix_bytes);
   // transform row A of the patch in registers: T(A, b) forms the row combination (B^T d)[A][b]; O(A, col) one frequency plane -> LDS
 #if MP_WINO_PK
   // packed fp32 (v_pk_add_f32: two lanes of fp32 per instruction, IEEE, same results): half the VALU issue slots of the transform
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WB_OP_ADD "v_add_f32"
 #endif
 #define WB_TR_T(A, B)                                                                                    \
-  if (DIAG & 2) {} else if ((A) == 0) { WB_F4ASM(WB_OP_SUB, trw[B], patch[0][B], patch[2][B]) }                              \
+  if (DIAG & (2 | 64)) {} else if ((A) == 0) { WB_F4ASM(WB_OP_SUB, trw[B], patch[0][B], patch[2][B]) }                              \
   else if ((A) == 1) { WB_F4ASM(WB_OP_ADD, trw[B], patch[1][B], patch[2][B]) }                         \
   else if ((A) == 2) { WB_F4ASM(WB_OP_SUB, trw[B], patch[2][B], patch[1][B]) }                         \
   else { WB_F4ASM(WB_OP_SUB, trw[B], patch[1][B], patch[3][B]) }
@@ -224,11 +237,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   WB_M(15, AC, UC) WB_SB WB_SP3() WB_SB
   // one frequency plane of the transform row in flight -> tplane (written to LDS one slot later: the store does not wait for its data)
 #define WB_TR_P(COL)                                                                                     \
-  if (DIAG & 2) {} else if ((COL) == 0) { WB_F4ASM(WB_OP_SUB, tplane, trw[0], trw[2]) }                                      \
+  if (DIAG & (2 | 64)) {} else if ((COL) == 0) { WB_F4ASM(WB_OP_SUB, tplane, trw[0], trw[2]) }                                      \
   else if ((COL) == 1) { WB_F4ASM(WB_OP_ADD, tplane, trw[1], trw[2]) }                                 \
   else if ((COL) == 2) { WB_F4ASM(WB_OP_SUB, tplane, trw[2], trw[1]) }                                 \
   else { WB_F4ASM(WB_OP_SUB, tplane, trw[1], trw[3]) }
-#define WB_TR_W(A, COL, VW) if (!(DIAG & 2)) *reinterpret_cast<float4*>((VW) + ((A) * 4 + (COL)) * (WT * WCK)) = tplane;
+#define WB_TR_W(A, COL, VW) if (!(DIAG & (2 | 32))) *reinterpret_cast<float4*>((VW) + ((A) * 4 + (COL)) * (WT * WCK)) = tplane;
   // slots 16..35, transform kind: rows R0, R1 of the next step's input transform, then the raw fragment reads of the point after next
 #define WB_TAIL_TR(AC, AN, UC, R0, R1, VW, VBN, N2FI)                                                    \
   WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_TR_T(R0, 0) WB_SB                                           \
@@ -314,11 +327,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4));
   }
   WB_SB
+  WB_PHASE(0, clk_start)
 #define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
-  WB_TR_ROW(0, vw) WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  WB_TR_ROW(0, vw) WB_PHASE(1, clk_start) WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  WB_PHASE(2, clk_start)
   _Pragma("unroll") for (int a = 0; a < 4; ++a)
     _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = pnext[a][bb];
   __syncthreads();
+  WB_PHASE(3, clk_start)
   WB_READ_RAW1(vr, 0, 0) WB_READ_RAW1(vr, 0, 1) WB_READ_RAW1(vr, 0, 2) WB_READ_RAW1(vr, 0, 3)
 #define WB_SPLIT4(AN, I, H) WB_SP0(AN, I, H) WB_SP1(I, H) WB_SP2(AN, I, H) WB_SP3() WB_SP4(AN, I, H)
   WB_SPLIT4(AA, 0, 0) WB_SPLIT4(AA, 0, 1) WB_SPLIT4(AA, 1, 0) WB_SPLIT4(AA, 1, 1)
@@ -338,6 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //      fragments split during point f-1 (raw fp32 read during point f-2) with the weights requested during point f-1.  ONE barrier per
   //      step, between points 1 and 2: V of this step is last read in point 1 (for point 3), V of the next step is complete after point 1
   //      (its transform rides in points 0 and 1) and first read in point 2.
+  WB_PHASE(4, clk_start)
   const bool clk_sample = p.telemetry != 0 && (blockIdx.x & 63) == 0 && tid == 0;
   unsigned long long clk_c0 = 0, clk_r0 = 0;
   if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_wb_clk[3], clk_c0 - clk_start); }
@@ -443,7 +460,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           sw[WT * WCOUT + row * WCOUT + j * 32] = (m1 - m2) - m3;
         }
   }
+  WB_PHASE(5, clk_epi)
   __syncthreads();
+  WB_PHASE(6, clk_epi)
   const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
   const bool has_res = p.residual != nullptr, relu = p.relu != 0, has_act = p.y_act != nullptr;
@@ -484,6 +503,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
   }
+#ifdef MP_WINO_PHASES
+  WB_PHASE(7, clk_epi)
+  if (ph_sample) { __builtin_amdgcn_s_waitcnt(0); WB_PHASE(8, clk_epi) atomicAdd(&g_wb_phase[9], 1ull); }
+#endif
   if (clk_sample) {
     __builtin_amdgcn_s_waitcnt(0);   // the stores are out
     atomicAdd(&g_wb_clk[4], __builtin_readcyclecounter() - clk_epi);
@@ -564,6 +587,17 @@ extern "C" int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogu
   return MP_OK;
 }
 
+#ifdef MP_WINO_PHASES
+extern "C" int mp_conv_wino_bf16_phase_probe(double* out9, int reset) {   // average cycle stamps per sampled workgroup (profiling build only)
+  unsigned long long h[10];
+  MP_CHECK_HIP(hipDeviceSynchronize());
+  MP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wb_phase), sizeof(h)));
+  for (int k = 0; k < 9; ++k) out9[k] = h[9] ? (double)h[k] / (double)h[9] : 0.0;
+  if (reset) { const unsigned long long z[10] = {0}; MP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wb_phase), z, sizeof(z))); }
+  return MP_OK;
+}
+#endif
+
 extern "C" int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int reset) {
   unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
   MP_CHECK_HIP(hipDeviceSynchronize());
@@ -606,12 +640,9 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
     MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
 #ifdef MP_CONV_EXPERIMENTS
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+#define WB_DIAG_ATTR(D) MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    WB_DIAG_ATTR(1) WB_DIAG_ATTR(2) WB_DIAG_ATTR(4) WB_DIAG_ATTR(7) WB_DIAG_ATTR(8) WB_DIAG_ATTR(16) WB_DIAG_ATTR(32) WB_DIAG_ATTR(64) WB_DIAG_ATTR(128)
+#undef WB_DIAG_ATTR
 #endif
     attr_dev = dev;
   }
@@ -629,13 +660,9 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   ProfScope prof("conv3x3_wino_bf16x9<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout)) + 6.0 * 16.0 * d->C * d->Cout, s, executed, 2500.0);
 #ifdef MP_CONV_EXPERIMENTS
   const int diag = getenv("MP_WINO_DIAG") ? atoi(getenv("MP_WINO_DIAG")) : 0;
-  if (diag == 1) hipLaunchKernelGGL(conv3x3_wino_bf16x9<1>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
-  else if (diag == 2) hipLaunchKernelGGL(conv3x3_wino_bf16x9<2>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
-  else if (diag == 4) hipLaunchKernelGGL(conv3x3_wino_bf16x9<4>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
-  else if (diag == 7) hipLaunchKernelGGL(conv3x3_wino_bf16x9<7>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
-  else if (diag == 8) hipLaunchKernelGGL(conv3x3_wino_bf16x9<8>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
-  else if (diag == 16) hipLaunchKernelGGL(conv3x3_wino_bf16x9<16>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
-  else
+#define WB_DIAG_LAUNCH(D) if (diag == D) hipLaunchKernelGGL(conv3x3_wino_bf16x9<D>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p); else
+  WB_DIAG_LAUNCH(1) WB_DIAG_LAUNCH(2) WB_DIAG_LAUNCH(4) WB_DIAG_LAUNCH(7) WB_DIAG_LAUNCH(8) WB_DIAG_LAUNCH(16) WB_DIAG_LAUNCH(32) WB_DIAG_LAUNCH(64) WB_DIAG_LAUNCH(128)
+#undef WB_DIAG_LAUNCH
 #endif
   hipLaunchKernelGGL(conv3x3_wino_bf16x9<0>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
   MP_CHECK_HIP(hipGetLastError());

@@ -2,6 +2,7 @@
 # Variant builds of libmp_engine.so that differ ONLY in conv_wino_bf16.o (the other objects are the product build's), for the round-6
 # root-cause experiment on the bf16x9 Winograd kernel and for tests/test_gpu_wino_permuted.py:
 #   _build/wperm3, wperm8   product source + -DMP_WINO_PERMUTE=3 / 8 (deliberately different vector-register assignment in the K loop)
+#   _build/pk1, phases, exp      (argument `ab`) A/B / profiling builds of round 6
 #   _build/r5bad            the archived round-5 "L2 prefetch" source exactly as it failed (profiles/r05_wino_prefetch_ab.hip.txt)
 #   _build/r5badfix         the same source + the two wait states in front of the accumulator-reset MFMAs (the round-6 fix), nothing else
 # Usage: bash scripts/microbench/build_wino_variants.sh   (after make -C megapose6d_amd/csrc)
@@ -17,6 +18,14 @@ for n in 3 8; do
   /opt/rocm/bin/hipcc $F -DMP_WINO_PERMUTE=$n -c $C/conv_wino_bf16.hip -o $B/wperm$n/conv_wino_bf16.o
   link wperm$n
 done
+if [ "$1" = "ab" ]; then   # A/B and profiling builds of the round: pk1 = packed-fp32 transform / split arithmetic, phases = cycle stamps
+  for v in "pk1 -DMP_WINO_PK=1" "phases -DMP_WINO_PHASES" "exp -DMP_CONV_EXPERIMENTS"; do
+    set -- $v; n=$1; shift
+    mkdir -p $B/$n
+    /opt/rocm/bin/hipcc $F "$@" -c $C/conv_wino_bf16.hip -o $B/$n/conv_wino_bf16.o
+    link $n
+  done
+fi
 if [ "$1" = "r5" ]; then
   for v in r5bad r5badfix; do
     mkdir -p $B/$v/src

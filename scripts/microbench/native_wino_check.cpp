@@ -4,6 +4,7 @@
 // then the config-2 layer shapes (576 rows) timed back to back with the direct kernel.
 // Build: hipcc -O2 -std=c++17 --offload-arch=gfx950 -Iinclude scripts/microbench/native_wino_check.cpp \
 //              -o scripts/microbench/_build/native_wino_check -Lmegapose6d_amd -lmp_engine -Wl,-rpath,'$ORIGIN/../../../megapose6d_amd'
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -162,7 +163,7 @@ static int run_case(const Case& s, int* n_bad) {
     for (int r = 0; r < reps; ++r) MP_OKAY(mp_conv3x3_wino_bf16_nhwc(&g, d_ub, nullptr));
     HIP_OK(hipEventRecord(e3, nullptr));
     if (getenv("MP_WINO_DIAG_SWEEP")) {   // timing experiments of an MP_CONV_EXPERIMENTS build of the library (results of diag != 0 are wrong)
-      for (int diag : {0, 8, 16, 1, 2, 4, 7}) {
+      for (int diag : {0, 1, 2, 4, 7, 32, 64, 128}) {
         char buf[8];
         snprintf(buf, sizeof(buf), "%d", diag);
         setenv("MP_WINO_DIAG", buf, 1);
@@ -178,7 +179,7 @@ static int run_case(const Case& s, int* n_bad) {
         HIP_OK(hipEventElapsedTime(&ms, a0, a1));
         double mhz = 0, cps = 0;
         MP_OKAY(mp_conv_wino_bf16_clock(&mhz, &cps, 1));
-        printf("DIAG %-34s | diag %d (1 no split, 2 no patch/transform, 4 no weight loads, 8 / 16 wave skew 64 / 128 cycles): %7.3f ms, %6.0f MHz, %7.0f cycles per step = %5.1f per MFMA\n",
+        printf("DIAG %-34s | diag %d (1 no split, 2 no patch/transform, 4 no weight loads, 32 no V writes, 64 no transform arithmetic, 128 no patch requests): %7.3f ms, %6.0f MHz, %7.0f cycles per step = %5.1f per MFMA\n",
                s.name, diag, ms / reps, mhz, cps, cps / 144.0);
       }
       unsetenv("MP_WINO_DIAG");
@@ -197,6 +198,14 @@ static int run_case(const Case& s, int* n_bad) {
     {
       double mhz = 0, cps = 0, pro = 0, epi = 0;
       MP_OKAY(mp_conv_wino_bf16_phases(&pro, &epi));
+      {   // profiling builds (-DMP_WINO_PHASES) export finer stamps
+        typedef int (*probe_fn)(double*, int);
+        probe_fn probe = (probe_fn)dlsym(RTLD_DEFAULT, "mp_conv_wino_bf16_phase_probe");
+        double ph[9];
+        if (probe && probe(ph, 1) == 0)
+          printf("PHASE %-33s | prologue: requests out %5.0f, row 0 transformed %5.0f, V written %5.0f, barrier %5.0f, loop entry %5.0f | epilogue: exchange written %5.0f, barrier %5.0f, stores issued %5.0f, retired %5.0f\n",
+                 s.name, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8]);
+      }
       MP_OKAY(mp_conv_wino_bf16_clock(&mhz, &cps, 1));
       printf("CLK  %-34s | bf16x9 K loop: %6.0f MHz, %7.0f cycles per 16-channel step = %5.1f per MFMA; per workgroup: prologue %6.0f, K loop %7.0f, epilogue %6.0f cycles\n",
              s.name, mhz, cps, cps / 144.0, pro, cps * (s.C / 16), epi);
