@@ -31,9 +31,9 @@ namespace mp {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef MP_WINO_PK
-#define MP_WINO_PK 0   // 1: packed-fp32 (v_pk_add_f32) transform / split arithmetic in the K loop -- measured SLOWER (round 6: 7.5 k vs 6.4 k cycles per step, profiles/r06_wino_kloop_experiments.txt): a pk op costs more than the two scalar ops it replaces
-#endif
+// (round 6: a packed-fp32 form of the transform / split arithmetic -- v_pk_add_f32, 653 instead of 781 instructions per step -- was built
+//  and measured SLOWER, 7.5 k vs 6.4 k cycles per step: one v_pk_add_f32 in an MFMA gap costs 17 cycles, five v_sub_f32 cost 1.5;
+//  profiles/r06_wino_kloop_experiments.txt.  v_dot2_f32_bf16 costs the same 17, a ds_write_b128 20, SALU beyond three per gap 8 each.)
 
 // v_perm_b32 selector 0x07060302: {hi16(second arg) in the low half, hi16(first arg) in the high half}
 __device__ __forceinline__ unsigned pack_hi16(unsigned e1, unsigned e0) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
@@ -44,6 +44,9 @@ __device__ constexpr int WB_PA[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}, WB_PB[9] = {2, 
 
 constexpr int UB_F_BYTES = 2 * 3 * 1024;          // one frequency point of one step: [cout block j][piece][lane][16 B]
 constexpr int UB_STEP_BYTES = 16 * UB_F_BYTES;    // 96 KB per 16-channel step
+// LDS: the two V stages (128 KB) + the tile table during the K loop; the exchange S[4 waves][2][64 tiles][72] (144 KB) in the epilogue
+constexpr size_t WB_LDS_BYTES = (size_t)4 * 2 * WT * 72 * sizeof(float);
+static_assert(WB_LDS_BYTES >= WINO_LDS_BYTES && WB_LDS_BYTES <= 160 * 1024, "LDS budget of conv3x3_wino_bf16x9");
 
 // Clock telemetry (as conv.hip's): every 64th workgroup adds the shader cycles (s_memtime), the 100 MHz real-time ticks (s_memrealtime)
 // and the number of steps of its K loop: mp_conv_wino_bf16_clock reports the effective shader clock and the cycles per 16-channel step.
@@ -60,7 +63,8 @@ __device__ unsigned long long g_wb_phase[10];
 #endif
 
 // DIAG (timing experiments only, wrong results; MP_WINO_DIAG): 1 = no split work, 2 = no patch requests / transform, 4 = no weight requests
-template <int DIAG>
+// RES: the launch has a residual input; its 16 loads per thread ride under the MFMAs of the LAST K step (round 6).
+template <int DIAG, bool RES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_bf16x9(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;
@@ -121,26 +125,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (!(DIAG & 4)) DST[(K) / 3][(K) % 3] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (ST) * UB_STEP_BYTES + (FI) * UB_F_BYTES + (K) * 1024, 0);
 #define WB_LOAD_PATCH1(A, B, CS) if (!(DIAG & (2 | 128))) patch[A][B] = buf4(x_rsrc, x_voff, (CS) + (A) * row_bytes + (B) * pix_bytes);
   // transform row A of the patch in registers: T(A, b) forms the row combination (B^T d)[A][b]; O(A, col) one frequency plane -> LDS
-#if MP_WINO_PK
-  // packed fp32 (v_pk_add_f32: two lanes of fp32 per instruction, IEEE, same results): half the VALU issue slots of the transform
-#define WB_F4ASM(OP, D, X, Y)                                                                             \
-  {                                                                                                       \
-    f32x2 dlo_, dhi_;                                                                                     \
-    asm volatile("v_pk_add_f32 %0, %2, %4 " OP "\n\tv_pk_add_f32 %1, %3, %5 " OP                          \
-                 : "=&v"(dlo_), "=&v"(dhi_)                                                               \
-                 : "v"(f32x2{X.x, X.y}), "v"(f32x2{X.z, X.w}), "v"(f32x2{Y.x, Y.y}), "v"(f32x2{Y.z, Y.w}));  \
-    D = make_float4(dlo_.x, dlo_.y, dhi_.x, dhi_.y);                                                      \
-  }
-#define WB_OP_SUB "neg_lo:[0,1] neg_hi:[0,1]"
-#define WB_OP_ADD ""
-#else
 #define WB_F4ASM(OP, D, X, Y)                                                                             \
   asm volatile(OP " %0, %4, %8\n\t" OP " %1, %5, %9\n\t" OP " %2, %6, %10\n\t" OP " %3, %7, %11"           \
                : "=&v"(D.x), "=&v"(D.y), "=&v"(D.z), "=&v"(D.w)                                            \
                : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
 #define WB_OP_SUB "v_sub_f32"
 #define WB_OP_ADD "v_add_f32"
-#endif
 #define WB_TR_T(A, B)                                                                                    \
   if (DIAG & (2 | 64)) {} else if ((A) == 0) { WB_F4ASM(WB_OP_SUB, trw[B], patch[0][B], patch[2][B]) }                              \
   else if ((A) == 1) { WB_F4ASM(WB_OP_ADD, trw[B], patch[1][B], patch[2][B]) }                         \
@@ -162,22 +152,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w), "s"(0x07060302u));                     \
     AN[I][0][2 * (H)] = p0_; AN[I][0][2 * (H) + 1] = p1_;                                               \
   }
-#if MP_WINO_PK
-#define WB_SP1(I, H)                                                                                     \
-  if (!(DIAG & 1)) {                                                                                     \
-    f32x2 lo_, hi_;                                                                                      \
-    asm volatile("v_pk_add_f32 %0, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %3, %5 neg_lo:[0,1] neg_hi:[0,1]"   \
-                 : "=&v"(lo_), "=&v"(hi_)                                                                \
-                 : "v"(f32x2{raw[I][H].x, raw[I][H].y}), "v"(f32x2{raw[I][H].z, raw[I][H].w}),           \
-                   "v"(f32x2{__uint_as_float(sm0), __uint_as_float(sm1)}), "v"(f32x2{__uint_as_float(sm2), __uint_as_float(sm3)}));  \
-    sr0 = lo_.x; sr1 = lo_.y; sr2 = hi_.x; sr3 = hi_.y;                                                  \
-  }
-#else
 #define WB_SP1(I, H)                                                                                     \
   if (!(DIAG & 1)) asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11"                    \
                : "=&v"(sr0), "=&v"(sr1), "=&v"(sr2), "=&v"(sr3)                                                                   \
                : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w), "v"(sm0), "v"(sm1), "v"(sm2), "v"(sm3));
-#endif
 #define WB_SP2(AN, I, H)                                                                                 \
   if (!(DIAG & 1)) {                                                                                                     \
     unsigned p0_, p1_;                                                                                  \
@@ -187,22 +165,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3), "s"(0x07060302u));                                                     \
     AN[I][1][2 * (H)] = p0_; AN[I][1][2 * (H) + 1] = p1_;                                               \
   }
-#if MP_WINO_PK
-#define WB_SP3()                                                                                         \
-  if (!(DIAG & 1)) {                                                                                     \
-    f32x2 lo_, hi_;                                                                                      \
-    asm volatile("v_pk_add_f32 %0, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %3, %5 neg_lo:[0,1] neg_hi:[0,1]"   \
-                 : "=&v"(lo_), "=&v"(hi_)                                                                \
-                 : "v"(f32x2{sr0, sr1}), "v"(f32x2{sr2, sr3}),                                           \
-                   "v"(f32x2{__uint_as_float(sm0), __uint_as_float(sm1)}), "v"(f32x2{__uint_as_float(sm2), __uint_as_float(sm3)}));  \
-    sq0 = lo_.x; sq1 = lo_.y; sq2 = hi_.x; sq3 = hi_.y;                                                  \
-  }
-#else
 #define WB_SP3()                                                                                         \
   if (!(DIAG & 1)) asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11"                    \
                : "=&v"(sq0), "=&v"(sq1), "=&v"(sq2), "=&v"(sq3)                                                                   \
                : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3), "v"(sm0), "v"(sm1), "v"(sm2), "v"(sm3));
-#endif
 #define WB_SP4(AN, I, H)                                                                                 \
   if (!(DIAG & 1)) {                                                                                                     \
     unsigned p0_, p1_;                                                                                  \
@@ -281,6 +247,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
   WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
 
+  // ---- the LAST K step (peeled, round 6): no next step to prepare -- no transform, no patch requests, no weights / fragments for a
+  //      following point -- so its free slots carry the epilogue's residual loads instead (16 per thread, into the registers of the patch)
+#define WB_LOAD_RES1(K) if (RES) res[(K) >> 2][(K) & 3] = __builtin_amdgcn_raw_buffer_load_b128(r_res, voff[(K) >> 2][(K) & 3], 0, 0);
+  // slots 16..35 of points 0 / 1 of the last step: only the raw fragment reads of point 2 / 3
+#define WB_TAIL_RD(AC, AN, UC, VBN, N2FI)                                                                \
+  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_SB                                                          \
+  WB_M(17, AC, UC) WB_M(18, AC, UC) WB_M(19, AC, UC) WB_M(20, AC, UC) WB_M(21, AC, UC) WB_M(22, AC, UC) WB_M(23, AC, UC) WB_M(24, AC, UC)  \
+  WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC) WB_M(28, AC, UC) WB_M(29, AC, UC) WB_M(30, AC, UC) WB_M(31, AC, UC) WB_SB  \
+  WB_M(32, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 0) WB_SB                                                \
+  WB_M(33, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 1) WB_SB                                                \
+  WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
+  WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
+  // slots 16..35 of point 2 of the last step: residual loads 0..7
+#define WB_TAIL_RES(AC, AN, UC)                                                                          \
+  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_LOAD_RES1(0) WB_SB                                          \
+  WB_M(17, AC, UC) WB_SB WB_LOAD_RES1(1) WB_SB                                                           \
+  WB_M(18, AC, UC) WB_SB WB_LOAD_RES1(2) WB_SB                                                           \
+  WB_M(19, AC, UC) WB_SB WB_LOAD_RES1(3) WB_SB                                                           \
+  WB_M(20, AC, UC) WB_SB WB_LOAD_RES1(4) WB_SB                                                           \
+  WB_M(21, AC, UC) WB_SB WB_LOAD_RES1(5) WB_SB                                                           \
+  WB_M(22, AC, UC) WB_SB WB_LOAD_RES1(6) WB_SB                                                           \
+  WB_M(23, AC, UC) WB_SB WB_LOAD_RES1(7) WB_SB                                                           \
+  WB_M(24, AC, UC) WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC) WB_M(28, AC, UC) WB_M(29, AC, UC)  \
+  WB_M(30, AC, UC) WB_M(31, AC, UC) WB_M(32, AC, UC) WB_M(33, AC, UC) WB_M(34, AC, UC) WB_M(35, AC, UC) WB_SB
+  // point 3 of the last step: nothing follows it -- 36 MFMAs, residual loads 8..15 in the first gaps
+#define WB_POINT_LAST(AC, UC)                                                                            \
+  WB_M(0, AC, UC) WB_SB WB_LOAD_RES1(8) WB_SB                                                            \
+  WB_M(1, AC, UC) WB_SB WB_LOAD_RES1(9) WB_SB                                                            \
+  WB_M(2, AC, UC) WB_SB WB_LOAD_RES1(10) WB_SB                                                           \
+  WB_M(3, AC, UC) WB_SB WB_LOAD_RES1(11) WB_SB                                                           \
+  WB_M(4, AC, UC) WB_SB WB_LOAD_RES1(12) WB_SB                                                           \
+  WB_M(5, AC, UC) WB_SB WB_LOAD_RES1(13) WB_SB                                                           \
+  WB_M(6, AC, UC) WB_SB WB_LOAD_RES1(14) WB_SB                                                           \
+  WB_M(7, AC, UC) WB_SB WB_LOAD_RES1(15) WB_SB                                                           \
+  WB_M(8, AC, UC) WB_M(9, AC, UC) WB_M(10, AC, UC) WB_M(11, AC, UC) WB_M(12, AC, UC) WB_M(13, AC, UC) WB_M(14, AC, UC)  \
+  WB_M(15, AC, UC) WB_M(16, AC, UC) WB_M(17, AC, UC) WB_M(18, AC, UC) WB_M(19, AC, UC) WB_M(20, AC, UC) WB_M(21, AC, UC) \
+  WB_M(22, AC, UC) WB_M(23, AC, UC) WB_M(24, AC, UC) WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC) WB_M(28, AC, UC) \
+  WB_M(29, AC, UC) WB_M(30, AC, UC) WB_M(31, AC, UC) WB_M(32, AC, UC) WB_M(33, AC, UC) WB_M(34, AC, UC) WB_M(35, AC, UC) WB_SB
+
   // fragment read position: lane (tile row = lane & 31 (+ 32), K group = lane >> 5 = channels 8h .. 8h+7 = 16-byte slots 2h, 2h+1)
   const int fsw = ((lane & 31) >> 2) & 3;
   const float* vr = Vs + ((4 * wave) * WT + (lane & 31)) * WCK;
@@ -335,10 +340,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = pnext[a][bb];
   __syncthreads();
   WB_PHASE(3, clk_start)
+  // the epilogue's store offsets, computed HERE (round 6): the tile table is visible after the barrier, its four reads fly under the
+  // splits below, and the offsets are what the last K step needs to request the residual under its MFMAs.  Branch-free: a tile or a
+  // pixel that does not exist gets the out-of-range offset (buffer accesses are range-checked: loads return 0, stores are dropped).
+  constexpr unsigned WOOB = 0xFFFFFFF0u;
+  int2 ttab[4];
+  _Pragma("unroll") for (int it = 0; it < 4; ++it) ttab[it] = *reinterpret_cast<const int2*>(tile_tab + 2 * (it * 16 + (tid >> 4)));
   WB_READ_RAW1(vr, 0, 0) WB_READ_RAW1(vr, 0, 1) WB_READ_RAW1(vr, 0, 2) WB_READ_RAW1(vr, 0, 3)
 #define WB_SPLIT4(AN, I, H) WB_SP0(AN, I, H) WB_SP1(I, H) WB_SP2(AN, I, H) WB_SP3() WB_SP4(AN, I, H)
   WB_SPLIT4(AA, 0, 0) WB_SPLIT4(AA, 0, 1) WB_SPLIT4(AA, 1, 0) WB_SPLIT4(AA, 1, 1)
   WB_READ_RAW1(vr, 1, 0) WB_READ_RAW1(vr, 1, 1) WB_READ_RAW1(vr, 1, 2) WB_READ_RAW1(vr, 1, 3)
+  const int n = cb * WCOUT + (tid & 15) * 4;
+  unsigned voff[4][4];
+  {
+    const int e_row = p.Wop * p.Cout * 4, e_pix = p.Cout * 4;
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {
+      const int off = ttab[it].x, bits = ttab[it].y;
+      const unsigned base = (unsigned)(off + n) * 4u;
+      const bool t_ok = off >= 0;
+      voff[it][0] = t_ok ? base : WOOB;
+      voff[it][1] = (t_ok && (bits & 2)) ? base + (unsigned)e_pix : WOOB;
+      voff[it][2] = (t_ok && (bits & 1)) ? base + (unsigned)e_row : WOOB;
+      voff[it][3] = (t_ok && (bits & 3) == 3) ? base + (unsigned)(e_row + e_pix) : WOOB;
+    }
+  }
+  const int out_bytes = p.out_bytes;
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (RES && p.residual) ? out_bytes : 0, 0x00020000);
+  u32x4 res[4][4];
 
 #ifdef MP_WINO_PERMUTE
   // TEST BUILD ONLY (tests/test_gpu_wino_permuted.py): MP_WINO_PERMUTE extra values are kept live across the K loop (read from the bias
@@ -358,13 +386,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const bool clk_sample = p.telemetry != 0 && (blockIdx.x & 63) == 0 && tid == 0;
   unsigned long long clk_c0 = 0, clk_r0 = 0;
   if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_wb_clk[3], clk_c0 - clk_start); }
-  for (int st = 0; st < ns; ++st) {
+  for (int st = 0; st < ns - 1; ++st) {
     const int buf = st & 1;
     const float* vb = vr + buf * WV_STAGE;          // V of this step
     const float* vbn = vr + (buf ^ 1) * WV_STAGE;   // V of the next step
     float* vwn = vw + (buf ^ 1) * WV_STAGE;
-    const int cs_patch = (st + 2 < ns ? st + 2 : ns - 1) * (WCK * 4);
-    const int st_next = st + 1 < ns ? st + 1 : st;   // (the last step harmlessly re-requests its own first weights)
+    const int cs_patch = (st + 2 < ns ? st + 2 : ns - 1) * (WCK * 4);   // (the step before the last re-requests the last patch: unused)
 #ifdef MP_WINO_PERMUTE
     _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) asm volatile("" : "+v"(perm_live[k]));   // (in registers, not in scratch)
 #endif
@@ -376,7 +403,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (DIAG & 16) { for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(2); }   // ... by 128 cycles each
 #endif
     { constexpr int fi = 2; WB_HEAD(AA, AB, Ua, Ub, st, 3) WB_TAIL_PL(AA, AB, Ua, 0, 1, cs_patch, vbn, 0) }
-    { constexpr int fi = 3; WB_HEAD(AB, AA, Ub, Ua, st_next, 0) WB_TAIL_PL(AB, AA, Ub, 2, 3, cs_patch, vbn, 1) }
+    { constexpr int fi = 3; WB_HEAD(AB, AA, Ub, Ua, st + 1, 0) WB_TAIL_PL(AB, AA, Ub, 2, 3, cs_patch, vbn, 1) }
+  }
+  {   // the last step: nothing to prepare for a following one (see WB_TAIL_RD / WB_TAIL_RES / WB_POINT_LAST)
+    const int st = ns - 1;
+    const float* vb = vr + (st & 1) * WV_STAGE;
+#ifdef MP_WINO_PERMUTE
+    _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) asm volatile("" : "+v"(perm_live[k]));
+#endif
+    { constexpr int fi = 0; WB_HEAD(AA, AB, Ua, Ub, st, 1) WB_TAIL_RD(AA, AB, Ua, vb, 2) }
+    { constexpr int fi = 1; WB_HEAD(AB, AA, Ub, Ua, st, 2) WB_TAIL_RD(AB, AA, Ub, vb, 3) }
+    { constexpr int fi = 2; WB_HEAD(AA, AB, Ua, Ub, st, 3) WB_TAIL_RES(AA, AB, Ua) }
+    { constexpr int fi = 3; WB_POINT_LAST(AB, Ub) }
   }
   if (clk_sample) {
     atomicAdd(&g_wb_clk[0], __builtin_readcyclecounter() - clk_c0);
@@ -392,6 +430,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #endif
   __syncthreads();   // (the epilogue reuses the V stages)
+#undef WB_POINT_LAST
+#undef WB_TAIL_RES
+#undef WB_TAIL_RD
+#undef WB_LOAD_RES1
 #undef WB_TAIL_PL
 #undef WB_TAIL_TR
 #undef WB_HEAD
@@ -414,58 +456,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WB_LOAD_U1
 #undef WB_SB
 
-  // ---- epilogue (as conv_wino.hip): output transform through LDS, bias + residual + ReLU (+ second activated output) ----------------
-  const int n = cb * WCOUT + (tid & 15) * 4;
-  constexpr unsigned WOOB = 0xFFFFFFF0u;
-  unsigned voff[4][4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int tl = it * 16 + (tid >> 4);
-    const int off = tile_tab[2 * tl], bits = tile_tab[2 * tl + 1];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const bool ok = off >= 0 && (!ii || (bits & 1)) && (!jj || (bits & 2));
-        voff[it][ii * 2 + jj] = ok ? (unsigned)(off + (ii * p.Wop + jj) * p.Cout + n) * 4u : WOOB;
-      }
-  }
-  const int out_bytes = p.out_bytes;
-  u32x4 res[4][4];
-  if (p.residual) {
-    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, out_bytes, 0x00020000);
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) res[it][k] = __builtin_amdgcn_raw_buffer_load_b128(r_res, voff[it][k], 0, 0);
-  }
+  // ---- epilogue: output transform through LDS, bias + residual + ReLU (+ second activated output).  The store offsets and the residual
+  //      are already in registers (computed after the prologue's barrier / requested under the last K step). -------------------------------
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
   if (p.y_act) {
     sc = *reinterpret_cast<const float4*>(p.act_scale + n);
     sh = *reinterpret_cast<const float4*>(p.act_shift + n);
   }
+  // S[wave][2][tile][WS]: row pitch 72 floats -- lanes 32..63 of a fragment (4 tiles further) then start 32 banks away from lanes 0..31
+  constexpr int WS = 72;
   float* S = smem;
   {
-    float* sw = S + (size_t)wave * (2 * WT * WCOUT) + ((lane >> 5) * 4) * WCOUT + (lane & 31);
+    float* sw = S + (size_t)wave * (2 * WT * WS) + ((lane >> 5) * 4) * WS + (lane & 31);
+    // one (tile block, cout block) at a time: 64 accumulators leave the matrix registers, become 32 values and go to LDS before the next
+    // 64 are touched (as one block the compiler copies all 256 out first and spills)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
+        // (the empty statements pin these four accumulators to the matrix registers up to HERE: the allocator cannot split their live
+        //  ranges at the loop exit and copy all 256 to vector registers at once)
+        asm volatile("" : "+a"(acc[0][i][j]), "+a"(acc[1][i][j]), "+a"(acc[2][i][j]), "+a"(acc[3][i][j]));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float m0 = acc[0][i][j][r], m1 = acc[1][i][j][r], m2 = acc[2][i][j][r], m3 = acc[3][i][j][r];
           const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-          sw[row * WCOUT + j * 32] = (m0 + m1) + m2;
-          sw[WT * WCOUT + row * WCOUT + j * 32] = (m1 - m2) - m3;
+          sw[row * WS + j * 32] = (m0 + m1) + m2;
+          sw[WT * WS + row * WS + j * 32] = (m1 - m2) - m3;
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
   }
   WB_PHASE(5, clk_epi)
   __syncthreads();
   WB_PHASE(6, clk_epi)
   const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
-  const bool has_res = p.residual != nullptr, relu = p.relu != 0, has_act = p.y_act != nullptr;
+  const bool relu = p.relu != 0, has_act = p.y_act != nullptr;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int tl = it * 16 + (tid >> 4);
@@ -473,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) s4[w][jj] = *reinterpret_cast<const float4*>(S + ((size_t)(w * 2 + jj) * WT + tl) * WCOUT + (tid & 15) * 4);
+      for (int jj = 0; jj < 2; ++jj) s4[w][jj] = *reinterpret_cast<const float4*>(S + ((size_t)(w * 2 + jj) * WT + tl) * WS + (tid & 15) * 4);
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -487,7 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           v.z = (s4[1][jj].z - s4[2][jj].z) - s4[3][jj].z; v.w = (s4[1][jj].w - s4[2][jj].w) - s4[3][jj].w;
         }
         v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        if (has_res) {
+        if (RES) {
           const u32x4 rr = res[it][ii * 2 + jj];
           v.x += __uint_as_float(rr.x); v.y += __uint_as_float(rr.y); v.z += __uint_as_float(rr.z); v.w += __uint_as_float(rr.w);
         }
@@ -638,9 +666,10 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   MP_CHECK_HIP(hipGetDevice(&dev));
   static int attr_dev = -1;
   if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
+    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
 #ifdef MP_CONV_EXPERIMENTS
-#define WB_DIAG_ATTR(D) MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS_BYTES));
+#define WB_DIAG_ATTR(D) MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
     WB_DIAG_ATTR(1) WB_DIAG_ATTR(2) WB_DIAG_ATTR(4) WB_DIAG_ATTR(7) WB_DIAG_ATTR(8) WB_DIAG_ATTR(16) WB_DIAG_ATTR(32) WB_DIAG_ATTR(64) WB_DIAG_ATTR(128)
 #undef WB_DIAG_ATTR
 #endif
@@ -660,11 +689,12 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   ProfScope prof("conv3x3_wino_bf16x9<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout)) + 6.0 * 16.0 * d->C * d->Cout, s, executed, 2500.0);
 #ifdef MP_CONV_EXPERIMENTS
   const int diag = getenv("MP_WINO_DIAG") ? atoi(getenv("MP_WINO_DIAG")) : 0;
-#define WB_DIAG_LAUNCH(D) if (diag == D) hipLaunchKernelGGL(conv3x3_wino_bf16x9<D>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p); else
+#define WB_DIAG_LAUNCH(D) if (diag == D) hipLaunchKernelGGL((conv3x3_wino_bf16x9<D, true>), dim3((unsigned)n_wg), dim3(256), WB_LDS_BYTES, s, p); else
   WB_DIAG_LAUNCH(1) WB_DIAG_LAUNCH(2) WB_DIAG_LAUNCH(4) WB_DIAG_LAUNCH(7) WB_DIAG_LAUNCH(8) WB_DIAG_LAUNCH(16) WB_DIAG_LAUNCH(32) WB_DIAG_LAUNCH(64) WB_DIAG_LAUNCH(128)
 #undef WB_DIAG_LAUNCH
 #endif
-  hipLaunchKernelGGL(conv3x3_wino_bf16x9<0>, dim3((unsigned)n_wg), dim3(256), WINO_LDS_BYTES, s, p);
+  if (d->d_residual) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true>), dim3((unsigned)n_wg), dim3(256), WB_LDS_BYTES, s, p);
+  else hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false>), dim3((unsigned)n_wg), dim3(256), WB_LDS_BYTES, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

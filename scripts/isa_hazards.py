@@ -13,7 +13,8 @@ so the first MFMA multiplied the registers' PREVIOUS contents.  This lint turns 
 hold for any assignment; tests/test_wino_isa_hazards_cpu.py runs it on the product build and on deliberately permuted builds.
 
 Rules (wait states: every instruction issued in between counts 1, `s_nop N` counts N + 1; the loop bodies are walked twice so that the
-back edge is covered; the walk is linear -- forward branches are treated as not taken, which only adds checks):
+back edge is covered; the walk is linear -- conditional forward branches are treated as not taken, which only adds checks; of an if / else the `then`
+side is walked):
   R1  VALU write of a VGPR -> MFMA reading it as SrcA / SrcB / SrcC: >= 2 wait states.
   R2  a register that is the destination of a load still in flight (vmcnt / lgkmcnt modelled in order, exactly as `s_waitcnt` counts them)
       is neither read nor written before the wait that covers the load.
@@ -106,6 +107,9 @@ def expand_loops(ins):
         if m and x["ops"] and x["ops"][0] in labels and labels[x["ops"][0]] < n and n not in done:
             done.add(n)
             order.extend(range(labels[x["ops"][0]], n + 1))
+        elif x["op"] == "s_branch" and x["ops"] and labels.get(x["ops"][0], -1) > n:
+            n = labels[x["ops"][0]]      # if / else: the walk takes the `then` side and skips the `else` side
+            continue
         n += 1
     return order
 
@@ -122,9 +126,13 @@ def lint(text):
     asm_written = {}        # statement id -> registers written so far inside it
     pos = 0
 
+    vm_ids, lg_ids = set(), set()
+
     def retire(queue, keep):
         while len(queue) > keep:
             idx, dests = queue.pop(0)
+            vm_ids.discard(idx)
+            lg_ids.discard(idx)
             for r in dests:
                 if pending.get(r) == idx:
                     del pending[r]
@@ -152,10 +160,14 @@ def lint(text):
             pos += 1
             continue
         d, u = defs_uses(x)
-        # R2
+        # R2 (a later load of the SAME in-order queue may overwrite a dead earlier one: the data lands in issue order)
+        is_vm_load = op.startswith(("buffer_load", "global_load", "scratch_load", "flat_load"))
+        is_lds_load = op.startswith("ds_read")
         for r in set(d + u):
             if r in pending:
-                flag("R2", k, f"{r} is the destination of a load still in flight: {ins[order[pending[r]]]['text']}")
+                same_queue = r in d and r not in u and ((is_vm_load and pending[r] in vm_ids) or (is_lds_load and pending[r] in lg_ids))
+                if not same_queue:
+                    flag("R2", k, f"{r} is the destination of a load still in flight: {ins[order[pending[r]]]['text']}")
         # R3
         if x["asm"] is not None:
             w = asm_written.setdefault((x["asm"], k // 100000), set())
@@ -186,10 +198,12 @@ def lint(text):
         # bookkeeping
         if op.startswith(("buffer_load", "global_load", "scratch_load", "flat_load")):
             vm.append((k, d))
+            vm_ids.add(k)
             for r in d:
                 pending[r] = k
         elif op.startswith(("ds_read",)):
             lg.append((k, d))
+            lg_ids.add(k)
             for r in d:
                 pending[r] = k
         elif op.startswith(("ds_write", "ds_add", "ds_max")):

@@ -7,6 +7,7 @@
 #   _build/r5badfix         the same source + the two wait states in front of the accumulator-reset MFMAs (the round-6 fix), nothing else
 # Usage: bash scripts/microbench/build_wino_variants.sh   (after make -C megapose6d_amd/csrc)
 set -e
+MODE="$1"
 cd "$(dirname "$0")/../.."
 C=megapose6d_amd/csrc
 B=scripts/microbench/_build
@@ -18,15 +19,22 @@ for n in 3 8; do
   /opt/rocm/bin/hipcc $F -DMP_WINO_PERMUTE=$n -c $C/conv_wino_bf16.hip -o $B/wperm$n/conv_wino_bf16.o
   link wperm$n
 done
-if [ "$1" = "ab" ]; then   # A/B and profiling builds of the round: pk1 = packed-fp32 transform / split arithmetic, phases = cycle stamps
-  for v in "pk1 -DMP_WINO_PK=1" "phases -DMP_WINO_PHASES" "exp -DMP_CONV_EXPERIMENTS"; do
+if [ "$MODE" = "ab" ]; then   # A/B and profiling builds of the round: phases = cycle stamps in prologue / epilogue, exp = the DIAG instances
+  for v in "phases -DMP_WINO_PHASES" "exp -DMP_CONV_EXPERIMENTS"; do
     set -- $v; n=$1; shift
     mkdir -p $B/$n
     /opt/rocm/bin/hipcc $F "$@" -c $C/conv_wino_bf16.hip -o $B/$n/conv_wino_bf16.o
     link $n
   done
 fi
-if [ "$1" = "r5" ]; then
+if [ "$MODE" = "ab" ]; then   # base = the kernel as it was before the round-6 restructuring (commit f0b2340, scalar arithmetic): same-box A/B
+  mkdir -p $B/base/src
+  cp $C/*.h $B/base/src/
+  git show f0b2340:megapose6d_amd/csrc/conv_wino_bf16.hip > $B/base/src/conv_wino_bf16.hip
+  /opt/rocm/bin/hipcc $F -DMP_WINO_PK=0 -c $B/base/src/conv_wino_bf16.hip -o $B/base/conv_wino_bf16.o
+  link base
+fi
+if [ "$MODE" = "r5" ]; then
   for v in r5bad r5badfix; do
     mkdir -p $B/$v/src
     cp $C/*.h $B/$v/src/
