@@ -293,17 +293,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- prologue: V of step 0 in stage 0, the patch of step 1 in registers, weights + split fragments of (step 0, point 0), the raw
   //      fragments of point 1 ---------------------------------------------------------------------------------------------------------
-  // every request the first two steps need goes out at once (one memory round trip instead of two: the CU runs ONE workgroup, nothing
-  // else hides this latency); the tile table of the epilogue and the accumulator reset fill the wait
+  // Request order (round 6; stamps in profiles/r06_wino_kloop_experiments.txt): a wave's vector-memory requests are accepted at the rate
+  // they come back (~16 outstanding per wave, ~2 k cycles each from HBM), so the 38 requests of the round-4/5 prologue took 6 k cycles to
+  // ISSUE, with everything behind them in program order waiting.  Now: the 16 patch requests of step 0 first, then the accumulator reset
+  // and the tile table (matrix pipe / LDS work in the shadow of the queue), the 6 weight requests, and the 16 requests of step 1's patch
+  // only after the first transform row -- they fly under the remaining transform rows, the barrier and the first splits.
   float4 pnext[4][4];
-  {
-    const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
-    _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)
-      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)
-      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) pnext[a][bb] = buf4(x_rsrc, x_voff, cs1 + a * row_bytes + bb * pix_bytes);
-  }
+  _Pragma("unroll") for (int a = 0; a < 4; ++a)
+    _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
   WB_SB
   if (tid < WT) {
     const int t = tile0 + tid;
@@ -332,9 +329,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4));
   }
   WB_SB
+  _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
+  WB_SB
   WB_PHASE(0, clk_start)
 #define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
-  WB_TR_ROW(0, vw) WB_PHASE(1, clk_start) WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  WB_TR_ROW(0, vw) WB_PHASE(1, clk_start)
+  WB_SB
+  {
+    const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) pnext[a][bb] = buf4(x_rsrc, x_voff, cs1 + a * row_bytes + bb * pix_bytes);
+  }
+  WB_SB
+  WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
   WB_PHASE(2, clk_start)
   _Pragma("unroll") for (int a = 0; a < 4; ++a)
     _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = pnext[a][bb];
@@ -491,6 +498,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   WB_PHASE(5, clk_epi)
   __syncthreads();
   WB_PHASE(6, clk_epi)
+  // (round 6: an L2 prefetch of the following workgroup's first patch lines from here -- 4 dword loads per thread, results unused -- was
+  //  built and measured: that workgroup's prologue gets 1.1 k cycles shorter, this epilogue 1.5 - 2.9 k cycles longer (the scattered requests
+  //  queue in front of the stores): a net loss on every layer, removed.  profiles/r06_wino_kloop_experiments.txt)
   const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
   const bool relu = p.relu != 0, has_act = p.y_act != nullptr;
