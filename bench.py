@@ -574,7 +574,7 @@ def main():
             rb = {"ms": sum(v["ms"] for v in rparts.values()), "bytes": sum(v["bytes"] for k, v in rparts.items() if k.startswith("raster_tiles")),
                   "launches": rparts[rb_name]["launches"], "parts_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in rparts.items()}}
         traffic, traffic_src, r_traffic = None, None, None
-        tfile = next((f for f in (ROOT / "profiles" / "r05_traffic.json", ROOT / "profiles" / "r04_traffic.json", ROOT / "profiles" / "r03_traffic.json")
+        tfile = next((f for f in (ROOT / "profiles" / "r06_traffic.json", ROOT / "profiles" / "r05_traffic.json", ROOT / "profiles" / "r04_traffic.json", ROOT / "profiles" / "r03_traffic.json")
                       if f.is_file()), None)
         if tfile is not None:  # PMC cannot be sampled from inside the process: committed rocprofv3 --pmc summary of the same command
             tj = json.loads(tfile.read_text())
@@ -600,6 +600,11 @@ def main():
                        "parallelism": f"rows sharded rank::world over {world} GPU(s)", "arch": arch, "cus": n_cu},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": dom["peak_tflops"], "unit": "TFLOP/s",
                          "frac": achieved / dom["peak_tflops"],
+                         "frac_convention": "EXECUTED flops of the dominant kernel on its matrix pipe / that pipe's dense peak (MFMA utilisation, "
+                                            "what north_star asks for); `frac_algorithmic` = SURVEY.md 8(d)'s algorithmic work (2 x MACs of the "
+                                            "direct convolution) / the same time / the same peak -- the kernel executes 9 x 16/36 x tile padding "
+                                            "= 4.1 x that",
+                         "frac_algorithmic": alg_rate / dom["peak_tflops"],
                          "executed_arithmetic": ("bf16 MFMA on exact pieces of the fp32 operands (each fp32 value = three bf16 pieces, all nine piece "
                                                  "products, fp32 accumulate): every product exact" if bf16 else "fp32 MFMA"),
                          "algorithmic_equiv": {"tflops": alg_rate, "over_fp32_mfma_peak": alg_rate / PEAK_FP32_MFMA_TFLOPS,
@@ -629,11 +634,15 @@ def main():
                         "total": extra_t["time"]},
         }
         if stem_wgs > 0:
+            # K steps of the stem's slice walk (csrc/conv_stem.hip stem::n_steps): short walk over the dense walk, for this workload's
+            # refiner stem (7x7, 3 fp32-kind + 24 integer channels: 5 record chunks, 2 of them hold the observation crop's pieces)
+            n_steps = lambda ks, q: ((ks * ks * q + 3) // 4 + 1) // 2 * 2   # noqa: E731
+            STEM_SHORT_WALK = n_steps(7, 2) / n_steps(7, 5)
             f_bg = stem_bg / stem_wgs
             out["stem_background"] = {
                 "workgroups_short_walk_fraction": f_bg, "workgroups_per_step": stem_wgs / a.steps,
-                "executed_flops_factor": 1.0 - f_bg * (1.0 - 26.0 / 62.0),
-                "note": "refiner-stem workgroups (8 x 16 output pixels) whose input patch no rendered view reaches walk 26 of the 62 K steps "
+                "executed_flops_factor": 1.0 - f_bg * (1.0 - STEM_SHORT_WALK),
+                "note": "refiner-stem workgroups (8 x 16 output pixels) whose input patch no rendered view reaches walk n_steps(7, 2) = 26 of the n_steps(7, 5) = 62 K steps "
                         "(only the observation crop's record chunks; the skipped products are exact zeros).  The per_kernel `executed_tflops` / "
                         "`mfma_utilisation` of that stem row are computed from the DENSE step count: multiply them by executed_flops_factor"}
         out["host"] = {"replicated_topk_ms_per_step": host_topk_ms,

@@ -49,15 +49,7 @@ int mp_profile_query(int idx, char* name, int name_len, int64_t* launches, doubl
 int mp_profile_query_ex(int idx, char* name, int name_len, int64_t* launches, double* total_ms, double* total_flops,
                         double* total_bytes, double* total_executed_flops, double* peak_tflops);
 
-/* Shader clock under fp32-MFMA load: runs a register-only v_mfma_f32_32x32x2_f32 loop on every CU for `ms_target` milliseconds
- * (two workgroups of four waves per CU, operands rotating every instruction), synchronises, and returns the effective shader clock
- * = delta(s_memtime) / delta(s_memrealtime at 100 MHz) in MHz and the loop's own TFLOP/s (NULL to skip either).  bench.py states
- * the clock its roofline fraction was measured at: boxes of the same pool differ by ~10 % in sustained clock. */
-int mp_clock_probe(double ms_target, double* shader_mhz, double* mfma_tflops, mp_stream stream);
 
-/* Effective shader clock (MHz) the fp32 convolution kernels ran at since the last reset: every 64th workgroup accumulates
- * s_memtime cycles and s_memrealtime (100 MHz) ticks over its K loop.  Synchronises the device.  0.0 if no convolution ran. */
-int mp_conv_clock_read(double* shader_mhz, int reset);
 
 /* number of CUs etc. of the current device; fails loudly when no gfx950 device is usable */
 int mp_device_info(int* n_cus, int* lds_bytes, char* arch_name, int arch_name_len);
@@ -174,8 +166,9 @@ int mp_raster_render_xrec(const mp_mesh_db* db, const int32_t* d_mesh_ids, const
                           int c_normals, int c_depth, void* d_workspace, size_t workspace_bytes,
                           const float* d_images, int images_nhwc4, int n_im, int C, int H, int W, const int32_t* d_im_ids,
                           const float* d_boxes, uint32_t f32_mask, const float* d_tCR, int depth_mode, mp_stream stream);
-/* The job flags of the LAST mp_raster_render* launch on `d_workspace` in its compacted form (default; NULL with MP_RASTER_COMPACT=0 is the
- * caller's business: the bytes are then stale): device pointer to [n_items][tiles_y = ceil(h / 8)][tiles_x = ceil(w / 8)] bytes, 0 = no
+/* The job flags of the LAST mp_raster_render* launch on `d_workspace`: NULL unless that launch ran in the compacted form (default;
+ * MP_RASTER_COMPACT=0 = direct form) with exactly this n_views, h and w (the library keeps a host-side record per workspace, so stale
+ * or foreign bytes are never handed out); else the device pointer to [n_items][tiles_y = ceil(h / 8)][tiles_x = ceil(w / 8)] bytes, 0 = no
  * view of the item reaches that 8x8-pixel tile (its render channels are all background).  Consumer: mp_conv_stem_xrec_sparse /
  * mp_backbone_forward_xrec_sparse on the same stream, before the next raster launch on this workspace. */
 const unsigned char* mp_raster_job_flags(const mp_mesh_db* db, const void* d_workspace, int n_views, int h, int w);
@@ -258,28 +251,15 @@ size_t mp_conv_wino_packed_floats(int Cin_p, int Cout);
 int mp_conv_wino_pack_weights(const float* h_w_oi33, int Cout, int Cin, int Cin_p, const float* h_scale /*[Cout] or NULL*/, float* h_packed);
 int mp_conv_wino_eligible(const mp_conv_desc* desc, int n_cu);
 int mp_conv3x3_wino_nhwc(const mp_conv_desc* desc, const float* d_u, mp_stream stream);
-/* totals over the Winograd launches since the last reset: algorithmic (direct-convolution) FLOPs and the FLOPs actually executed */
-int mp_conv_wino_stats(double* direct_flops, double* executed_flops, int reset);
 
 /* The same fused Winograd convolution with its multiplications on the bf16 MFMA through EXACT operand pieces (csrc/conv_wino_bf16.hip):
  * U = G g G^T and every fp32 fragment of V = B^T d B are split by truncation into three bf16 pieces (24 = 3 x 8 mantissa bits) and ALL
  * nine piece products are accumulated in fp32 -- every product is exact, the result differs from mp_conv3x3_wino_nhwc only in the order
  * of the fp32 additions -- at 9/16 of the fp32-MFMA matrix time.  Same descriptor, eligibility (mp_conv_wino_eligible) and read-slack
- * contract; d_u_pieces = the blob of mp_conv_wino_bf16_pack_weights.  mp_conv_wino_bf16_stats: algorithmic (direct-convolution) FLOPs
- * and executed bf16 FLOPs (9 x 16 per 2x2 tile and channel pair) since the last reset. */
+ * contract; d_u_pieces = the blob of mp_conv_wino_bf16_pack_weights.  (Counters / clock telemetry of these launches: mp_engine_debug.h.) */
 size_t mp_conv_wino_bf16_packed_bytes(int Cin_p, int Cout);
 int mp_conv_wino_bf16_pack_weights(const float* h_w_oi33, int Cout, int Cin, int Cin_p, const float* h_scale /*[Cout] or NULL*/, void* h_packed);
 int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* desc, const void* d_u_pieces, mp_stream stream);
-int mp_conv_wino_bf16_stats(double* direct_flops, double* executed_bf16_flops, int reset);
-/* effective shader clock (MHz) inside the K loops of the bf16 Winograd launches since the last reset and their shader cycles per
- * 16-channel step (every 64th workgroup samples s_memtime / s_memrealtime); synchronises the device; 0.0 if none ran */
-int mp_conv_wino_bf16_clock(double* shader_mhz, double* cycles_per_step, int reset);
-/* shader cycles a sampled workgroup of those launches spent before its K loop (requests, first transform) and after it (output transform,
- * exchange, stores), averaged since the last mp_conv_wino_bf16_clock reset; call BEFORE the resetting clock read */
-int mp_conv_wino_bf16_phases(double* prologue_cycles, double* epilogue_cycles);
-/* switches the in-kernel clock telemetry behind the two calls above on / off (default OFF: the pose pipeline does not pay the six global
- * atomics of every 64th workgroup; bench.py and the microbenchmarks switch it on); returns the previous setting */
-int mp_conv_wino_bf16_telemetry(int on);
 
 /* Stem convolution on the bf16 MFMA through EXACT operand pieces (csrc/conv_stem.hip; same call site as mp_conv2d_nhwc for the first
  * layer: models/torchvision_resnet.py:213-216, models/wide_resnet.py:65-67).  The render channels of the CNN input are 8-bit integers
@@ -309,19 +289,18 @@ int mp_conv_stem_xrec(const mp_conv_desc* desc, const void* d_packed, int n_f32,
 int mp_conv_stem_xrec_pool(const mp_conv_desc* desc, const void* d_packed, int n_f32, float* d_ypool, int pool_border, mp_stream stream);
 
 /* Background tiles (round 5).  A stem workgroup (8 x 16 output pixels) whose input patch holds no rendered geometry -- every integer
- * channel of every pixel 0: 55 % of a refiner step's tiles -- needs only the record chunks that hold fp32-kind pieces:
+ * channel of every pixel 0: 47 % of a refiner step's tiles (measured, profiles/r05_stem_sparse_ab.txt) -- needs only the record chunks that hold fp32-kind pieces:
  * mp_conv_stem_sparse_chunks = ceil(3 n_f32 / 8) if that is fewer than the record's chunks and the fp32-kind channels are the leading
  * ones (no depth channels), else 0.  mp_conv_stem_xrec_sparse = mp_conv_stem_xrec[_pool] (d_ypool may be NULL) that takes, besides the
  * dense blob, the blob packed for that short walk and the rasteriser's job flags of the launch that wrote the records
  * (mp_raster_job_flags): such workgroups run 26 instead of 62 steps (7x7, 40-element records) and stage 2 of 5 chunks.  Skipped products
  * are exact zeros; the evaluated ones are grouped into MFMAs differently from the dense walk (order of the fp32 additions).
- * mp_conv_stem_bg_stats: workgroups that took the short walk / all workgroups of such launches, counted while the event profiler runs. */
+ * (mp_conv_stem_bg_stats, mp_engine_debug.h: how many workgroups took the short walk.) */
 int mp_conv_stem_sparse_chunks(int KS, int n_f32, int n_u8);
 size_t mp_conv_stem_sparse_packed_bytes(int KS, int n_f32, int n_u8, int Cout);
 int mp_conv_stem_pack_weights_sparse(const float* h_w_oihw, int Cout, int Cin, int KS, int n_f32, const float* h_scale, void* h_packed);
 int mp_conv_stem_xrec_sparse(const mp_conv_desc* desc, const void* d_packed, const void* d_packed_sparse, int n_f32,
                              const unsigned char* d_tile_flags, float* d_ypool, int pool_border, mp_stream stream);
-int mp_conv_stem_bg_stats(double* background_wgs, double* total_wgs, int reset);
 
 /* 3x3 stride-2 pad-1 max pool on padded NHWC (input must be >= 0, i.e. post-ReLU).        */
 int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border, float* d_y,
@@ -379,6 +358,8 @@ int mp_backbone_forward_f16(mp_backbone* bb, const void* d_x_half, int batch, in
 /* mp_backbone_xrec_elements: record length in bf16 elements for this backbone (packs the piece blob on first use), 0 = the stem has   */
 /* no such form (records outside 16..48 elements): use mp_backbone_forward.  The tensor has the geometry    */
 /* of the fp32 input (border mp_backbone_input_border()) with records of that many bf16 elements per pixel.                            */
+/* PRECONDITION of every mp_backbone_forward_xrec*: mp_backbone_xrec_elements / mp_backbone_xrec_prepare was called for that mask before   */
+/* (once, outside stream capture): the forwards only look the blob up and fail with MP_ERR_INVALID if it is missing -- they never allocate. */
 int mp_backbone_xrec_elements(mp_backbone* bb, int n_f32);
 int mp_backbone_forward_xrec(mp_backbone* bb, const void* d_xrec, int n_f32, int batch, int h, int w, float* d_out,
                              float* d_sigmoid, float* d_feat, void* d_workspace, size_t workspace_bytes,

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct mp_backbone {
   // exact-piece bf16 stem (conv_stem.hip): the stem's OIHW weights + folded BN scale stay on the host so that the piece blob can be
   // packed for the record layout (number of fp32-kind channels) the caller's rasteriser launch writes
   std::vector<float> stem_w_host, stem_scale_host;
+  std::mutex blob_mu;                     // guards the two maps below: prepare (one thread) vs forwards looking blobs up on other threads / streams
   std::map<uint32_t, void*> stem_blobs;   // f32-kind channel mask -> device blob (mp_backbone_xrec_prepare); never freed before destroy
   std::map<uint32_t, void*> stem_blobs_sparse;   // ... -> blob of the background-tile walk (leading-channel masks with something to skip)
   // workspace bookkeeping: borders are zeroed once per (pointer, batch, h, w); several workspaces may be live at once
@@ -324,6 +326,7 @@ extern "C" int mp_backbone_xrec_prepare(mp_backbone* bb, uint32_t f32_mask) {
   if (bb->c_in < 32 && (f32_mask >> bb->c_in) != 0u) return 0;
   const int n_f32 = __builtin_popcount(f32_mask), n_u8 = bb->c_in - n_f32;
   if (!mp_conv_stem_supported(bb->stem.K, n_f32, n_u8) || bb->stem.Cout % 64 != 0) return 0;
+  std::lock_guard<std::mutex> blob_lock(bb->blob_mu);
   if (!bb->stem_blobs.count(f32_mask)) {
     std::vector<unsigned char> blob(mp_conv_stem_packed_bytes(bb->stem.K, n_f32, n_u8, bb->stem.Cout));
     if (mp_conv_stem_pack_weights_mask(bb->stem_w_host.data(), bb->stem.Cout, bb->c_in, bb->stem.K, f32_mask,
@@ -395,10 +398,17 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
   bool stem_pooled = false;
   // stem: conv + folded bn + relu, then 3x3/s2 max pool (+ first block's pre-activation for the wide nets)
   if (x_mode == 2) {
-    const auto blob_it = bb->stem_blobs.find(f32_mask);
-    MP_REQUIRE(blob_it != bb->stem_blobs.end(), "mp_backbone_forward_xrec: no piece blob for the fp32-kind channel mask 0x%x of this %d-channel stem: "
+    const void* d_stem_pieces = nullptr;
+    const void* d_sparse_blob = nullptr;
+    {
+      std::lock_guard<std::mutex> blob_lock(bb->blob_mu);
+      const auto blob_it = bb->stem_blobs.find(f32_mask);
+      if (blob_it != bb->stem_blobs.end()) d_stem_pieces = blob_it->second;
+      const auto sp_it = bb->stem_blobs_sparse.find(f32_mask);
+      if (sp_it != bb->stem_blobs_sparse.end()) d_sparse_blob = sp_it->second;
+    }
+    MP_REQUIRE(d_stem_pieces != nullptr, "mp_backbone_forward_xrec: no piece blob for the fp32-kind channel mask 0x%x of this %d-channel stem: "
                "call mp_backbone_xrec_prepare / mp_backbone_xrec_elements first (it returns 0 if the stem has no exact-piece form)", f32_mask, bb->c_in);
-    const void* d_stem_pieces = blob_it->second;
     const int n_f32 = __builtin_popcount(f32_mask);
     mp_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -408,8 +418,7 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
     // vanilla ResNet: the max pool rides in the stem's epilogue and the stem map is never written (MP_STEM_POOL=0: separate kernels);
     // the pre-activation WideResNets need relu(bn1(pooled)) as a second output of the pool, which takes the complete maximum
     static const bool fuse_pool = !(getenv("MP_STEM_POOL") && atoi(getenv("MP_STEM_POOL")) == 0);
-    const auto sp_it = d_tile_flags ? bb->stem_blobs_sparse.find(f32_mask) : bb->stem_blobs_sparse.end();
-    const void* d_sparse = sp_it != bb->stem_blobs_sparse.end() ? sp_it->second : nullptr;   // background-tile walk where it applies
+    const void* d_sparse = d_tile_flags ? d_sparse_blob : nullptr;   // background-tile walk where it applies
     if (!bb->wide && fuse_pool) {
       d.d_y = nullptr;
       rc = d_sparse ? mp_conv_stem_xrec_sparse(&d, d_stem_pieces, d_sparse, n_f32, d_tile_flags, A[0], 1, s)

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "mp_engine.h"
+#include "mp_engine_debug.h"
 
 namespace mp {
 

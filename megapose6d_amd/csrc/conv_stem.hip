@@ -106,7 +106,7 @@ struct Geo {
 // is combined with unsigned atomicMax on the float bits (the values are post-ReLU, >= 0: the integer order IS the float order; max is
 // associative and commutative, so the result is deterministic) into a position that pool_zero_kernel cleared beforehand.  The stem map
 // itself is then never written (y may be NULL) and the separate pool kernel + its 2.9-GB read at 576 rows disappear.
-// SP (round 5): BACKGROUND TILES.  55 % of a refiner step's stem tiles see no rendered geometry in any view (the object fills ~30 % of its
+// SP (round 5): BACKGROUND TILES.  47 % (measured, profiles/r05_stem_sparse_ab.txt) of a refiner step's stem tiles see no rendered geometry in any view (the object fills ~30 % of its
 // crop): every integer (render) channel of every pixel of their input patch is 0, and 3 of the 5 record chunks contribute exact zeros.
 // The rasteriser already knows which 8x8-pixel tiles no view reaches (raster_classify's job flags); a workgroup whose whole patch lies in
 // such tiles walks only the slices of the chunks that hold fp32-kind pieces (q < q_use: 2 of 5 for the RGB refiner) with a piece blob
@@ -423,7 +423,12 @@ extern "C" int mp_conv_stem_pack_weights_mask(const float* w, int Cout, int Cin,
 extern "C" int mp_conv_stem_sparse_chunks(int KS, int n_f32, int n_u8) {
   if (!mp_conv_stem_supported(KS, n_f32, n_u8) || n_f32 <= 0) return 0;
   const int Q = mp_xrec_elements(n_f32, n_u8) / 8, q_use = (3 * n_f32 + 7) / 8;
-  return q_use < Q ? q_use : 0;
+  if (q_use >= Q) return 0;
+  // the short walk runs 4 n_steps(KS, q_use) + 4 slices (one group ahead) over KS * KS * q_use real ones and ONE zero row of KS * q_use
+  // slices behind them: a walk that needs more padding than that row (q_use = 1, i.e. n_f32 = 1 or 2: 11 > 7 / 5) would step past it
+  // and read LDS outside the patch -- no background-tile form for such records (the pipeline's records have q_use = 2)
+  const int pad = 4 * stem::n_steps(KS, q_use) + 4 - KS * KS * q_use;
+  return pad <= KS * q_use ? q_use : 0;
 }
 extern "C" size_t mp_conv_stem_sparse_packed_bytes(int KS, int n_f32, int n_u8, int Cout) {
   const int q_use = mp_conv_stem_sparse_chunks(KS, n_f32, n_u8);

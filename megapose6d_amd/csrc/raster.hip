@@ -23,6 +23,8 @@
 //                     contiguous pixel records (one launch fills the CNN input with full-line writes).
 // Roofline: HBM-bound on the output writes ((3+3[+1])*4*h*w bytes per view + the mesh once per view).
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1075,8 +1077,24 @@ extern "C" float mp_mesh_db_radius(const mp_mesh_db* db, int i) {
 
 static BinLayout bin_layout(const mp_mesh_db* db, int h, int w);
 static size_t job_tail_offset_ints(const BinLayout& lay, int n_views);
+// what the last launch on a workspace left behind its view blocks (host-side record): the job flags are only handed out for the
+// launch that wrote them -- compacted form, same number of views, same image size
+struct LastLaunch { bool compact; int n_views, h, w; };
+static std::mutex g_last_mu;
+static std::map<const void*, LastLaunch> g_last_launch;
+static void note_launch(const void* d_ws, bool compact, int n_views, int h, int w) {
+  std::lock_guard<std::mutex> lock(g_last_mu);
+  if (g_last_launch.size() > 256) g_last_launch.clear();   // (workspaces come and go with their allocations: the record is a cache)
+  g_last_launch[d_ws] = LastLaunch{compact, n_views, h, w};
+}
+
 extern "C" const unsigned char* mp_raster_job_flags(const mp_mesh_db* db, const void* d_ws, int n_views, int h, int w) {
   if (!db || !d_ws || n_views <= 0 || h <= 0 || w <= 0) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_last_mu);
+    auto it = g_last_launch.find(d_ws);
+    if (it == g_last_launch.end() || !it->second.compact || it->second.n_views != n_views || it->second.h != h || it->second.w != w) return nullptr;
+  }
   const BinLayout lay = bin_layout(db, h, w);
   const int* counters = (const int*)d_ws + job_tail_offset_ints(lay, n_views);
   return (const unsigned char*)(counters + 4 + (size_t)n_views * lay.n_tiles);
@@ -1138,7 +1156,8 @@ static int raster_render_impl(const mp_mesh_db* db, const int32_t* d_mesh_ids, c
   unsigned char* const job_flags = (unsigned char*)(light_list + (size_t)n_views * lay.n_tiles);
   unsigned char* const view_flags = job_flags + (((size_t)n_views * lay.n_tiles + 15) & ~(size_t)15);
   const char* compact_env = getenv("MP_RASTER_COMPACT");
-  const bool compact = !(compact_env && atoi(compact_env) == 0);
+  const bool compact = !(compact_env && compact_env[0] && atoi(compact_env) == 0);   // (the ONE place the switch is parsed: "0" / "00" = direct form)
+  note_launch(d_ws, compact, n_views, h, w);
   const bool do_norm = (flags & MP_RASTER_NORMALS) && c_normals >= 0, do_depth = (flags & MP_RASTER_DEPTH) && c_depth >= 0;
   // channel run [c_lo, c_hi) one pixel record of this launch spans, and which of its channels are written
   int c_lo = 1 << 30, c_hi = -1;

@@ -438,9 +438,9 @@ class PosePredictor(nn.Module):
         out = torch.empty(b, n_out, dtype=torch.float32, device=device)
         sig = torch.empty(b, n_out, dtype=torch.float32, device=device) if want_sigmoid else None
         tile_flags = 0
-        if (records and self.stem_sparse and vg >= V and not (self.input_depth or self.render_depth)
-                and os.environ.get("MP_RASTER_COMPACT", "1") != "0"):
-            # the job flags of THIS step's (single) raster launch: same stream, consumed before the next launch on this slot's workspace
+        if records and self.stem_sparse and vg >= V and not (self.input_depth or self.render_depth):
+            # the job flags of THIS step's (single) raster launch: same stream, consumed before the next launch on this slot's workspace;
+            # 0 (dense walk) unless that launch ran in the compacted form with this shape -- the library keeps the record
             tile_flags = eng.raster_job_flags(self.renderer._ensure_db(), b * V, h, w, device, slot)
         bb.forward(x, b, h, w, out, sig, slot=slot, f32_mask=self._f32_mask(), tile_flags=tile_flags)
         if ev is not None:

@@ -18,6 +18,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = ROOT / "include" / "mp_engine.h"
+DEBUG_HEADER = ROOT / "include" / "mp_engine_debug.h"   # measurement / telemetry entry points: exported, not part of the product boundary
 DOC = ROOT / "INTEGRATION.md"
 BEGIN = "<!-- BEGIN ENTRY POINTS (generated from include/mp_engine.h by scripts/gen_entry_points.py -- do not edit by hand) -->"
 END = "<!-- END ENTRY POINTS -->"
@@ -88,10 +89,17 @@ def parse_header(path: Path = HEADER):
     return uniq
 
 
-def render_block(entries) -> str:
-    rows = [BEGIN, "", f"{len(entries)} exported entry points (`extern \"C\"`, `include/mp_engine.h`; line = where it is declared):", "",
+def render_block(entries, debug_entries=None) -> str:
+    if debug_entries is None:
+        debug_entries = parse_header(DEBUG_HEADER) if DEBUG_HEADER.is_file() else []
+    rows = [BEGIN, "", f"{len(entries)} entry points of the product boundary (`extern \"C\"`, `include/mp_engine.h`; line = where it is declared):", "",
             "| entry point | header line | what the header says it is / replaces (first sentence) |", "|---|---|---|"]
     for name, no, summary in entries:
+        rows.append(f"| `{name}` | {no} | {summary} |")
+    rows += ["", f"{len(debug_entries)} measurement / telemetry entry points (`include/mp_engine_debug.h`: exported by the same library, called by bench.py "
+                 "and scripts/ only -- not what an integrator binds):", "",
+             "| entry point | header line | what it reports (first sentence) |", "|---|---|---|"]
+    for name, no, summary in debug_entries:
         rows.append(f"| `{name}` | {no} | {summary} |")
     rows += ["", END]
     return "\n".join(rows)

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mp_engine.h"
+#include "mp_engine_debug.h"
 
 #define HIP_OK(e)                                                                      \
   do {                                                                                 \

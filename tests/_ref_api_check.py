@@ -15,6 +15,7 @@ from oracle import ref_import  # noqa: E402
 
 ref_import.install()
 
+import megapose.datasets.object_dataset as r_od  # noqa: E402
 import megapose.inference.depth_refiner as r_dr  # noqa: E402
 import megapose.inference.icp_refiner as r_icp  # noqa: E402
 import megapose.inference.pose_estimator as r_pe  # noqa: E402
@@ -65,6 +66,8 @@ PAIRS = [
     (r_pbr.Panda3dBatchRenderer, mp.renderer.Panda3dBatchRenderer, ["__init__", "render", "stop"]),
     (r_icp.ICPRefiner, mp.icp_refiner.ICPRefiner, ["__init__", "refine_poses"]),
     (r_dr.DepthRefiner, mp.icp_refiner.DepthRefiner, ["refine_poses"]),
+    (r_od.RigidObject, mp.object_dataset.RigidObject, ["__init__", "make_symmetry_poses"]),
+    (r_od.RigidObjectDataset, mp.object_dataset.RigidObjectDataset, ["__init__", "__getitem__", "get_object_by_label", "__len__", "filter_objects"]),
 ]
 for rc, oc, methods in PAIRS:
     for m in methods:

@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_c_abi_library_exports_every_declared_symbol():
     from megapose6d_amd import _lib
 
-    header = (ROOT / "include" / "mp_engine.h").read_text()
+    header = (ROOT / "include" / "mp_engine.h").read_text() + (ROOT / "include" / "mp_engine_debug.h").read_text()
     declared = set(re.findall(r"\b(mp_[A-Za-z0-9_]+)\s*\(", header))
     declared -= {"mp_stream"}
     assert declared, "no declarations parsed"
