@@ -307,6 +307,12 @@ int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int in_border,
                     int out_border, float* d_y_act, const float* d_act_scale, const float* d_act_shift,
                     mp_stream stream);
 
+/* y_act = relu(x * scale[c] + shift[c]) on the interior of a padded NHWC map (same border in and out): the pre-activation of a
+ * WideResNet's first block (models/wide_resnet.py:29-44 bn1 / relu) when the max pool in front of it is fused into the stem
+ * (mp_conv_stem_xrec_pool) -- bit-identical to the second output of mp_maxpool3x3s2. */
+int mp_bn_relu_nhwc(const float* d_x, int N, int H, int W, int C, int border, float* d_y_act, const float* d_act_scale,
+                    const float* d_act_shift, mp_stream stream);
+
 /* global average pool (+ optional fc) + heads: models/torchvision_resnet.py:311-314 and  */
 /* models/pose_rigid.py:326-333.  d_fc_w may be NULL (WideResNet: features = pooled).      */
 int mp_pool_fc_heads(const float* d_x, int N, int H, int W, int C, int in_border, const float* d_fc_w,

@@ -140,6 +140,7 @@ SIGNATURES = {
     "mp_conv_stem_xrec": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
     "mp_conv_stem_xrec_pool": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp, _i, _vp]),
     "mp_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mp_bn_relu_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mp_pool_fc_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mp_backbone_create": (_i, [_i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),
     "mp_backbone_create_wide": (_i, [_i, _i, _i, _i, _i, C.POINTER(NamedTensor), _i, C.POINTER(_vp)]),

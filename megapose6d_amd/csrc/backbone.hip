@@ -415,14 +415,16 @@ static int backbone_forward_impl(mp_backbone* bb, const float* d_x, int x_mode, 
     d.d_x = d_x; d.N = batch; d.H = h; d.W = w; d.C = bb->stem.Cin_p; d.c_real = bb->c_in; d.in_border = bb->in_border;
     d.d_bias = bb->stem.d_b; d.Cout = bb->stem.Cout; d.KH = bb->stem.K; d.KW = bb->stem.K; d.stride = 2; d.pad = bb->stem.pad;
     d.d_y = S; d.out_border = 1; d.relu = 1;
-    // vanilla ResNet: the max pool rides in the stem's epilogue and the stem map is never written (MP_STEM_POOL=0: separate kernels);
-    // the pre-activation WideResNets need relu(bn1(pooled)) as a second output of the pool, which takes the complete maximum
+    // the max pool rides in the stem's epilogue and the stem map is never written (MP_STEM_POOL=0: separate kernels)
     static const bool fuse_pool = !(getenv("MP_STEM_POOL") && atoi(getenv("MP_STEM_POOL")) == 0);
     const void* d_sparse = d_tile_flags ? d_sparse_blob : nullptr;   // background-tile walk where it applies
-    if (!bb->wide && fuse_pool) {
+    if (fuse_pool) {
       d.d_y = nullptr;
       rc = d_sparse ? mp_conv_stem_xrec_sparse(&d, d_stem_pieces, d_sparse, n_f32, d_tile_flags, A[0], 1, s)
                     : mp_conv_stem_xrec_pool(&d, d_stem_pieces, n_f32, A[0], 1, s);
+      // pre-activation WideResNets (round 6): relu(bn1(pooled)) by a small elementwise pass over the pooled map (the fused pool completes
+      // straddling windows with atomics, so the stem itself cannot emit it) instead of the separate pool kernel's pass over the 4x larger stem map
+      if (!rc && bb->wide) rc = mp_bn_relu_nhwc(A[0], batch, g.hs[0], g.ws[0], bb->stageC[0], 1, Aact[0], bb->blocks[0].pre.d_scale, bb->blocks[0].pre.d_shift, s);
       stem_pooled = true;
     } else {
       rc = d_sparse ? mp_conv_stem_xrec_sparse(&d, d_stem_pieces, d_sparse, n_f32, d_tile_flags, nullptr, 0, s)

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #define WB_SB __builtin_amdgcn_sched_barrier(0);
 #define WB_LOAD_U1(DST, ST, FI, K) \
-  if (!(DIAG & 4)) DST[(K) / 3][(K) % 3] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, (ST) * UB_STEP_BYTES + (FI) * UB_F_BYTES + (K) * 1024, 0);
+  if (!(DIAG & 4)) DST[(K) / 3][(K) % 3] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff + ((K) & 3) * 1024, (ST) * UB_STEP_BYTES + (FI) * UB_F_BYTES + ((K) >> 2) * 4096, 0);   /* (the low part of the fragment offset travels in the instruction: two scalar adds per point instead of six) */
 #define WB_LOAD_PATCH1(A, B, CS) if (!(DIAG & (2 | 128))) patch[A][B] = buf4(x_rsrc, x_voff, (CS) + (A) * row_bytes + (B) * pix_bytes);
   // transform row A of the patch in registers: T(A, b) forms the row combination (B^T d)[A][b]; O(A, col) one frequency plane -> LDS
 #define WB_F4ASM(OP, D, X, Y)                                                                             \
@@ -183,24 +183,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   acc[fi][((S) & 3) >> 1][(S) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                            \
       __builtin_bit_cast(bf16x8, AC[((S) & 3) >> 1][WB_PA[(S) >> 2]]), __builtin_bit_cast(bf16x8, UC[(S) & 1][WB_PB[(S) >> 2]]), \
       acc[fi][((S) & 3) >> 1][(S) & 1], 0, 0, 0);
-  // slots 0..15 of a group: the split of the NEXT point's fragments + the six weight requests of the next point
-#define WB_HEAD(AC, AN, UC, UN, NST, NFI)                                                                \
-  WB_M(0, AC, UC) WB_SB WB_SP0(AN, 0, 0) WB_SB                                                           \
-  WB_M(1, AC, UC) WB_SB WB_SP1(0, 0) WB_LOAD_U1(UN, NST, NFI, 0) WB_SB                                   \
-  WB_M(2, AC, UC) WB_SB WB_SP2(AN, 0, 0) WB_SB                                                           \
-  WB_M(3, AC, UC) WB_SB WB_SP3() WB_LOAD_U1(UN, NST, NFI, 1) WB_SB                                       \
-  WB_M(4, AC, UC) WB_SB WB_SP4(AN, 0, 0) WB_SP0(AN, 0, 1) WB_SB                                          \
-  WB_M(5, AC, UC) WB_SB WB_SP1(0, 1) WB_LOAD_U1(UN, NST, NFI, 2) WB_SB                                   \
-  WB_M(6, AC, UC) WB_SB WB_SP2(AN, 0, 1) WB_SB                                                           \
-  WB_M(7, AC, UC) WB_SB WB_SP3() WB_LOAD_U1(UN, NST, NFI, 3) WB_SB                                       \
-  WB_M(8, AC, UC) WB_SB WB_SP4(AN, 0, 1) WB_SP0(AN, 1, 0) WB_SB                                          \
-  WB_M(9, AC, UC) WB_SB WB_SP1(1, 0) WB_LOAD_U1(UN, NST, NFI, 4) WB_SB                                   \
-  WB_M(10, AC, UC) WB_SB WB_SP2(AN, 1, 0) WB_SB                                                          \
-  WB_M(11, AC, UC) WB_SB WB_SP3() WB_LOAD_U1(UN, NST, NFI, 5) WB_SB                                      \
-  WB_M(12, AC, UC) WB_SB WB_SP4(AN, 1, 0) WB_SP0(AN, 1, 1) WB_SB                                         \
-  WB_M(13, AC, UC) WB_SB WB_SP1(1, 1) WB_SB                                                              \
-  WB_M(14, AC, UC) WB_SB WB_SP2(AN, 1, 1) WB_SB                                                          \
-  WB_M(15, AC, UC) WB_SB WB_SP3() WB_SB
   // one frequency plane of the transform row in flight -> tplane (written to LDS one slot later: the store does not wait for its data)
 #define WB_TR_P(COL)                                                                                     \
   if (DIAG & (2 | 64)) {} else if ((COL) == 0) { WB_F4ASM(WB_OP_SUB, tplane, trw[0], trw[2]) }                                      \
@@ -208,69 +190,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   else if ((COL) == 2) { WB_F4ASM(WB_OP_SUB, tplane, trw[2], trw[1]) }                                 \
   else { WB_F4ASM(WB_OP_SUB, tplane, trw[1], trw[3]) }
 #define WB_TR_W(A, COL, VW) if (!(DIAG & (2 | 32))) *reinterpret_cast<float4*>((VW) + ((A) * 4 + (COL)) * (WT * WCK)) = tplane;
-  // slots 16..35, transform kind: rows R0, R1 of the next step's input transform, then the raw fragment reads of the point after next
-#define WB_TAIL_TR(AC, AN, UC, R0, R1, VW, VBN, N2FI)                                                    \
-  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_TR_T(R0, 0) WB_SB                                           \
-  WB_M(17, AC, UC) WB_SB WB_TR_T(R0, 1) WB_SB                                                            \
-  WB_M(18, AC, UC) WB_SB WB_TR_T(R0, 2) WB_SB                                                            \
-  WB_M(19, AC, UC) WB_SB WB_TR_T(R0, 3) WB_SB                                                            \
-  WB_M(20, AC, UC) WB_SB WB_TR_P(0) WB_SB                                                                \
-  WB_M(21, AC, UC) WB_SB WB_TR_W(R0, 0, VW) WB_TR_P(1) WB_SB                                             \
-  WB_M(22, AC, UC) WB_SB WB_TR_W(R0, 1, VW) WB_TR_P(2) WB_SB                                             \
-  WB_M(23, AC, UC) WB_SB WB_TR_W(R0, 2, VW) WB_TR_P(3) WB_SB                                             \
-  WB_M(24, AC, UC) WB_SB WB_TR_W(R0, 3, VW) WB_TR_T(R1, 0) WB_SB                                         \
-  WB_M(25, AC, UC) WB_SB WB_TR_T(R1, 1) WB_SB                                                            \
-  WB_M(26, AC, UC) WB_SB WB_TR_T(R1, 2) WB_SB                                                            \
-  WB_M(27, AC, UC) WB_SB WB_TR_T(R1, 3) WB_SB                                                            \
-  WB_M(28, AC, UC) WB_SB WB_TR_P(0) WB_SB                                                                \
-  WB_M(29, AC, UC) WB_SB WB_TR_W(R1, 0, VW) WB_TR_P(1) WB_SB                                             \
-  WB_M(30, AC, UC) WB_SB WB_TR_W(R1, 1, VW) WB_TR_P(2) WB_SB                                             \
-  WB_M(31, AC, UC) WB_SB WB_TR_W(R1, 2, VW) WB_TR_P(3) WB_SB                                             \
-  WB_M(32, AC, UC) WB_SB WB_TR_W(R1, 3, VW) WB_READ_RAW1(VBN, N2FI, 0) WB_SB                             \
-  WB_M(33, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 1) WB_SB                                                \
-  WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
-  WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
-  // slots 16..35, patch kind: rows R0, R1 of the patch of the step after next are requested
-#define WB_TAIL_PL(AC, AN, UC, R0, R1, CS, VBN, N2FI)                                                    \
-  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_LOAD_PATCH1(R0, 0, CS) WB_SB                                \
-  WB_M(17, AC, UC) WB_SB WB_LOAD_PATCH1(R0, 1, CS) WB_SB                                                 \
-  WB_M(18, AC, UC) WB_SB WB_LOAD_PATCH1(R0, 2, CS) WB_SB                                                 \
-  WB_M(19, AC, UC) WB_SB WB_LOAD_PATCH1(R0, 3, CS) WB_SB                                                 \
-  WB_M(20, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 0, CS) WB_SB                                                 \
-  WB_M(21, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 1, CS) WB_SB                                                 \
-  WB_M(22, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 2, CS) WB_SB                                                 \
-  WB_M(23, AC, UC) WB_SB WB_LOAD_PATCH1(R1, 3, CS) WB_SB                                                 \
-  WB_M(24, AC, UC) WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC)                                    \
-  WB_M(28, AC, UC) WB_M(29, AC, UC) WB_M(30, AC, UC) WB_M(31, AC, UC) WB_SB                              \
-  WB_M(32, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 0) WB_SB                                                \
-  WB_M(33, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 1) WB_SB                                                \
-  WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
-  WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
-
   // ---- the LAST K step (peeled, round 6): no next step to prepare -- no transform, no patch requests, no weights / fragments for a
   //      following point -- so its free slots carry the epilogue's residual loads instead (16 per thread, into the registers of the patch)
 #define WB_LOAD_RES1(K) if (RES) res[(K) >> 2][(K) & 3] = __builtin_amdgcn_raw_buffer_load_b128(r_res, voff[(K) >> 2][(K) & 3], 0, 0);
-  // slots 16..35 of points 0 / 1 of the last step: only the raw fragment reads of point 2 / 3
-#define WB_TAIL_RD(AC, AN, UC, VBN, N2FI)                                                                \
-  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_SB                                                          \
-  WB_M(17, AC, UC) WB_M(18, AC, UC) WB_M(19, AC, UC) WB_M(20, AC, UC) WB_M(21, AC, UC) WB_M(22, AC, UC) WB_M(23, AC, UC) WB_M(24, AC, UC)  \
-  WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC) WB_M(28, AC, UC) WB_M(29, AC, UC) WB_M(30, AC, UC) WB_M(31, AC, UC) WB_SB  \
-  WB_M(32, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 0) WB_SB                                                \
-  WB_M(33, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 1) WB_SB                                                \
-  WB_M(34, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 2) WB_SB                                                \
-  WB_M(35, AC, UC) WB_SB WB_READ_RAW1(VBN, N2FI, 3) WB_SB
-  // slots 16..35 of point 2 of the last step: residual loads 0..7
-#define WB_TAIL_RES(AC, AN, UC)                                                                          \
-  WB_M(16, AC, UC) WB_SB WB_SP4(AN, 1, 1) WB_LOAD_RES1(0) WB_SB                                          \
-  WB_M(17, AC, UC) WB_SB WB_LOAD_RES1(1) WB_SB                                                           \
-  WB_M(18, AC, UC) WB_SB WB_LOAD_RES1(2) WB_SB                                                           \
-  WB_M(19, AC, UC) WB_SB WB_LOAD_RES1(3) WB_SB                                                           \
-  WB_M(20, AC, UC) WB_SB WB_LOAD_RES1(4) WB_SB                                                           \
-  WB_M(21, AC, UC) WB_SB WB_LOAD_RES1(5) WB_SB                                                           \
-  WB_M(22, AC, UC) WB_SB WB_LOAD_RES1(6) WB_SB                                                           \
-  WB_M(23, AC, UC) WB_SB WB_LOAD_RES1(7) WB_SB                                                           \
-  WB_M(24, AC, UC) WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC) WB_M(28, AC, UC) WB_M(29, AC, UC)  \
-  WB_M(30, AC, UC) WB_M(31, AC, UC) WB_M(32, AC, UC) WB_M(33, AC, UC) WB_M(34, AC, UC) WB_M(35, AC, UC) WB_SB
+  // The split as single 4-instruction groups and single v_perm instructions (round 6): the slot tables place ONE group per MFMA gap
+  // (conv_wino_bf16_sched.h, generated and checked by scripts/gen_wino_schedule.py; the prologue still uses the fused WB_SP0..WB_SP4).
+  //   A: m = v & hi16    B (= WB_SP1): r = v - m    C: n = r & hi16    D (= WB_SP3): q = r - n
+  //   PRM_A / PRM_B / PRM_C: piece-1 / -2 / -3 pair j of the four elements = v_perm of (v | r | q)[2j + 1], [2j]
+#define WB_SPA(I, H)                                                                                     \
+  if (!(DIAG & 1)) asm volatile("v_and_b32 %0, 0xffff0000, %4\n\tv_and_b32 %1, 0xffff0000, %5\n\tv_and_b32 %2, 0xffff0000, %6\n\tv_and_b32 %3, 0xffff0000, %7"  \
+                                : "=&v"(sm0), "=&v"(sm1), "=&v"(sm2), "=&v"(sm3)                           \
+                                : "v"(raw[I][H].x), "v"(raw[I][H].y), "v"(raw[I][H].z), "v"(raw[I][H].w));
+#define WB_SPC()                                                                                         \
+  if (!(DIAG & 1)) asm volatile("v_and_b32 %0, 0xffff0000, %4\n\tv_and_b32 %1, 0xffff0000, %5\n\tv_and_b32 %2, 0xffff0000, %6\n\tv_and_b32 %3, 0xffff0000, %7"  \
+                                : "=&v"(sm0), "=&v"(sm1), "=&v"(sm2), "=&v"(sm3) : "v"(sr0), "v"(sr1), "v"(sr2), "v"(sr3));
+#define WB_PRM1(DST, E1, E0)                                                                             \
+  if (!(DIAG & 1)) { unsigned p_; asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(p_) : "v"(E1), "v"(E0), "s"(0x07060302u)); DST = p_; }
+#define WB_PRM_A(AN, I, H, J) WB_PRM1(AN[I][0][2 * (H) + (J)], ((J) ? raw[I][H].w : raw[I][H].y), ((J) ? raw[I][H].z : raw[I][H].x))
+#define WB_PRM_B(AN, I, H, J) WB_PRM1(AN[I][1][2 * (H) + (J)], ((J) ? sr3 : sr1), ((J) ? sr2 : sr0))
+#define WB_PRM_C(AN, I, H, J) WB_PRM1(AN[I][2][2 * (H) + (J)], ((J) ? sq3 : sq1), ((J) ? sq2 : sq0))
+#include "conv_wino_bf16_sched.h"
+
   // point 3 of the last step: nothing follows it -- 36 MFMAs, residual loads 8..15 in the first gaps
 #define WB_POINT_LAST(AC, UC)                                                                            \
   WB_M(0, AC, UC) WB_SB WB_LOAD_RES1(8) WB_SB                                                            \
@@ -402,15 +342,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef MP_WINO_PERMUTE
     _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) asm volatile("" : "+v"(perm_live[k]));   // (in registers, not in scratch)
 #endif
-    { constexpr int fi = 0; WB_HEAD(AA, AB, Ua, Ub, st, 1) WB_TAIL_TR(AA, AB, Ua, 0, 1, vwn, vb, 2) }
-    { constexpr int fi = 1; WB_HEAD(AB, AA, Ub, Ua, st, 2) WB_TAIL_TR(AB, AA, Ub, 2, 3, vwn, vb, 3) }
+    { constexpr int fi = 0; WB_BLK_TR(AA, AB, Ua, Ub, st, 1, 0, 1, vwn, vb, 2) }
+    { constexpr int fi = 1; WB_BLK_TR(AB, AA, Ub, Ua, st, 2, 2, 3, vwn, vb, 3) }
     __syncthreads();
 #ifdef MP_CONV_EXPERIMENTS
     if (DIAG & 8) { for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(1); }    // skew the four waves by 64 cycles each
     if (DIAG & 16) { for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(2); }   // ... by 128 cycles each
 #endif
-    { constexpr int fi = 2; WB_HEAD(AA, AB, Ua, Ub, st, 3) WB_TAIL_PL(AA, AB, Ua, 0, 1, cs_patch, vbn, 0) }
-    { constexpr int fi = 3; WB_HEAD(AB, AA, Ub, Ua, st + 1, 0) WB_TAIL_PL(AB, AA, Ub, 2, 3, cs_patch, vbn, 1) }
+    { constexpr int fi = 2; WB_BLK_PL(AA, AB, Ua, Ub, st, 3, 0, 1, cs_patch, vbn, 0) }
+    { constexpr int fi = 3; WB_BLK_PL(AB, AA, Ub, Ua, st + 1, 0, 2, 3, cs_patch, vbn, 1) }
   }
   {   // the last step: nothing to prepare for a following one (see WB_TAIL_RD / WB_TAIL_RES / WB_POINT_LAST)
     const int st = ns - 1;
@@ -418,9 +358,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef MP_WINO_PERMUTE
     _Pragma("unroll") for (int k = 0; k < MP_WINO_PERMUTE; ++k) asm volatile("" : "+v"(perm_live[k]));
 #endif
-    { constexpr int fi = 0; WB_HEAD(AA, AB, Ua, Ub, st, 1) WB_TAIL_RD(AA, AB, Ua, vb, 2) }
-    { constexpr int fi = 1; WB_HEAD(AB, AA, Ub, Ua, st, 2) WB_TAIL_RD(AB, AA, Ub, vb, 3) }
-    { constexpr int fi = 2; WB_HEAD(AA, AB, Ua, Ub, st, 3) WB_TAIL_RES(AA, AB, Ua) }
+    { constexpr int fi = 0; WB_BLK_RD(AA, AB, Ua, Ub, st, 1, vb, 2) }
+    { constexpr int fi = 1; WB_BLK_RD(AB, AA, Ub, Ua, st, 2, vb, 3) }
+    { constexpr int fi = 2; WB_BLK_RES(AA, AB, Ua, Ub, st, 3) }
     { constexpr int fi = 3; WB_POINT_LAST(AB, Ub) }
   }
   if (clk_sample) {
@@ -438,12 +378,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
   __syncthreads();   // (the epilogue reuses the V stages)
 #undef WB_POINT_LAST
-#undef WB_TAIL_RES
-#undef WB_TAIL_RD
+#undef WB_BLK_RES
+#undef WB_BLK_RD
+#undef WB_BLK_PL
+#undef WB_BLK_TR
+#undef WB_PRM_C
+#undef WB_PRM_B
+#undef WB_PRM_A
+#undef WB_PRM1
+#undef WB_SPC
+#undef WB_SPA
 #undef WB_LOAD_RES1
-#undef WB_TAIL_PL
-#undef WB_TAIL_TR
-#undef WB_HEAD
 #undef WB_M
 #undef WB_READ_RAW1
 #undef WB_SPLIT4

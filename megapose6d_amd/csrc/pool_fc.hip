@@ -53,6 +53,34 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
   }
 }
 
+// y_act = relu(x * scale[c] + shift[c]) over the interior of a padded NHWC map: one thread per (pixel, 4 channels).  The pre-activation
+// WideResNets need relu(bn1(pooled)) next to the pooled stem map; with the max pool fused into the stem's epilogue (windows that straddle
+// tiles are completed by atomics, so no workgroup sees the final maximum) this small pass produces it -- the same fmaf / fmaxf as the
+// second output of maxpool3x3s2_kernel, bit for bit.
+__global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ x, int N, int H, int W, int C, int b, float* __restrict__ y_act,
+                                                      const float* __restrict__ sc, const float* __restrict__ sh) {
+  const int c4n = C / 4;
+  const long total = (long)N * H * W * c4n;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % c4n);
+  long t = idx / c4n;
+  const int xx = (int)(t % W);
+  t /= W;
+  const int yy = (int)(t % H);
+  const int n = (int)(t / H);
+  const size_t o = (((size_t)n * (H + 2 * b) + yy + b) * (W + 2 * b) + xx + b) * C + c4 * 4;
+  const float4 m = *reinterpret_cast<const float4*>(x + o);
+  const float4 s = *reinterpret_cast<const float4*>(sc + c4 * 4);
+  const float4 h = *reinterpret_cast<const float4*>(sh + c4 * 4);
+  float4 a;
+  a.x = fmaxf(fmaf(m.x, s.x, h.x), 0.f);
+  a.y = fmaxf(fmaf(m.y, s.y, h.y), 0.f);
+  a.z = fmaxf(fmaf(m.z, s.z, h.z), 0.f);
+  a.w = fmaxf(fmaf(m.w, s.w, h.w), 0.f);
+  *reinterpret_cast<float4*>(y_act + o) = a;
+}
+
 // one workgroup per batch row: mean over H*W (sequential, row-major like torch), optional fc, heads, sigmoid
 __global__ __launch_bounds__(256) void pool_fc_heads_kernel(const float* __restrict__ x, int H, int W, int C, int ib,
                                                             const float* __restrict__ fc_w, const float* __restrict__ fc_b,
@@ -116,6 +144,18 @@ extern "C" int mp_maxpool3x3s2(const float* d_x, int N, int H, int W, int C, int
   ProfScope prof("maxpool3x3s2", 0.0, 4.0 * C * ((double)N * H * W + (double)N * Ho * Wo * (d_y && d_y_act ? 2 : 1)), (hipStream_t)stream);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, N, H, W, C,
                      in_border, d_y, out_border, Ho, Wo, d_y_act, d_sc, d_sh);
+  MP_CHECK_HIP(hipGetLastError());
+  return MP_OK;
+}
+
+extern "C" int mp_bn_relu_nhwc(const float* d_x, int N, int H, int W, int C, int border, float* d_y_act, const float* d_sc, const float* d_sh,
+                              mp_stream stream) {
+  MP_REQUIRE(d_x && d_y_act && d_sc && d_sh, "mp_bn_relu_nhwc: null pointer");
+  MP_REQUIRE(C % 4 == 0 && border >= 0, "mp_bn_relu_nhwc: C %% 4 == 0 required");
+  const long total = (long)N * H * W * (C / 4);
+  if (total == 0) return MP_OK;
+  ProfScope prof("bn_relu", 0.0, 8.0 * C * (double)N * H * W, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_relu_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d_x, N, H, W, C, border, d_y_act, d_sc, d_sh);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

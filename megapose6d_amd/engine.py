@@ -476,6 +476,12 @@ def maxpool3x3s2(x, N, H, W, Cc, in_border, y, out_border, y_act=None, sc=None, 
                                       _stream()))
 
 
+def bn_relu_nhwc(x, N, H, W, Cc, border, y_act, sc, sh) -> None:
+    """y_act = relu(x * sc[c] + sh[c]) on the interior of a padded NHWC map (mp_bn_relu_nhwc: the WideResNets' first pre-activation
+    behind the stem's fused max pool)"""
+    check(_lib.load().mp_bn_relu_nhwc(x.data_ptr(), N, H, W, Cc, border, y_act.data_ptr(), sc.data_ptr(), sh.data_ptr(), _stream()))
+
+
 def pool_fc_heads(x, N, H, W, Cc, in_border, fc_w, fc_b, n_feat, head_w, head_b, n_out, feat, out, sigmoid) -> None:
     check(_lib.load().mp_pool_fc_heads(x.data_ptr(), N, H, W, Cc, in_border, _ptr(fc_w), _ptr(fc_b), n_feat, head_w.data_ptr(),
                                        head_b.data_ptr(), n_out, _ptr(feat), out.data_ptr(), _ptr(sigmoid), _stream()))

@@ -139,35 +139,40 @@ def logit_flip_rule(err, scale: float, tol: float = 1e-4) -> Dict[str, object]:
             "ok": bool(e.size > 0 and n_over <= allowed and (e.max() < 2 * tol * scale))}
 
 
-# What a pose difference does to a score logit (measured, profiles/r05_parity_config3_records.txt: BASELINE configs[2], five un-damped
+# What a pose difference does to a score logit (measured, profiles/r05_parity_config3_records.txt: BASELINE configs[2], five chained RGBD
 # refiner iterations: final poses 3.4e-5 / 5.6e-5 apart -> chained score logits 7e-5 / 2.0e-4 apart, teacher-forced ones <= 9e-6): <= 3.6 logit
-# units per unit of pose error on the seeded networks; the chained bound carries it with a margin of ~3.
+# units per unit of pose error on the seeded networks (8 rows); the chained bound carries it with a margin of ~3 and is CAPPED.
 POSE_TO_LOGIT = 10.0
+CHAINED_CAP = 3.0      # x tol x scale: no chained logit may be further off than that, whatever its row's pose difference
 
 
 def chained_score_rule(res: Dict[str, object], tol: float = 1e-4) -> Dict[str, object]:
-    """The score logits compared CHAINED (the oracle scores its own final pose, the device its own): each row within
-    tol x scale + POSE_TO_LOGIT x (that row's final-pose difference) -- the scoring stage's own bound plus what the refiner's pose
-    difference, itself held to `tol`, can move the re-render.  The scoring stage ALONE is held to `logit_flip_rule` through the
-    teacher-forced comparison (`score_logit_errs_teacher_forced`)."""
+    """SECONDARY, explicitly opted-in rule for score logits compared CHAINED (the oracle scores its own final pose, the device its own)
+    on workloads whose refiner chain lets the two final poses drift apart within the pose tolerance: each row within
+    min(2 tol x scale + POSE_TO_LOGIT x (that row's final-pose difference), CHAINED_CAP x tol x scale).  The gate of the default path is
+    `logit_flip_rule` on the same chained logits (parity_ok(..., chained="strict")); the scoring stage ALONE is always held to
+    `logit_flip_rule` through the teacher-forced comparison (`score_logit_errs_teacher_forced`).  (the relaxed bound must not be
+    the default gate, and it is capped.)"""
     e = np.abs(np.asarray(res["score_logit_errs"], dtype=np.float64))
     scale = float(res.get("logit_scale", 1.0))
     pe = np.abs(np.asarray(res.get("final_pose_errs", np.zeros_like(e)), dtype=np.float64))
-    bound = 2.0 * tol * scale + POSE_TO_LOGIT * pe      # (2 x tol: the flip rule's cap for a row with a flipped sample)
+    bound = np.minimum(2.0 * tol * scale + POSE_TO_LOGIT * pe, CHAINED_CAP * tol * scale)
     return {"rows": int(e.size), "max_err": float(e.max()) if e.size else 0.0, "max_over_bound": float((e / bound).max()) if e.size else 0.0,
-            "ok": bool(e.size > 0 and (e < bound).all())}
+            "cap": CHAINED_CAP * tol * scale, "ok": bool(e.size > 0 and (e < bound).all())}
 
 
-def parity_ok(res: Dict[str, object], tol: float = 1e-4) -> bool:
-    """north_star tolerance: 1e-4 on the pose tensors; logits by `logit_flip_rule` (the score logits teacher-forced where the harness
-    computed them, and chained by `chained_score_rule`)"""
+def parity_ok(res: Dict[str, object], tol: float = 1e-4, chained: str = "strict") -> bool:
+    """north_star tolerance: 1e-4 on the pose tensors; every logit comparison by `logit_flip_rule` -- coarse logits, the score logits
+    teacher-forced (where the harness computed them) AND chained.  chained="pose_aware" (opt-in, for chains that are known to drift within
+    the pose tolerance): the chained score logits by `chained_score_rule` instead."""
+    assert chained in ("strict", "pose_aware"), chained
     scale = float(res.get("logit_scale", 1.0))
     ok = res.get("coarse_TCO_max_err", 0.0) < tol
     if "coarse_logit_errs" in res:
         ok = ok and logit_flip_rule(res["coarse_logit_errs"], scale, tol)["ok"]
     if "score_logit_errs_teacher_forced" in res:
-        ok = ok and logit_flip_rule(res["score_logit_errs_teacher_forced"], scale, tol)["ok"] and chained_score_rule(res, tol)["ok"]
-    elif "score_logit_errs" in res:
-        ok = ok and logit_flip_rule(res["score_logit_errs"], scale, tol)["ok"]
+        ok = ok and logit_flip_rule(res["score_logit_errs_teacher_forced"], scale, tol)["ok"]
+    if "score_logit_errs" in res:
+        ok = ok and (chained_score_rule(res, tol)["ok"] if chained == "pose_aware" else logit_flip_rule(res["score_logit_errs"], scale, tol)["ok"])
     ok = ok and all(e < tol for e in res.get("pose_max_err_per_iter", []))
     return bool(ok)

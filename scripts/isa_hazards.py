@@ -170,7 +170,9 @@ def lint(text):
                     flag("R2", k, f"{r} is the destination of a load still in flight: {ins[order[pending[r]]]['text']}")
         # R3
         if x["asm"] is not None:
-            w = asm_written.setdefault((x["asm"], k // 100000), set())
+            if k == 0 or ins[order[k - 1]]["asm"] != x["asm"] or order[k - 1] != n - 1:
+                asm_written[x["asm"]] = set()      # (first instruction of this execution of the statement: loops are walked twice)
+            w = asm_written.setdefault(x["asm"], set())
             for r in u:
                 if r in w:
                     flag("R3", k, f"{r} was written earlier in the same asm statement (missing early-clobber?)")

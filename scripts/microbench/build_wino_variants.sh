@@ -27,10 +27,12 @@ if [ "$MODE" = "ab" ]; then   # A/B and profiling builds of the round: phases = 
     link $n
   done
 fi
-if [ "$MODE" = "ab" ]; then   # base = the kernel as it was before the round-6 restructuring (commit f0b2340, scalar arithmetic): same-box A/B
+if [ "$MODE" = "ab" ]; then   # base = the kernel at git revision $BASE_REV (default HEAD = before the edit being measured): same-box A/B
+  REV=${BASE_REV:-HEAD}
   mkdir -p $B/base/src
   cp $C/*.h $B/base/src/
-  git show f0b2340:megapose6d_amd/csrc/conv_wino_bf16.hip > $B/base/src/conv_wino_bf16.hip
+  for f in conv_wino_bf16.hip wino_common.h; do git show $REV:megapose6d_amd/csrc/$f > $B/base/src/$f; done
+  git show $REV:megapose6d_amd/csrc/conv_wino_bf16_sched.h > $B/base/src/conv_wino_bf16_sched.h 2>/dev/null || rm -f $B/base/src/conv_wino_bf16_sched.h
   /opt/rocm/bin/hipcc $F -DMP_WINO_PK=0 -c $B/base/src/conv_wino_bf16.hip -o $B/base/conv_wino_bf16.o
   link base
 fi

@@ -16,25 +16,29 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _check(res):
+def _check(res, chained="strict"):
+    """chained: how the CHAINED score logits (each side scores its own final pose) are held -- "strict" = oracle.harness.logit_flip_rule, the
+    gate of the default path; "pose_aware" = oracle.harness.chained_score_rule (capped, secondary), opted into by the one workload whose
+    chain is known to drift within the pose tolerance, with both figures printed."""
     scale = res["logit_scale"]
     assert scale < 50 and res.get("feature_max", 1.0) < 10.0, res  # O(1) networks: the bounds below are (near-)absolute
     assert res.get("coarse_TCO_max_err", 0.0) < 1e-5, res
     # logits: 1e-4 x max(1, |logit|), flipped-silhouette rows counted (<= 1 per 64 sampled rows, each <= 2e-4): oracle.harness.logit_flip_rule
-    from oracle.harness import logit_flip_rule
-
-    from oracle.harness import chained_score_rule
+    from oracle.harness import chained_score_rule, logit_flip_rule
 
     # the scoring stage alone: the oracle scores the DEVICE's final pose of the sampled rows (teacher-forced) -- the strict rule
     for key in ("coarse_logit_errs", "score_logit_errs_teacher_forced"):
         if key in res:
             r = logit_flip_rule(res[key], scale, TOL)
             assert r["ok"], (key, r)
-    # chained (each side scores its own final pose): the strict bound + what the refiner's pose difference (itself < TOL, asserted below)
-    # moves the re-render -- oracle.harness.chained_score_rule
     if "score_logit_errs" in res:
-        r = chained_score_rule(res, TOL)
-        assert r["ok"], ("score_logit_errs (chained)", r, res.get("final_pose_errs"))
+        strict = logit_flip_rule(res["score_logit_errs"], scale, TOL)
+        if chained == "strict":
+            assert strict["ok"], ("score_logit_errs (chained, strict rule)", strict, res.get("final_pose_errs"))
+        else:
+            r = chained_score_rule(res, TOL)
+            print("chained score logits:", {"strict_rule": strict, "pose_aware_rule": r, "final_pose_max_err": res.get("final_pose_max_err")})
+            assert r["ok"], ("score_logit_errs (chained, pose-aware rule)", r, res.get("final_pose_errs"))
     for n, e in enumerate(res.get("pose_max_err_per_iter", [])):
         assert e < TOL, (n, res)
     for n, e in enumerate(res.get("pose_out_max_err_per_iter", [])):
@@ -58,6 +62,33 @@ def test_config2_rgb_1x576x5_sampled_rows_vs_oracle():
     assert len(res["pose_out_max_err_per_iter"]) == 5
 
 
+def test_config2_chained_parity_with_a_strong_pose_head():
+    """The headline config CHAINED over its 5 iterations with a pose head 5x stronger than the seeded default (pose_head_scale 0.25: every
+    iteration moves a pose by ~0.1, so a conv-stack difference of iteration n is fed, amplified, into the render of iteration n + 1): poses
+    within 1e-4 after every iteration, chained score logits under the strict rule.  Measured (profiles/r06_parity_undamped_config2.txt,
+    scripts/parity_undamped_config2.py): 2.3e-5 after 5 iterations -- the same level on the fp32-MFMA Winograd kernel (3.0e-5) and on the
+    direct fp32-MFMA kernel (3.2e-5): no kernel family owns it; at 'weights x 1' (updates of 0.5 - 0.8 per iteration, chains crossing the
+    near plane) every family incl. the direct fp32 kernel is at 4e-4 -- not an operating point any fp32 implementation can hold to 1e-4.
+    Reference: models/pose_rigid.py:498-604, lib3d/cosypose_ops.py:33-58."""
+    from tests.support import synthetic as syn
+    from tests.support.scene import make_scene
+    from oracle import harness
+
+    tmp = tempfile.mkdtemp(prefix="mp_p2s_")
+    est, obs, det, _ = make_scene(n_objects=1, seed=0, SO3_grid_size=576, tmp_dir=tmp, pose_head_scale=0.25)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=5, n_pose_hypotheses=576)
+    preds = extra["refiner_all_hypotheses"]["preds"]
+    step = (preds["iteration=1"].poses - preds["iteration=1"].poses_input).abs().flatten(1).max(dim=1).values
+    assert step.median().item() > 0.05, step.median().item()   # the head really is strong: ~0.09 per iteration
+    ds = syn.make_object_dataset(tmp, n_objects=1, seed=0)
+    oest, db = harness.make_oracle_estimator(ds, 576, bsz=16, pose_head_scale=0.25)
+    res = harness.sampled_rows_parity(oest, db, obs.images.cpu(), obs.K.cpu(), det.bboxes.cpu(), extra,
+                                      coarse_rows=[0, 383], refine_rows=[0, 191, 320, 575], n_iterations=5)
+    print("strong pose head:", {k: res[k] for k in ("pose_max_err_per_iter", "final_pose_max_err", "score_logit_max_err")})
+    _check(res)
+    assert res["final_pose_max_err"] < 5e-5, res["final_pose_max_err"]   # measured 2.3e-5: keep a 2x margin to the tolerance visible
+
+
 def test_config3_rgbd_wide_resnet_8x576_sampled_rows_vs_oracle():
     """BASELINE configs[2]: RGB coarse + 32-channel RGBD refiner on WideResNet-34, 8 objects x 576 hypotheses, all refined"""
     from tests.support import synthetic as syn
@@ -73,7 +104,10 @@ def test_config3_rgbd_wide_resnet_8x576_sampled_rows_vs_oracle():
     res = harness.sampled_rows_parity(oest, db, obs.images.cpu(), obs.K.cpu(), det.bboxes.cpu(), extra,
                                       coarse_rows=[5, 576 + 200, 3 * 576 + 575, 7 * 576 + 1], refine_rows=[3, 2 * 576 + 17, 5 * 576 + 300, 8 * 576 - 1],
                                       n_iterations=5)
-    _check(res)
+    # the RGBD chain drifts further within the pose tolerance than the RGB one (profiles/r05_parity_config3_records.txt: 3.4e-5 on the fp32
+    # tensor path, 5.6e-5 on records), and a pose difference moves the re-render: the chained logits of THIS workload are held to the
+    # pose-aware rule (capped at 3e-4); everything else -- poses per iteration, coarse logits, teacher-forced score logits -- to the strict ones
+    _check(res, chained="pose_aware")
 
 
 def test_config4_64_detections_two_detections_vs_oracle():

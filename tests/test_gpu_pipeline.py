@@ -286,14 +286,20 @@ def test_bench_multi_rank_code_path_with_two_ranks_on_one_gpu():
     env = dict(os.environ, MP_BENCH_SHARED_GPU="1")
     port = 29800 + os.getpid() % 1000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+           str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["objects"] == 2
     assert j["rccl"]["backend"] == "gloo" and j["rccl"]["world_size"] == 2 and j["rccl"]["all_gathers_per_step"] == 3
+    assert j["rccl"]["final_poses_identical_across_ranks"] is True
+    # the strong-scaled companion (BASELINE configs[3]: 64 detections, K = 5) measured in the same launch by both ranks
+    sc = j["strong_scaling_config4"]
+    assert "error" not in sc, sc
+    assert sc["scaling"] == "strong" and sc["n_gpus"] == 2 and sc["all_gathers_per_step"] == 3 and sc["refiner_rows_per_rank"] == 160
+    assert sc["pose_hypotheses_per_s"] > 0
     assert [r["rank"] for r in j["per_rank"]] == [0, 1] and all(r["timed_region_ms_per_step"] > 0 for r in j["per_rank"])
     assert 0.0 < j["host"]["replicated_topk_ms_per_step"] < 200.0
 

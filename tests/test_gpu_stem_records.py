@@ -133,7 +133,8 @@ def test_stem_conv_on_rgbd_records_with_scattered_fp32_channels(eng, K):
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("case", [STEM_CASES[1], STEM_CASES[0], (2, 3, 24, 34, 70, 7, 64), (1, 3, 24, 240, 320, 7, 64)])
+@pytest.mark.parametrize("case", [STEM_CASES[1], STEM_CASES[0], (2, 3, 24, 34, 70, 7, 64), (1, 3, 24, 240, 320, 7, 64),
+                                  STEM_CASES[2], STEM_CASES[4], (1, 3, 24, 240, 320, 5, 64), (2, 8, 24, 34, 70, 5, 64)])   # + the WideResNets' 5x5 stem (round 6)
 def test_fused_max_pool_equals_the_separate_pool_kernel_bit_for_bit(eng, case):
     """mp_conv_stem_xrec_pool (max pool taken from the tile in LDS, windows that straddle tiles combined with atomicMax) against
     mp_conv_stem_xrec + mp_maxpool3x3s2: the same fp32 maxima -> identical bits, whatever the order of the atomics; ragged tiles, odd
@@ -163,6 +164,15 @@ def test_fused_max_pool_equals_the_separate_pool_kernel_bit_for_bit(eng, case):
             assert torch.equal(y2, y)
     tref = F.max_pool2d(F.relu(F.conv2d(x, w * scale.view(-1, 1, 1, 1), bias, stride=2, padding=pad)), 3, 2, 1)
     assert (eng.padded_view(ref, N, Hq, Wq, Cout, 1).permute(0, 3, 1, 2).cpu() - tref).abs().max().item() < 1e-5 * max(1.0, tref.abs().max().item())
+    # the pre-activation a WideResNet's first block reads (models/wide_resnet.py:29-44): second output of the separate pool kernel ==
+    # mp_bn_relu_nhwc over the fused pool's map, bit for bit
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.2).cuda()
+    act_ref = eng.padded_nhwc(N, Hq, Wq, Cout, 1, "cuda")
+    eng.maxpool3x3s2(y, N, Ho, Wo, Cout, 1, None, 1, y_act=act_ref, sc=sc, sh=sh)
+    act = eng.padded_nhwc(N, Hq, Wq, Cout, 1, "cuda")
+    eng.bn_relu_nhwc(got, N, Hq, Wq, Cout, 1, act, sc, sh)
+    torch.cuda.synchronize()
+    assert torch.equal(act, act_ref) and act.abs().max() > 0
 
 
 def test_stem_map_of_a_batch_beyond_4_gb_is_addressed_per_image(eng):

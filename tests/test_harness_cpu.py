@@ -75,3 +75,19 @@ def test_sampled_rows_parity_is_exact_on_the_oracles_own_run():
     extra["refiner_all_hypotheses"]["preds"]["iteration=1"] = SimpleNamespace(poses=res["refiner_poses"][0].flip(0))
     bad = harness.sampled_rows_parity(oest, db, images, K, bboxes, extra, coarse_rows=[], refine_rows=[0, 1], n_iterations=n_it)
     assert not harness.parity_ok(bad)
+
+
+def test_chained_logit_rules_strict_by_default_and_capped_when_opted_in():
+    """the strict flip rule gates the chained score logits by default; the pose-aware rule is an explicit opt-in and capped."""
+    from oracle import harness
+
+    base = {"logit_scale": 1.0, "coarse_TCO_max_err": 0.0, "pose_max_err_per_iter": [5e-5], "score_logit_errs_teacher_forced": [1e-6] * 8}
+    drift = dict(base, score_logit_errs=[2.0e-4] + [1e-5] * 7, final_pose_errs=[5.6e-5] + [1e-6] * 7)   # the round-5 RGBD figures
+    assert not harness.parity_ok(drift)                          # 2.0e-4 is not < 2 x tol: the default gate refuses it
+    assert harness.parity_ok(drift, chained="pose_aware")        # ... the opt-in rule carries the row's pose difference (2e-4 + 5.6e-4, capped at 3e-4)
+    r = harness.chained_score_rule(drift)
+    assert r["ok"] and abs(r["cap"] - 3e-4) < 1e-12
+    big = dict(base, score_logit_errs=[3.5e-4] + [1e-5] * 7, final_pose_errs=[9e-5] + [1e-6] * 7)
+    assert not harness.parity_ok(big, chained="pose_aware")      # over the cap, whatever the pose difference
+    fine = dict(base, score_logit_errs=[3e-5] * 8, final_pose_errs=[2e-6] * 8)                           # the headline config's figures
+    assert harness.parity_ok(fine) and harness.parity_ok(fine, chained="pose_aware")
