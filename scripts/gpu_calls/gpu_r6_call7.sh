@@ -24,3 +24,17 @@ for f in sorted(glob.glob("gpurun_out/r6c7/bench_*.json")):
     except Exception as e: print(f, "error", e)
 PY
 tail -n 3 $O/bench.err
+# the tests of the other round-6 changes: WideResNet fused pool, strict / pose-aware logit rules, strong pose head, bench --gpus 2 on one GPU
+timeout 1500 python -m pytest tests/test_gpu_stem_records.py tests/test_gpu_parity_full_size.py tests/test_gpu_pipeline.py -m gpu -q -p no:cacheprovider -s > $O/pytest_more.log 2>&1; echo "rc=$?" >> $O/pytest_more.log
+grep -E "strong pose head|chained score logits" $O/pytest_more.log | cut -c1-400; tail -n 4 $O/pytest_more.log
+for bbk in resnet34; do
+  timeout 300 python bench.py --config 3 --backbone $bbk --steps 2 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_c3_$bbk.json 2>> $O/bench.err
+  MP_STEM_POOL=0 timeout 300 python bench.py --config 3 --backbone $bbk --steps 2 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_c3_${bbk}_nopool.json 2>> $O/bench.err
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r6c7/bench_c3*.json")):
+    try:
+        b=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], round(b["value"],1), round(b["ms_per_step"],2), {k:v for k,v in list(b["kernel_ms_per_step"].items())[:8]})
+    except Exception as e: print(f, "error", e)
+PY
