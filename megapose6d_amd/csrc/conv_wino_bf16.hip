@@ -64,7 +64,9 @@ __device__ unsigned long long g_wb_phase[10];
 
 // DIAG (timing experiments only, wrong results; MP_WINO_DIAG): 1 = no split work, 2 = no patch requests / transform, 4 = no weight requests
 // RES: the launch has a residual input; its 16 loads per thread ride under the MFMAs of the LAST K step (round 6).
-template <int DIAG, bool RES>
+// ACT: the launch writes the second, pre-activated output relu(y * scale + shift) (WideResNet blocks).  Both compile-time, and ReLU is a
+// maximum with 0 or -inf: the store loop of the epilogue is straight-line code (it was 48 branches + their mask bookkeeping per workgroup).
+template <int DIAG, bool RES, bool ACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_bf16x9(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //      are already in registers (computed after the prologue's barrier / requested under the last K step). -------------------------------
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
-  if (p.y_act) {
+  if (ACT && p.y_act) {   // (p.y_act is set whenever ACT is, except in the timing-experiment instances)
     sc = *reinterpret_cast<const float4*>(p.act_scale + n);
     sh = *reinterpret_cast<const float4*>(p.act_shift + n);
   }
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //  built and measured: that workgroup's prologue gets 1.1 k cycles shorter, this epilogue 1.5 - 2.9 k cycles longer (the scattered requests
   //  queue in front of the stores): a net loss on every layer, removed.  profiles/r06_wino_kloop_experiments.txt)
   const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y ? out_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, p.y_act ? out_bytes : 0, 0x00020000);
-  const bool relu = p.relu != 0, has_act = p.y_act != nullptr;
+  const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.y_act, 0, (ACT && p.y_act) ? out_bytes : 0, 0x00020000);
+  const float relu_floor = p.relu != 0 ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int tl = it * 16 + (tid >> 4);
@@ -474,11 +476,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const u32x4 rr = res[it][ii * 2 + jj];
           v.x += __uint_as_float(rr.x); v.y += __uint_as_float(rr.y); v.z += __uint_as_float(rr.z); v.w += __uint_as_float(rr.w);
         }
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
         u32x4 o;
         o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
         __builtin_amdgcn_raw_buffer_store_b128(o, r_y, voff[it][ii * 2 + jj], 0, 0);
-        if (has_act) {
+        if (ACT) {
           u32x4 a;
           a.x = __float_as_uint(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f)); a.y = __float_as_uint(fmaxf(fmaf(v.y, sc.y, sh.y), 0.f));
           a.z = __float_as_uint(fmaxf(fmaf(v.z, sc.z, sh.z), 0.f)); a.w = __float_as_uint(fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
@@ -621,13 +623,13 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   MP_CHECK_HIP(hipGetDevice(&dev));
   static int attr_dev = -1;
   if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
-    MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
+#define WB_ATTR(...) MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
+    WB_ATTR(0, false, false) WB_ATTR(0, true, false) WB_ATTR(0, false, true) WB_ATTR(0, true, true)
 #ifdef MP_CONV_EXPERIMENTS
-#define WB_DIAG_ATTR(D) MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
-    WB_DIAG_ATTR(1) WB_DIAG_ATTR(2) WB_DIAG_ATTR(4) WB_DIAG_ATTR(7) WB_DIAG_ATTR(8) WB_DIAG_ATTR(16) WB_DIAG_ATTR(32) WB_DIAG_ATTR(64) WB_DIAG_ATTR(128)
-#undef WB_DIAG_ATTR
+    WB_ATTR(1, true, true) WB_ATTR(2, true, true) WB_ATTR(4, true, true) WB_ATTR(7, true, true) WB_ATTR(8, true, true) WB_ATTR(16, true, true)
+    WB_ATTR(32, true, true) WB_ATTR(64, true, true) WB_ATTR(128, true, true)
 #endif
+#undef WB_ATTR
     attr_dev = dev;
   }
   const long n_wg = ((n_tiles + WT - 1) / WT) * p.n_cblocks;
@@ -642,14 +644,17 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   }
   p.telemetry = g_wb_telemetry.load(std::memory_order_relaxed);
   ProfScope prof("conv3x3_wino_bf16x9<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout)) + 6.0 * 16.0 * d->C * d->Cout, s, executed, 2500.0);
+  const dim3 grid((unsigned)n_wg), block(256);
 #ifdef MP_CONV_EXPERIMENTS
   const int diag = getenv("MP_WINO_DIAG") ? atoi(getenv("MP_WINO_DIAG")) : 0;
-#define WB_DIAG_LAUNCH(D) if (diag == D) hipLaunchKernelGGL((conv3x3_wino_bf16x9<D, true>), dim3((unsigned)n_wg), dim3(256), WB_LDS_BYTES, s, p); else
+#define WB_DIAG_LAUNCH(D) if (diag == D) hipLaunchKernelGGL((conv3x3_wino_bf16x9<D, true, true>), grid, block, WB_LDS_BYTES, s, p); else
   WB_DIAG_LAUNCH(1) WB_DIAG_LAUNCH(2) WB_DIAG_LAUNCH(4) WB_DIAG_LAUNCH(7) WB_DIAG_LAUNCH(8) WB_DIAG_LAUNCH(16) WB_DIAG_LAUNCH(32) WB_DIAG_LAUNCH(64) WB_DIAG_LAUNCH(128)
 #undef WB_DIAG_LAUNCH
 #endif
-  if (d->d_residual) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true>), dim3((unsigned)n_wg), dim3(256), WB_LDS_BYTES, s, p);
-  else hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false>), dim3((unsigned)n_wg), dim3(256), WB_LDS_BYTES, s, p);
+  if (d->d_residual && d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, true>), grid, block, WB_LDS_BYTES, s, p);
+  else if (d->d_residual) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, false>), grid, block, WB_LDS_BYTES, s, p);
+  else if (d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false, true>), grid, block, WB_LDS_BYTES, s, p);
+  else hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false, false>), grid, block, WB_LDS_BYTES, s, p);
   MP_CHECK_HIP(hipGetLastError());
   return MP_OK;
 }

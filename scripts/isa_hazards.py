@@ -22,7 +22,7 @@ side is walked):
       asks for it (our statements never do: a hit means a missing early-clobber `&`).
   R4  the destination of an MFMA is not touched by a non-MFMA instruction within 18 wait states (8-pass MFMA), and not by a later MFMA as
       a partially overlapping SrcC.
-  R5  a store's data registers (> 64 bit, buffer / global / scratch) are not overwritten by the next instruction (1 wait state).
+  R5  a store's data registers (> 64 bit, buffer / global / scratch) are not overwritten by a VALU instruction right behind it (1 wait state).
 """
 import re
 import subprocess
@@ -193,8 +193,8 @@ def lint(text):
             for r in set(d + u):
                 if r in mfma_dest and pos - mfma_dest[r][0] - 1 < MFMA_GUARD_STATES:
                     flag("R4", k, f"{r} is the destination of an MFMA issued {pos - mfma_dest[r][0] - 1} wait states earlier")
-        # R5
-        for r in d:
+        # R5 (VALU writes only: a load's data lands tens of cycles later)
+        for r in (d if op.startswith("v_") else []):
             if r in store_data and pos - store_data[r] - 1 < 1:
                 flag("R5", k, f"{r} is still being read by the wide store in front of it")
         # bookkeeping

@@ -17,7 +17,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "scripts"))
 SRC = ROOT / "megapose6d_amd" / "csrc" / "conv_wino_bf16.hip"
-KERNELS = ("conv3x3_wino_bf16x9ILi0ELb0E", "conv3x3_wino_bf16x9ILi0ELb1E")   # <DIAG 0, without / with a residual input>
+KERNELS = ("conv3x3_wino_bf16x9ILi0ELb0ELb0E", "conv3x3_wino_bf16x9ILi0ELb1ELb0E", "conv3x3_wino_bf16x9ILi0ELb1ELb1E")   # <DIAG 0, residual?, second output?>
 needs_hipcc = pytest.mark.skipif(shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists(), reason="hipcc not available")
 
 
