@@ -185,13 +185,18 @@ def extras(est, obs, det, steps: int) -> dict:
             rend.msaa = 4
     guarded("single_sample_renders", single_sample)
 
-    def streams3():
-        est.n_streams = 3  # chunk interleave on 3 HIP streams: fills the tails of the conv grids and overlaps raster with MFMA work; not
-        try:               # the default because overlapping kernels distort the per-kernel event timing the roofline figures rest on
-            return hyp_line("same fp32 path, PoseEstimator.n_streams=3 (MP_N_STREAMS); not used for `value`")
-        finally:
-            est.n_streams = 1
-    guarded("three_stream_interleave", streams3)
+    def streams(n):
+        def run():
+            est.n_streams = n  # chunk interleave on n HIP streams: fills the tails of the conv grids (a 576-row Winograd launch is 5.6 .. 42.2 rounds
+            try:               # of 256 workgroups) and overlaps raster with MFMA work; not the default because overlapping kernels distort the per-kernel
+                               # event timing the roofline figures rest on (each kernel's duration then includes the other's share of the chip)
+                return hyp_line(f"same fp32 path, PoseEstimator.n_streams={n} (MP_N_STREAMS); not used for `value` (round 6, same box: 260.7 / 262.5 "
+                                "ms on one stream, 255.5 / 257.2 on two, 256.6 on three)")
+            finally:
+                est.n_streams = 1
+        return run
+    guarded("two_stream_interleave", streams(2))
+    guarded("three_stream_interleave", streams(3))
 
     def fp16_renders():
         est.render_dtype = torch.float16
