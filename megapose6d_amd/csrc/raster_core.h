@@ -587,6 +587,8 @@ MP_HD void tex_sample(const TexRef& m, int level, float u, float v, float out[3]
   }
 }
 
+constexpr int MAX_ANISO = 16;   // the reference's `texture-anisotropic-degree` (panda3d_scene_renderer.py:72)
+
 // level of detail from rho^2 (squared texel footprint): lambda = log2(rho) ~ 0.5 * (exponent + mantissa fraction) of rho^2
 MP_HD void tex_lod(int levels, float rho2, int& level, float& frac) {
   level = 0;
@@ -673,19 +675,35 @@ MP_HD void shade(const MeshRef& m, const TexRef* tex, const Lights& L, const flo
     const float dudx = fmaf(-u, dDx, dNux) * z * tw, dvdx = fmaf(-v, dDx, dNvx) * z * th;
     const float dudy = fmaf(-u, dDy, dNuy) * z * tw, dvdy = fmaf(-v, dDy, dNvy) * z * th;
     const float rx2 = fmaf(dvdx, dvdx, dudx * dudx), ry2 = fmaf(dvdy, dvdy, dudy * dudy);
+    // anisotropic filtering, degree 16 (panda3d_scene_renderer.py:72 `texture-anisotropic-degree 16`), by the formula of the OpenGL
+    // extension's specification (EXT_texture_filter_anisotropic): N = min(ceil(Pmax / Pmin), 16) trilinear probes spread along the major
+    // axis of the pixel's footprint at x - 1/2 + i / (N + 1), their level of detail from Pmax / N.  N = 1 is the isotropic sample.
+    const bool x_major = rx2 >= ry2;
+    const float r2max = x_major ? rx2 : ry2, r2min = x_major ? ry2 : rx2;
+    int n_probe = 1;
+    while (n_probe < MAX_ANISO && (float)(n_probe * n_probe) * r2min < r2max) ++n_probe;
     int level;
     float frac;
-    tex_lod(tex->tex_levels, fmaxf(rx2, ry2), level, frac);
-    float tc[3];
-    tex_sample(*tex, level, u, v, tc);
-    if (frac > 0.f) {
-      float tc1[3];
-      tex_sample(*tex, level + 1, u, v, tc1);
+    tex_lod(tex->tex_levels, r2max / (float)(n_probe * n_probe), level, frac);
+    const float du = (x_major ? dudx : dudy) / tw, dv = (x_major ? dvdx : dvdy) / th;   // the major axis in (u, v)
+    float acc3[3] = {0.f, 0.f, 0.f};
+    for (int i = 1; i <= n_probe; ++i) {
+      const float t = (float)i / (float)(n_probe + 1) - 0.5f;
+      const float ui = fmaf(t, du, u), vi = fmaf(t, dv, v);
+      float tc[3];
+      tex_sample(*tex, level, ui, vi, tc);
+      if (frac > 0.f) {
+        float tc1[3];
+        tex_sample(*tex, level + 1, ui, vi, tc1);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tc[k] = fmaf(tc1[k] - tc[k], frac, tc[k]);
+        for (int k = 0; k < 3; ++k) tc[k] = fmaf(tc1[k] - tc[k], frac, tc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc3[k] += tc[k];
     }
+    const float inv_n = 1.0f / (float)n_probe;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) col[k] *= tc[k] / 255.0f;
+    for (int k = 0; k < 3; ++k) col[k] *= (acc3[k] * inv_n) / 255.0f;
   }
   float lr = L.ambient[0], lg = L.ambient[1], lb = L.ambient[2];
   if (FULL && L.n_point > 0) {

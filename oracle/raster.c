@@ -29,10 +29,14 @@
  *              rounded to uint8 like the 8-bit multisample colour buffer, the pixel is the rounded mean of its samples (background
  *              samples = 0), then / 255.  Depth output = sample 0's own depth (a resolve of a multisample depth buffer picks one
  *              sample; 0 = background).
- *   texture    albedo = vertex colour x texture (modulate); repeat wrap; TRILINEAR with a per-pixel level of detail from the
- *              analytic screen-space derivatives of (u, v) at the pixel centre: rho^2 = max(|d(uv)/dx|^2, |d(uv)/dy|^2) in texels,
- *              lambda = log2(rho) approximated piecewise-linearly from the float's exponent and mantissa (exact integer ops, no
- *              libm), level = floor(lambda), blend = lambda - level.  16x anisotropic filtering is NOT reproduced.
+ *   texture    albedo = vertex colour x texture (modulate); repeat wrap; TRILINEAR probes with a per-pixel level of detail from the
+ *              analytic screen-space derivatives of (u, v) at the pixel centre, and ANISOTROPIC filtering of degree 16 (the reference's
+ *              `texture-anisotropic-degree 16`) by the formula of the OpenGL extension specification (contract v2.1, round 6):
+ *              Px^2 = |d(uv)/dx|^2, Py^2 = |d(uv)/dy|^2 in texels, n = min(ceil(Pmax / Pmin), 16) probes along the major axis at
+ *              x - 1/2 + i / (n + 1), i = 1..n, averaged; rho^2 = Pmax^2 / n^2; lambda = log2(rho) approximated piecewise-linearly
+ *              from the float's exponent and mantissa (exact integer ops, no libm), level = floor(lambda), blend = lambda - level.
+ *              (n = 1 is the isotropic trilinear sample of contract v2.  What Panda3D's GL driver really does with the degree is
+ *              implementation-defined and unpinned here, as every pixel of the third-party renderer is.)
  *   lights     RGB = albedo * (ambient + sum_l color_l * max(0, n.l)), light l at dir_l * 10 * radius + offset_l (object frame).
  *
  * Written as a straightforward "for every piece, for every pixel of its bbox, for every sample" loop with plain per-sample
@@ -104,6 +108,11 @@ static int tex_offset(const tex_t* tx, int level) {
   }
   return off;
 }
+
+/* degree of the anisotropic filter: 16 = the contract; oracle_set_max_aniso(1) is a TEST HOOK that renders the isotropic trilinear sample
+ * of contract v2 instead, so that a test can show what the anisotropic probes change (tests/test_raster_contract_cpu.py) */
+static int g_max_aniso = 16;
+void oracle_set_max_aniso(int degree) { g_max_aniso = degree < 1 ? 1 : (degree > 16 ? 16 : degree); }
 
 static void tex_sample(const tex_t* tx, int level, float u, float v, float out[3]) {
   const int tw = (tx->w >> level) > 1 ? (tx->w >> level) : 1, th = (tx->h >> level) > 1 ? (tx->h >> level) : 1;
@@ -287,16 +296,31 @@ static void shade(const piece_t* p, int px, int py, const float* verts, const fl
     const float dudx = fmaf(-u, dDx, dNux) * z * tw, dvdx = fmaf(-v, dDx, dNvx) * z * th;
     const float dudy = fmaf(-u, dDy, dNuy) * z * tw, dvdy = fmaf(-v, dDy, dNvy) * z * th;
     const float rx2 = fmaf(dvdx, dvdx, dudx * dudx), ry2 = fmaf(dvdy, dvdy, dudy * dudy);
+    /* anisotropic filtering of degree 16 (the reference's `texture-anisotropic-degree 16`, panda3d_scene_renderer.py:72) as the OpenGL
+     * extension specifies it: n = min(ceil(Pmax / Pmin), 16) trilinear probes along the major axis of the footprint, at
+     * x - 1/2 + i / (n + 1); level of detail from Pmax / n.  (Compared on squares: n is the first integer with n^2 * Pmin^2 >= Pmax^2.) */
+    const int along_x = rx2 >= ry2;
+    const float big2 = along_x ? rx2 : ry2, small2 = along_x ? ry2 : rx2;
+    int n = 1;
+    while (n < g_max_aniso && (float)(n * n) * small2 < big2) n++;
     int level;
     float frac;
-    tex_lod(tx, fmaxf(rx2, ry2), &level, &frac);
-    float tc[3], tc1[3];
-    tex_sample(tx, level, u, v, tc);
-    if (frac > 0.f) {
-      tex_sample(tx, level + 1, u, v, tc1);
-      for (int k = 0; k < 3; ++k) tc[k] = fmaf(tc1[k] - tc[k], frac, tc[k]);
+    tex_lod(tx, big2 / (float)(n * n), &level, &frac);
+    const float axis_u = (along_x ? dudx : dudy) / tw, axis_v = (along_x ? dvdx : dvdy) / th;
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (int i = 1; i <= n; ++i) {
+      const float t = (float)i / (float)(n + 1) - 0.5f;
+      const float us = fmaf(t, axis_u, u), vs = fmaf(t, axis_v, v);
+      float tc[3], tc1[3];
+      tex_sample(tx, level, us, vs, tc);
+      if (frac > 0.f) {
+        tex_sample(tx, level + 1, us, vs, tc1);
+        for (int k = 0; k < 3; ++k) tc[k] = fmaf(tc1[k] - tc[k], frac, tc[k]);
+      }
+      for (int k = 0; k < 3; ++k) sum[k] += tc[k];
     }
-    for (int k = 0; k < 3; ++k) col[k] *= tc[k] / 255.0f;
+    const float inv_n = 1.0f / (float)n;
+    for (int k = 0; k < 3; ++k) col[k] *= (sum[k] * inv_n) / 255.0f;
   }
   float lr = L->ambient[0], lg = L->ambient[1], lb = L->ambient[2];
   if (L->n_point > 0) {

@@ -19,6 +19,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $R/$O/pmc_SQ -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $R/$O/pmc_SQ.log 2>&1
 cd $R
+# summaries for profiles/: per-kernel stats of the bench command, HBM traffic / SQ counters per launch (scripts/pmc_summary.py)
+cp $(find $O/stats -name "*kernel_stats.csv" | head -n 1) $O/bench_kernel_stats.csv 2>/dev/null
+python scripts/pmc_summary.py $O/traffic.json "gpurun_out/final (round 6 final code, scripts/gpu_final.sh): rocprofv3 --pmc, one counter group per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), python bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline" $(find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ -name "*counter_collection.csv") > $O/pmc_summary.log 2>&1
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*.csv" -size +30M -delete
 tail -n 3 $O/pytest_gpu.log; tail -n 2 $O/smoke.log; tail -c 400 $O/bench_n1.json; tail -n 2 $O/bench_n1.err
