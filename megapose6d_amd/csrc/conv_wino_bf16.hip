@@ -44,7 +44,7 @@ __device__ constexpr int WB_PA[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}, WB_PB[9] = {2, 
 
 constexpr int UB_F_BYTES = 2 * 3 * 1024;          // one frequency point of one step: [cout block j][piece][lane][16 B]
 constexpr int UB_STEP_BYTES = 16 * UB_F_BYTES;    // 96 KB per 16-channel step
-// LDS: the two V stages (128 KB) + the tile table during the K loop; the exchange S[4 waves][2][64 tiles][72] (144 KB) in the epilogue
+// LDS: the two V stages (128 KB) + the tile table during the K loop; the exchange S[4 waves][2][64 tiles][pitch] in the epilogue (sized for a pitch of up to 72 floats: A/B builds)
 constexpr size_t WB_LDS_BYTES = (size_t)4 * 2 * WT * 72 * sizeof(float);
 static_assert(WB_LDS_BYTES >= WINO_LDS_BYTES && WB_LDS_BYTES <= 160 * 1024, "LDS budget of conv3x3_wino_bf16x9");
 
@@ -418,8 +418,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     sc = *reinterpret_cast<const float4*>(p.act_scale + n);
     sh = *reinterpret_cast<const float4*>(p.act_shift + n);
   }
-  // S[wave][2][tile][WS]: row pitch 72 floats -- lanes 32..63 of a fragment (4 tiles further) then start 32 banks away from lanes 0..31
-  constexpr int WS = 72;
+  // S[wave][2][tile][WS]
+#ifndef MP_WINO_WS
+#define MP_WINO_WS 64
+#endif
+  constexpr int WS = MP_WINO_WS;   // (a pitch of 72 floats -- lanes 32..63 of a fragment 32 banks away from lanes 0..31 -- measured 130 cycles SLOWER per workgroup: r6 call 10)
   float* S = smem;
   {
     float* sw = S + (size_t)wave * (2 * WT * WS) + ((lane >> 5) * 4) * WS + (lane & 31);
