@@ -66,40 +66,48 @@ __device__ unsigned long long g_wb_phase[10];
 // RES: the launch has a residual input; its 16 loads per thread ride under the MFMAs of the LAST K step (round 6).
 // ACT: the launch writes the second, pre-activated output relu(y * scale + shift) (WideResNet blocks).  Both compile-time, and ReLU is a
 // maximum with 0 or -inf: the store loop of the epilogue is straight-line code (it was 48 branches + their mask bookkeeping per workgroup).
-template <int DIAG, bool RES, bool ACT>
+// PERSIST (round 6, the default launch form; MP_WINO_PERSIST=0 = one workgroup per unit): one workgroup per CU walks the units blockIdx,
+// blockIdx + gridDim, ...; the next unit's indices and tile table are computed before the exchange of the current unit's epilogue, its 16
+// patch requests go out four at a time behind the four accumulator blocks of the exchange (the memory pipe is idle there, the patch registers
+// are dead) and its accumulator reset four MFMAs at a time behind the passes of the store loop -- the next prologue finds its data arrived
+// instead of waiting ~3 k cycles with nothing to overlap (prologue 6.6 k -> 3.2 k, epilogue 6.2 k -> 8.0 k cycles: r6 calls 11 - 14).
+template <int DIAG, bool RES, bool ACT, bool PERSIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_bf16x9(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;
   int* tile_tab = (int*)(smem + 4 * 2 * WT * WCOUT);   // [64][2]: output element offset of pixel (2ty, 2tx) (-1: no such tile), validity bits
 
-  const unsigned long long clk_start = __builtin_readcyclecounter();
+  unsigned long long clk_start = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef MP_WINO_PHASES
   const bool ph_sample = (blockIdx.x & 63) == 0 && threadIdx.x == 0;
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int cb = wg % p.n_cblocks;      // channel block fastest: the workgroups that share an input tile set run together
-  const int tg = wg / p.n_cblocks;
-  const int tile0 = tg * WT;
-
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, -1, 0x00020000);
   const int row_bytes = p.Wp * p.C * 4, pix_bytes = p.C * 4;
-  // weights: [cb][step][f][j][piece][lane][8 bf16]; this wave's four frequency points of a step are 24 KB contiguous
-  const unsigned char* ub = reinterpret_cast<const unsigned char*>(p.u) + (size_t)cb * p.n_steps * UB_STEP_BYTES + (size_t)(4 * wave) * UB_F_BYTES;
-  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, -1, 0x00020000);
   const int u_voff = lane * 16;
-
-  float4 patch[4][4];
   const int ptile = tid >> 2, pc4 = tid & 3;
-  int x_voff;
-  {
-    int t = tile0 + ptile;
-    t = t < p.n_tiles ? t : p.n_tiles - 1;
-    const int tx = t % p.tiles_x, r = t / p.tiles_x;
-    const int ty = r % p.tiles_y, n = r / p.tiles_y;
-    const size_t pix = ((size_t)n * p.Hp + (size_t)(2 * ty + p.in_off)) * p.Wp + (size_t)(2 * tx + p.in_off);
-    x_voff = (int)((pix * p.C + pc4 * 4) * sizeof(float));
+  float4 patch[4][4];
+  // the unit (= what a workgroup of the non-persistent launch does): cout block cb (fastest: the units that share an input tile set run
+  // together) of tile group tile0 / 64
+  int unit = (int)blockIdx.x;
+  const int n_units = PERSIST ? p.n_units : (int)gridDim.x;
+  int cb, tile0, x_voff;
+  __amdgpu_buffer_rsrc_t u_rsrc;   // weights: [cb][step][f][j][piece][lane][8 bf16]; this wave's four frequency points of a step are 24 KB contiguous
+#define WB_UNIT_INDICES(U)                                                                               \
+  {                                                                                                      \
+    const int wg_ = xcd_remap((U), n_units);                                                             \
+    const int tg_ = (int)wino_fastdiv((unsigned)wg_, (unsigned)p.n_cblocks, p.mg_cb, p.sh_cb);           \
+    cb = wg_ - tg_ * p.n_cblocks;                                                                        \
+    tile0 = tg_ * WT;                                                                                    \
+    const unsigned char* ub_ = reinterpret_cast<const unsigned char*>(p.u) + (size_t)cb * p.n_steps * UB_STEP_BYTES + (size_t)(4 * wave) * UB_F_BYTES;  \
+    u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ub_, 0, -1, 0x00020000);                            \
+    int t_ = tile0 + ptile;                                                                              \
+    t_ = t_ < p.n_tiles ? t_ : p.n_tiles - 1;                                                            \
+    const int r_ = (int)wino_fastdiv((unsigned)t_, (unsigned)p.tiles_x, p.mg_tx, p.sh_tx), tx_ = t_ - r_ * p.tiles_x;   \
+    const int n_ = (int)wino_fastdiv((unsigned)r_, (unsigned)p.tiles_y, p.mg_ty, p.sh_ty), ty_ = r_ - n_ * p.tiles_y;   \
+    const size_t pix_ = ((size_t)n_ * p.Hp + (size_t)(2 * ty_ + p.in_off)) * p.Wp + (size_t)(2 * tx_ + p.in_off);  \
+    x_voff = (int)((pix_ * p.C + pc4 * 4) * sizeof(float));                                               \
   }
   // V[stage][f][tile][16 floats], 16-byte slot s of a row holds channels 4s..4s+3, slots XOR-swizzled by (tile >> 2) & 3 (as conv_wino.hip)
   float* vw = Vs + ptile * WCK + ((pc4 ^ ((ptile >> 2) & 3)) * 4);
@@ -241,37 +249,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // and the tile table (matrix pipe / LDS work in the shadow of the queue), the 6 weight requests, and the 16 requests of step 1's patch
   // only after the first transform row -- they fly under the remaining transform rows, the barrier and the first splits.
   float4 pnext[4][4];
-  _Pragma("unroll") for (int a = 0; a < 4; ++a)
-    _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) }
+  // the first requests of a unit: 16 patch loads of step 0, then (in the shadow of the queue) the tile table of the epilogue and the
+  // accumulator reset by the matrix pipe itself (0 x 0 + 0: 16 instructions instead of 256 register writes; asm volatile: as a builtin the 16
+  // identical products are merged into one and copied), then the 6 weight loads of (step 0, point 0).
+  // `s_nop 1` INSIDE the reset's string: the compiler materialises the zero operand with v_mov right in front of the statement, and a VALU
+  // write of a register an MFMA reads as A / B needs two wait states that the hazard recogniser does not insert for a consumer inside inline
+  // asm.  Without them the first MFMA multiplies whatever the registers held BEFORE the v_mov -- rounds 4 / 5 shipped that way and were
+  // right only because the allocator happened to pick registers that held small integers (bf16 pairs whose products underflow to 0); any
+  // edit that moved the operand to never-written registers (stale data of the previous kernel) gave inf / NaN on every shape: DESIGN.md
+  // 3.1.1, round 6.
+#define WB_UNIT_REQUESTS() \
+  _Pragma("unroll") for (int a = 0; a < 4; ++a) \
+    _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(a, bb, 0) } \
+  WB_SB \
+  if (tid < WT) { \
+    const int t = tile0 + tid; \
+    int off = -1, bits = 0; \
+    if (t < p.n_tiles) { \
+      const int r = (int)wino_fastdiv((unsigned)t, (unsigned)p.tiles_x, p.mg_tx, p.sh_tx), tx = t - r * p.tiles_x; \
+      const int n = (int)wino_fastdiv((unsigned)r, (unsigned)p.tiles_y, p.mg_ty, p.sh_ty), ty = r - n * p.tiles_y; \
+      off = ((n * p.Hop + 2 * ty + p.out_border) * p.Wop + 2 * tx + p.out_border) * p.Cout; \
+      bits = ((2 * ty + 1 < p.Ho) ? 1 : 0) | ((2 * tx + 1 < p.Wo) ? 2 : 0); \
+    } \
+    tile_tab[2 * tid] = off; \
+    tile_tab[2 * tid + 1] = bits; \
+  } \
+  { \
+    const u32x4 z4 = {0u, 0u, 0u, 0u}; \
+    _Pragma("unroll") for (int fi = 0; fi < 4; ++fi) \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4)); \
+  } \
   WB_SB
-  if (tid < WT) {
-    const int t = tile0 + tid;
-    int off = -1, bits = 0;
-    if (t < p.n_tiles) {
-      const int tx = t % p.tiles_x, r = t / p.tiles_x;
-      const int ty = r % p.tiles_y, n = r / p.tiles_y;
-      off = ((n * p.Hop + 2 * ty + p.out_border) * p.Wop + 2 * tx + p.out_border) * p.Cout;
-      bits = ((2 * ty + 1 < p.Ho) ? 1 : 0) | ((2 * tx + 1 < p.Wo) ? 2 : 0);
-    }
-    tile_tab[2 * tid] = off;
-    tile_tab[2 * tid + 1] = bits;
+  // the tile table alone (persistent form: patch loads and accumulator reset are spread over the store loop of the previous unit)
+#define WB_UNIT_TABLE() \
+  if (tid < WT) { \
+    const int t = tile0 + tid; \
+    int off = -1, bits = 0; \
+    if (t < p.n_tiles) { \
+      const int r = (int)wino_fastdiv((unsigned)t, (unsigned)p.tiles_x, p.mg_tx, p.sh_tx), tx = t - r * p.tiles_x; \
+      const int n = (int)wino_fastdiv((unsigned)r, (unsigned)p.tiles_y, p.mg_ty, p.sh_ty), ty = r - n * p.tiles_y; \
+      off = ((n * p.Hop + 2 * ty + p.out_border) * p.Wop + 2 * tx + p.out_border) * p.Cout; \
+      bits = ((2 * ty + 1 < p.Ho) ? 1 : 0) | ((2 * tx + 1 < p.Wo) ? 2 : 0); \
+    } \
+    tile_tab[2 * tid] = off; \
+    tile_tab[2 * tid + 1] = bits; \
   }
-
-  {   // accumulator reset by the matrix pipe itself (0 x 0 + 0: 16 instructions instead of 256 register writes right before the loop;
-      // asm volatile: as a builtin the 16 identical products are merged into one and copied).
-      // `s_nop 1` INSIDE the string: the compiler materialises z4 with v_mov right in front of the statement, and a VALU write of a register
-      // an MFMA reads as A / B needs two wait states that the hazard recogniser does not insert for a consumer inside inline asm.  Without
-      // them the first MFMA multiplies whatever the registers held BEFORE the v_mov -- rounds 4 / 5 shipped that way and were right only
-      // because the allocator happened to pick registers that held small integers (bf16 pairs whose products underflow to 0); any edit that
-      // moved z4 to never-written registers (stale data of the previous kernel) gave inf / NaN on every shape: DESIGN.md 3.1.1, round 6.
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-    _Pragma("unroll") for (int fi = 0; fi < 4; ++fi)
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)
-          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[fi][i][j]) : "v"(z4));
-  }
-  WB_SB
-  _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }
+  WB_UNIT_INDICES(unit)
+  WB_UNIT_REQUESTS()
+  for (;;) {   // (one pass unless PERSIST)
+  _Pragma("unroll") for (int k = 0; k < 6; ++k) { WB_LOAD_U1(Ua, 0, 0, k) }   // the 6 weight loads of (step 0, point 0)
   WB_SB
   WB_PHASE(0, clk_start)
 #define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //      step, between points 1 and 2: V of this step is last read in point 1 (for point 3), V of the next step is complete after point 1
   //      (its transform rides in points 0 and 1) and first read in point 2.
   WB_PHASE(4, clk_start)
-  const bool clk_sample = p.telemetry != 0 && (blockIdx.x & 63) == 0 && tid == 0;
+  const bool clk_sample = p.telemetry != 0 && (unit & 63) == 0 && tid == 0;
   unsigned long long clk_c0 = 0, clk_r0 = 0;
   if (clk_sample) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_wb_clk[3], clk_c0 - clk_start); }
   for (int st = 0; st < ns - 1; ++st) {
@@ -379,36 +407,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #endif
   __syncthreads();   // (the epilogue reuses the V stages)
-#undef WB_POINT_LAST
-#undef WB_BLK_RES
-#undef WB_BLK_RD
-#undef WB_BLK_PL
-#undef WB_BLK_TR
-#undef WB_PRM_C
-#undef WB_PRM_B
-#undef WB_PRM_A
-#undef WB_PRM1
-#undef WB_SPC
-#undef WB_SPA
-#undef WB_LOAD_RES1
-#undef WB_M
-#undef WB_READ_RAW1
-#undef WB_SPLIT4
-#undef WB_SP4
-#undef WB_SP3
-#undef WB_SP2
-#undef WB_SP1
-#undef WB_SP0
-#undef WB_TR_W
-#undef WB_TR_P
-#undef WB_TR_ROW
-#undef WB_TR_T
-#undef WB_F4ASM
-#undef WB_OP_SUB
-#undef WB_OP_ADD
-#undef WB_LOAD_PATCH1
-#undef WB_LOAD_U1
-#undef WB_SB
 
   // ---- epilogue: output transform through LDS, bias + residual + ReLU (+ second activated output).  The store offsets and the residual
   //      are already in registers (computed after the prologue's barrier / requested under the last K step). -------------------------------
@@ -417,6 +415,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (ACT && p.y_act) {   // (p.y_act is set whenever ACT is, except in the timing-experiment instances)
     sc = *reinterpret_cast<const float4*>(p.act_scale + n);
     sh = *reinterpret_cast<const float4*>(p.act_shift + n);
+  }
+  // Persistent form: the NEXT unit's indices and tile table now (the table is dead since the prologue), its 16 patch requests four at a time
+  // behind each of the four accumulator blocks of the exchange below (rows 0, 2, 1, 3: the order the first transform rows need them; the
+  // memory pipe is idle during the exchange) and its accumulator reset four MFMAs at a time behind the passes of the store loop.  All 16
+  // requests at once in front of the stores filled the wave's request queue and every store waited an HBM round trip (r6 calls 11 - 13).
+  const int next_unit = unit + (int)gridDim.x;
+  const bool more = PERSIST && next_unit < n_units;
+  if (more) {
+    WB_UNIT_INDICES(next_unit)
+    WB_UNIT_TABLE()
   }
   // S[wave][2][tile][WS]
 #ifndef MP_WINO_WS
@@ -441,6 +449,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const int row = i * 32 + (r & 3) + 8 * (r >> 2);
           sw[row * WS + j * 32] = (m0 + m1) + m2;
           sw[WT * WS + row * WS + j * 32] = (m1 - m2) - m3;
+        }
+        if (more) {
+          constexpr int prow[4] = {0, 2, 1, 3};
+          _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(prow[i * 2 + j], bb, 0) }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -490,16 +502,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           __builtin_amdgcn_raw_buffer_store_b128(a, r_act, voff[it][ii * 2 + jj], 0, 0);
         }
       }
+    if (more) {
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[it][bb >> 1][bb & 1]) : "v"(z4));
+    }
   }
 #ifdef MP_WINO_PHASES
   WB_PHASE(7, clk_epi)
   if (ph_sample) { __builtin_amdgcn_s_waitcnt(0); WB_PHASE(8, clk_epi) atomicAdd(&g_wb_phase[9], 1ull); }
 #endif
   if (clk_sample) {
-    __builtin_amdgcn_s_waitcnt(0);   // the stores are out
+    if (!more) __builtin_amdgcn_s_waitcnt(0);   // the stores are out (persistent form: the next unit's requests are in flight, do not wait for them)
     atomicAdd(&g_wb_clk[4], __builtin_readcyclecounter() - clk_epi);
     atomicAdd(&g_wb_clk[5], 1ull);
   }
+  if (!more) break;
+  unit = next_unit;
+  clk_start = __builtin_readcyclecounter();
+  __syncthreads();   // every wave has read the exchange: the next unit's transform may overwrite it
+  }   // units
+#undef WB_POINT_LAST
+#undef WB_BLK_RES
+#undef WB_BLK_RD
+#undef WB_BLK_PL
+#undef WB_BLK_TR
+#undef WB_PRM_C
+#undef WB_PRM_B
+#undef WB_PRM_A
+#undef WB_PRM1
+#undef WB_SPC
+#undef WB_SPA
+#undef WB_LOAD_RES1
+#undef WB_M
+#undef WB_READ_RAW1
+#undef WB_SPLIT4
+#undef WB_SP4
+#undef WB_SP3
+#undef WB_SP2
+#undef WB_SP1
+#undef WB_SP0
+#undef WB_TR_W
+#undef WB_TR_P
+#undef WB_TR_ROW
+#undef WB_TR_T
+#undef WB_F4ASM
+#undef WB_OP_SUB
+#undef WB_OP_ADD
+#undef WB_LOAD_PATCH1
+#undef WB_LOAD_U1
+#undef WB_SB
+#undef WB_UNIT_TABLE
+#undef WB_UNIT_REQUESTS
+#undef WB_UNIT_INDICES
 }
 
 }  // namespace mp
@@ -620,14 +675,18 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   p.n_tiles = (int)n_tiles;
   p.n_chunks = d->C / 8;
   p.n_steps = d->C / WCK;
+  wino_fastdiv_make((unsigned)p.tiles_x, &p.mg_tx, &p.sh_tx);
+  wino_fastdiv_make((unsigned)p.tiles_y, &p.mg_ty, &p.sh_ty);
   p.relu = d->relu;
   p.n_cblocks = d->Cout / WCOUT;
+  wino_fastdiv_make((unsigned)p.n_cblocks, &p.mg_cb, &p.sh_cb);
   int dev = 0;
   MP_CHECK_HIP(hipGetDevice(&dev));
   static int attr_dev = -1;
   if (attr_dev != dev) {   // (per device: the attribute does not travel with the process)
 #define WB_ATTR(...) MP_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_bf16x9<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES));
     WB_ATTR(0, false, false) WB_ATTR(0, true, false) WB_ATTR(0, false, true) WB_ATTR(0, true, true)
+    WB_ATTR(0, false, false, true) WB_ATTR(0, true, false, true) WB_ATTR(0, false, true, true) WB_ATTR(0, true, true, true)
 #ifdef MP_CONV_EXPERIMENTS
     WB_ATTR(1, true, true) WB_ATTR(2, true, true) WB_ATTR(4, true, true) WB_ATTR(7, true, true) WB_ATTR(8, true, true) WB_ATTR(16, true, true)
     WB_ATTR(32, true, true) WB_ATTR(64, true, true) WB_ATTR(128, true, true)
@@ -648,13 +707,26 @@ extern "C" int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* d, const void* d_u_
   p.telemetry = g_wb_telemetry.load(std::memory_order_relaxed);
   ProfScope prof("conv3x3_wino_bf16x9<64t,64c>", direct, 4.0 * ((double)d->N * d->H * d->W * (d->C + d->Cout)) + 6.0 * 16.0 * d->C * d->Cout, s, executed, 2500.0);
   const dim3 grid((unsigned)n_wg), block(256);
+  // persistent form (default since round 6, MP_WINO_PERSIST=0 = one workgroup per unit): one workgroup per CU walks the units
+  static const int persist_env = getenv("MP_WINO_PERSIST") ? atoi(getenv("MP_WINO_PERSIST")) : 1;
+  static int n_cu = 0;
+  if (!n_cu) { hipDeviceProp_t prop; MP_CHECK_HIP(hipGetDeviceProperties(&prop, dev)); n_cu = prop.multiProcessorCount; }
+  p.n_units = (int)n_wg;
+  bool launched = false;
 #ifdef MP_CONV_EXPERIMENTS
   const int diag = getenv("MP_WINO_DIAG") ? atoi(getenv("MP_WINO_DIAG")) : 0;
-#define WB_DIAG_LAUNCH(D) if (diag == D) hipLaunchKernelGGL((conv3x3_wino_bf16x9<D, true, true>), grid, block, WB_LDS_BYTES, s, p); else
+#define WB_DIAG_LAUNCH(D) if (diag == D) { hipLaunchKernelGGL((conv3x3_wino_bf16x9<D, true, true>), grid, block, WB_LDS_BYTES, s, p); launched = true; }
   WB_DIAG_LAUNCH(1) WB_DIAG_LAUNCH(2) WB_DIAG_LAUNCH(4) WB_DIAG_LAUNCH(7) WB_DIAG_LAUNCH(8) WB_DIAG_LAUNCH(16) WB_DIAG_LAUNCH(32) WB_DIAG_LAUNCH(64) WB_DIAG_LAUNCH(128)
 #undef WB_DIAG_LAUNCH
 #endif
-  if (d->d_residual && d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, true>), grid, block, WB_LDS_BYTES, s, p);
+  if (launched) {
+  } else if (persist_env && n_wg > n_cu) {
+    const dim3 pgrid((unsigned)n_cu);
+    if (d->d_residual && d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, true, true>), pgrid, block, WB_LDS_BYTES, s, p);
+    else if (d->d_residual) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, false, true>), pgrid, block, WB_LDS_BYTES, s, p);
+    else if (d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false, true, true>), pgrid, block, WB_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false, false, true>), pgrid, block, WB_LDS_BYTES, s, p);
+  } else if (d->d_residual && d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, true>), grid, block, WB_LDS_BYTES, s, p);
   else if (d->d_residual) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, true, false>), grid, block, WB_LDS_BYTES, s, p);
   else if (d->d_y_act) hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false, true>), grid, block, WB_LDS_BYTES, s, p);
   else hipLaunchKernelGGL((conv3x3_wino_bf16x9<0, false, false>), grid, block, WB_LDS_BYTES, s, p);

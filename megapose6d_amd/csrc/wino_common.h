@@ -31,12 +31,29 @@ struct WinoParams {
   int relu;
   int n_cblocks;        // Cout / 64
   int out_bytes;        // size of the output tensor (range check of the epilogue's buffer accesses)
+  unsigned mg_tx, sh_tx, mg_ty, sh_ty, mg_cb, sh_cb;   // bf16 kernel: magic numbers of the divisions by tiles_x / tiles_y / n_cblocks (wino_fastdiv)
+  int n_units;          // bf16 kernel, persistent form: units (= workgroups of the plain launch) the resident workgroups walk
   int telemetry;        // != 0: every 64th workgroup adds its clock readings to the kernel's telemetry counters (mp_conv_wino_bf16_telemetry)
 };
 
 __device__ __forceinline__ float4 buf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// Division of a 32-bit unsigned by a launch constant d >= 1 (Granlund / Montgomery round-up method, exact for every 32-bit numerator):
+// host: wino_fastdiv_make(d, &M, &s); device: q = wino_fastdiv(t, d, M, s).  Seven vector instructions with the remainder instead of the
+// ~25 of a generic division: the tile -> (image, row, column) arithmetic sits in front of a workgroup's first memory request.
+static inline void wino_fastdiv_make(unsigned d, unsigned* M, unsigned* s) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                       // l = ceil(log2 d)
+  *M = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  *s = l;
+}
+__device__ __forceinline__ unsigned wino_fastdiv(unsigned t, unsigned d, unsigned M, unsigned s) {
+  const unsigned t1 = __umulhi(t, M);
+  const unsigned q = (t1 + ((t - t1) >> 1)) >> (s - 1);   // (s >= 1 whenever d >= 2)
+  return d == 1 ? t : q;
 }
 
 // LDS: V[2][16][64][16] floats (128 KB) during the K loop; S[4][2][64][64] floats (128 KB) in the epilogue; + the tile table.

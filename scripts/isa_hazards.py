@@ -52,6 +52,14 @@ def compile_kernel(src, kernel_substr, extra=()):
     raise KeyError(kernel_substr)
 
 
+def compile_all(src, extra=()):
+    """-> {mangled kernel name: its assembly text} of every kernel in the translation unit (one compilation)"""
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-S", "--cuda-device-only", "-o", "-", str(src)], capture_output=True,
+                         text=True, check=True).stdout
+    parts = re.split(r"\n(_Z\w+):[^\n]*\n", asm)
+    return {parts[i]: parts[i + 1].split("s_endpgm")[0] for i in range(1, len(parts), 2)}
+
+
 def parse(text):
     """-> list of {op, ops, asm (statement id or None), text, label}"""
     out, stmt, n_stmt = [], None, 0
@@ -96,22 +104,27 @@ def defs_uses(ins):
 
 
 def expand_loops(ins):
-    """Walk order: every backward-branch loop body is repeated once right after itself (innermost loops only matter here)."""
+    """Walk order: every backward-branch loop body is walked once more right after itself (nested loops included, each once per level);
+    of an if / else the `then` side is walked (an unconditional forward s_branch is followed)."""
     labels = {x["label"]: n for n, x in enumerate(ins) if x["label"]}
-    order, n = [], 0
-    done = set()
-    while n < len(ins):
-        order.append(n)
-        x = ins[n]
-        m = re.match(r"s_cbranch_\w+|s_branch", x["op"])
-        if m and x["ops"] and x["ops"][0] in labels and labels[x["ops"][0]] < n and n not in done:
-            done.add(n)
-            order.extend(range(labels[x["ops"][0]], n + 1))
-        elif x["op"] == "s_branch" and x["ops"] and labels.get(x["ops"][0], -1) > n:
-            n = labels[x["ops"][0]]      # if / else: the walk takes the `then` side and skips the `else` side
-            continue
-        n += 1
-    return order
+
+    def walk(start, end, done, depth):
+        order, n = [], start
+        while n <= end:
+            order.append(n)
+            x = ins[n]
+            tgt = labels.get(x["ops"][0], None) if x["ops"] else None
+            if re.match(r"s_cbranch_\w+|s_branch", x["op"]) and tgt is not None and tgt < n and tgt >= start and n not in done and depth < 3:
+                order.extend(walk(tgt, n, done | {n}, depth + 1))      # the loop body once more (its own back edge not followed again)
+            elif x["op"] == "s_branch" and tgt is not None and tgt > n:
+                if tgt > end:
+                    break
+                n = tgt
+                continue
+            n += 1
+        return order
+
+    return walk(0, len(ins) - 1, frozenset(), 0)
 
 
 def lint(text):
