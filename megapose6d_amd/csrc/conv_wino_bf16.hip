@@ -305,13 +305,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WB_TR_ROW(A, VW) WB_TR_T(A, 0) WB_TR_T(A, 1) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_TR_P(1) WB_TR_W(A, 1, VW) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_TR_P(3) WB_TR_W(A, 3, VW)
   WB_TR_ROW(0, vw) WB_PHASE(1, clk_start)
   WB_SB
-  {
-    const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)
-      _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) pnext[a][bb] = buf4(x_rsrc, x_voff, cs1 + a * row_bytes + bb * pix_bytes);
-  }
-  WB_SB
-  WB_TR_ROW(1, vw) WB_TR_ROW(2, vw) WB_TR_ROW(3, vw)
+  // step 1's 16 patch requests, one behind every second statement of transform rows 1..3 (each occupies the address unit for 16 cycles x 4
+  // waves: back to back they stalled the wave ~600 cycles)
+  const int cs1 = (ns > 1 ? 1 : 0) * (WCK * 4);
+#define WB_PN(K) WB_SB pnext[(K) >> 2][(K) & 3] = buf4(x_rsrc, x_voff, cs1 + ((K) >> 2) * row_bytes + ((K) & 3) * pix_bytes); WB_SB
+#define WB_TR_ROW_PN(A, VW, K0)                                                                          \
+  WB_TR_T(A, 0) WB_TR_T(A, 1) WB_PN((K0) + 0) WB_TR_T(A, 2) WB_TR_T(A, 3) WB_PN((K0) + 1) WB_TR_P(0) WB_TR_W(A, 0, VW) WB_PN((K0) + 2)  \
+  WB_TR_P(1) WB_TR_W(A, 1, VW) WB_PN((K0) + 3) WB_TR_P(2) WB_TR_W(A, 2, VW) WB_PN((K0) + 4) WB_TR_P(3) WB_TR_W(A, 3, VW)
+  WB_TR_ROW_PN(1, vw, 0) WB_PN(5) WB_TR_ROW_PN(2, vw, 6) WB_TR_ROW_PN(3, vw, 11)
+#undef WB_TR_ROW_PN
+#undef WB_PN
   WB_PHASE(2, clk_start)
   _Pragma("unroll") for (int a = 0; a < 4; ++a)
     _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) patch[a][bb] = pnext[a][bb];
@@ -450,8 +453,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           sw[row * WS + j * 32] = (m0 + m1) + m2;
           sw[WT * WS + row * WS + j * 32] = (m1 - m2) - m3;
         }
-        if (more) {
-          constexpr int prow[4] = {0, 2, 1, 3};
+        if (more) {   // the next unit's patch requests, four behind each accumulator block (spreading them further makes the patch registers
+          constexpr int prow[4] = {0, 2, 1, 3};   // live early enough for the allocator to spill 13 loop invariants, whose reloads then queue
+          __builtin_amdgcn_sched_barrier(0);      // behind these very requests)
           _Pragma("unroll") for (int bb = 0; bb < 4; ++bb) { WB_LOAD_PATCH1(prow[i * 2 + j], bb, 0) }
         }
         __builtin_amdgcn_sched_barrier(0);
