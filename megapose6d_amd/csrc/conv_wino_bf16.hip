@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   WB_M(5, AC, UC) WB_SB WB_LOAD_RES1(13) WB_SB                                                           \
   WB_M(6, AC, UC) WB_SB WB_LOAD_RES1(14) WB_SB                                                           \
   WB_M(7, AC, UC) WB_SB WB_LOAD_RES1(15) WB_SB                                                           \
-  WB_M(8, AC, UC) WB_M(9, AC, UC) WB_M(10, AC, UC) WB_M(11, AC, UC) WB_M(12, AC, UC) WB_M(13, AC, UC) WB_M(14, AC, UC)  \
+  WB_M(8, AC, UC) WB_M(9, AC, UC) WB_M(10, AC, UC) WB_M(11, AC, UC) WB_NEXT_INDICES() WB_M(12, AC, UC) WB_M(13, AC, UC) WB_M(14, AC, UC)  \
   WB_M(15, AC, UC) WB_M(16, AC, UC) WB_M(17, AC, UC) WB_M(18, AC, UC) WB_M(19, AC, UC) WB_M(20, AC, UC) WB_M(21, AC, UC) \
   WB_M(22, AC, UC) WB_M(23, AC, UC) WB_M(24, AC, UC) WB_M(25, AC, UC) WB_M(26, AC, UC) WB_M(27, AC, UC) WB_M(28, AC, UC) \
   WB_M(29, AC, UC) WB_M(30, AC, UC) WB_M(31, AC, UC) WB_M(32, AC, UC) WB_M(33, AC, UC) WB_M(34, AC, UC) WB_M(35, AC, UC) WB_SB
@@ -385,6 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     { constexpr int fi = 2; WB_BLK_PL(AA, AB, Ua, Ub, st, 3, 0, 1, cs_patch, vbn, 0) }
     { constexpr int fi = 3; WB_BLK_PL(AB, AA, Ub, Ua, st + 1, 0, 2, 3, cs_patch, vbn, 1) }
   }
+  const int next_unit = unit + (int)gridDim.x;
+  const bool more = PERSIST && next_unit < n_units;
   {   // the last step: nothing to prepare for a following one (see WB_TAIL_RD / WB_TAIL_RES / WB_POINT_LAST)
     const int st = ns - 1;
     const float* vb = vr + (st & 1) * WV_STAGE;
@@ -394,7 +396,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     { constexpr int fi = 0; WB_BLK_RD(AA, AB, Ua, Ub, st, 1, vb, 2) }
     { constexpr int fi = 1; WB_BLK_RD(AB, AA, Ub, Ua, st, 2, vb, 3) }
     { constexpr int fi = 2; WB_BLK_RES(AA, AB, Ua, Ub, st, 3) }
+    // persistent form: the next unit's index arithmetic (~60 instructions) inside the unfenced run of MFMAs of the last point, for the
+    // scheduler to spread under them (this unit needs cb / tile0 / x_voff / u_rsrc no more: its last weight request is in point 2)
+#define WB_NEXT_INDICES() if constexpr (PERSIST) { WB_UNIT_INDICES(next_unit) }   /* (unconditional: a branch would end the scheduling region; unused after the last unit) */
     { constexpr int fi = 3; WB_POINT_LAST(AB, Ub) }
+#undef WB_NEXT_INDICES
   }
   if (clk_sample) {
     atomicAdd(&g_wb_clk[0], __builtin_readcyclecounter() - clk_c0);
@@ -423,10 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // behind each of the four accumulator blocks of the exchange below (rows 0, 2, 1, 3: the order the first transform rows need them; the
   // memory pipe is idle during the exchange) and its accumulator reset four MFMAs at a time behind the passes of the store loop.  All 16
   // requests at once in front of the stores filled the wave's request queue and every store waited an HBM round trip (r6 calls 11 - 13).
-  const int next_unit = unit + (int)gridDim.x;
-  const bool more = PERSIST && next_unit < n_units;
-  if (more) {
-    WB_UNIT_INDICES(next_unit)
+  if (more) {   // (indices: computed under the MFMAs of the last K step)
     WB_UNIT_TABLE()
   }
   // S[wave][2][tile][WS]
