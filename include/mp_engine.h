@@ -256,7 +256,8 @@ int mp_conv3x3_wino_nhwc(const mp_conv_desc* desc, const float* d_u, mp_stream s
  * U = G g G^T and every fp32 fragment of V = B^T d B are split by truncation into three bf16 pieces (24 = 3 x 8 mantissa bits) and ALL
  * nine piece products are accumulated in fp32 -- every product is exact, the result differs from mp_conv3x3_wino_nhwc only in the order
  * of the fp32 additions -- at 9/16 of the fp32-MFMA matrix time.  Same descriptor, eligibility (mp_conv_wino_eligible) and read-slack
- * contract; d_u_pieces = the blob of mp_conv_wino_bf16_pack_weights.  (Counters / clock telemetry of these launches: mp_engine_debug.h.) */
+ * contract; d_u_pieces = the blob of mp_conv_wino_bf16_pack_weights.  Launch form: persistent (one workgroup per CU walks the 64-tile x
+ * 64-channel units; MP_WINO_PERSIST=0 = one workgroup per unit); results are identical.  (Counters / clock telemetry: mp_engine_debug.h.) */
 size_t mp_conv_wino_bf16_packed_bytes(int Cin_p, int Cout);
 int mp_conv_wino_bf16_pack_weights(const float* h_w_oi33, int Cout, int Cin, int Cin_p, const float* h_scale /*[Cout] or NULL*/, void* h_packed);
 int mp_conv3x3_wino_bf16_nhwc(const mp_conv_desc* desc, const void* d_u_pieces, mp_stream stream);
