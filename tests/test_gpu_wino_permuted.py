@@ -31,3 +31,17 @@ def test_winograd_parity_holds_under_a_permuted_register_assignment(n):
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.gpu
+def test_winograd_parity_holds_for_the_one_workgroup_per_unit_launch_form():
+    """The pipeline launches the persistent form of conv3x3_wino_bf16x9 (one workgroup per CU walks the units); MP_WINO_PERSIST=0 selects
+    the form with one workgroup per unit -- the same unit code, kept for A/B runs and as the fallback for grids smaller than the chip.
+    The kernel's parity tests run on it in a child process (the switch is read once per process)."""
+    env = dict(os.environ, MP_WINO_PERSIST="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "(winograd_conv_matches_torch_fp32 and bf16x9) or (exact_piece and bf16x9) or backbone_matches_oracle"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
