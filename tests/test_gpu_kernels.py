@@ -118,6 +118,7 @@ WINO_CASES = [
     (4, 256, 8, 10, 256, 1),
     (70, 16, 6, 6, 64, 2),      # 630 tiles: ten workgroups, the last one partial; border larger than the pad
     (2, 512, 8, 10, 512, 1),
+    (64, 64, 30, 38, 128, 1),   # 18 240 tiles x 2 channel blocks = 570 units > 256 CUs: the PERSISTENT launch form (round 6), ragged: 58 CUs walk 3 units, 198 walk 2
 ]
 
 
