@@ -500,11 +500,43 @@ class PoseEstimator(torch.nn.Module):
         tie order unspecified."""
         t0 = time.perf_counter()
         df = data_TCO.infos
-        group_cols = ["batch_im_id", "label", "instance_id"]
-        df = df.sort_values(filter_field, ascending=ascending, kind="stable").groupby(group_cols).head(top_K)
-        out = data_TCO[df.index.tolist()]
+        keep = _topk_rows_fast(df, top_K, filter_field, ascending)
+        if keep is None:   # (scores with NaN, non-integer ids, ids beyond the packed key's range: the plain pandas form)
+            group_cols = ["batch_im_id", "label", "instance_id"]
+            keep = df.sort_values(filter_field, ascending=ascending, kind="stable").groupby(group_cols).head(top_K).index.to_numpy()
+        out = data_TCO[keep.tolist()]
         mpdist.stats.host_s += time.perf_counter() - t0   # (replicated on every rank: bench.py reports its share of a step)
         return out
+
+
+def _topk_rows_fast(df, top_K: int, field: str, ascending: bool):
+    """Row positions `df.sort_values(field, kind="stable").groupby([batch_im_id, label, instance_id]).head(top_K)` keeps, in that order,
+    without pandas' group-by (1.1 -> 0.2 ms on a 576-row table, 15 -> 9 ms on 36 864 rows; every rank of a multi-GPU run repeats it, so it
+    is the part of a step that does not shrink with the world size).  Integer group key = batch_im_id | instance_id | factorised label;
+    None when that key cannot be formed -- the caller then uses the pandas form, which this reproduces row for row (ties keep the lower
+    row first, as the stable sort does: tests/test_host_cpu.py)."""
+    import pandas as pd
+
+    if len(df) == 0 or df.index.dtype.kind not in "iu" or not df.index.is_unique:
+        return None
+    v = df[field].to_numpy()
+    c1, c3 = df["batch_im_id"].to_numpy(), df["instance_id"].to_numpy()
+    if v.dtype.kind != "f" or c1.dtype.kind not in "iu" or c3.dtype.kind not in "iu" or np.isnan(v).any():
+        return None
+    c2 = pd.factorize(df["label"].to_numpy())[0]
+    if c1.min() < 0 or c1.max() >= 1 << 22 or c3.min() < 0 or c3.max() >= 1 << 24 or c2.min() < 0 or c2.max() >= 1 << 16:
+        return None
+    n = len(v)
+    codes = (c1.astype(np.int64) << 40) | (c3.astype(np.int64) << 16) | c2.astype(np.int64)
+    order = np.argsort(v if ascending else -v, kind="stable")   # (negation keeps ties in row order, like ascending=False of a stable sort)
+    cs = codes[order]
+    o2 = np.argsort(cs, kind="stable")
+    sc = cs[o2]
+    start = np.r_[True, sc[1:] != sc[:-1]]
+    first = np.maximum.accumulate(np.where(start, np.arange(n), 0))
+    rank = np.empty(n, dtype=np.int64)
+    rank[o2] = np.arange(n) - first
+    return df.index.to_numpy()[order[rank < top_K]]
 
 
 # name used by BASELINE.json's north_star; the reference snapshot only has PoseEstimator (SURVEY.md section 0 item 6)

@@ -135,6 +135,34 @@ def test_filter_pose_estimates_topk_and_ties():
     assert sorted(top1.poses.tolist()) == [1.0, 5.0]  # exact tie -> lowest row wins (stable sort)
 
 
+def test_fast_topk_reproduces_the_pandas_group_by_row_for_row():
+    """PoseEstimator.filter_pose_estimates keeps the rows of `sort_values(kind="stable").groupby(...).head(K)` (reference
+    inference/pose_estimator.py:643-667 with a stable sort) through an integer group key instead of pandas' group-by: same rows, same order --
+    ties, descending / ascending, shuffled row order, many groups, string labels; and it steps aside (None) for what the key cannot carry."""
+    from megapose6d_amd.pose_estimator import _topk_rows_fast
+
+    def ref(df, K, field, asc):
+        return df.sort_values(field, ascending=asc, kind="stable").groupby(["batch_im_id", "label", "instance_id"]).head(K).index.to_numpy()
+
+    rng = np.random.RandomState(0)
+    for B, M, K in ((1, 576, 576), (1, 576, 5), (8, 576, 576), (64, 36, 5), (64, 5, 1), (3, 7, 100)):
+        df = pd.DataFrame(dict(label=np.repeat([f"obj_{i % 5:06d}" for i in range(B)], M), batch_im_id=np.repeat(np.arange(B) // 8, M),
+                               instance_id=np.repeat(np.arange(B), M), hypothesis_id=np.tile(np.arange(M), B),
+                               s=rng.randn(B * M).astype(np.float32)))
+        df.loc[::7, "s"] = 0.5   # exact ties
+        for asc in (False, True):
+            assert np.array_equal(_topk_rows_fast(df, K, "s", asc), ref(df, K, "s", asc)), (B, M, K, asc)
+        sh = df.sample(frac=1.0, random_state=1).reset_index(drop=True)
+        assert np.array_equal(_topk_rows_fast(sh, K, "s", False), ref(sh, K, "s", False))
+    nan = df.copy()
+    nan.loc[3, "s"] = np.nan
+    assert _topk_rows_fast(nan, 2, "s", False) is None
+    big = df.copy()
+    big["instance_id"] = big["instance_id"] + (1 << 30)
+    assert _topk_rows_fast(big, 2, "s", False) is None
+    assert _topk_rows_fast(df.iloc[:0], 2, "s", False) is None
+
+
 def test_config_back_compat_and_named_models():
     from megapose6d_amd import load_model as lm
 
