@@ -8,7 +8,7 @@ mkdir -p $O
 R="$GRAFT_REPO_ROOT"
 timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log
-timeout 700 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; echo "rc=$?" >> $O/bench_n1.err
+T0=$(date +%s); timeout 700 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; echo "rc=$? wall_s=$(( $(date +%s) - T0 ))" >> $O/bench_n1.err
 for c in 3 4 5; do timeout 200 python bench.py --config $c --steps 1 --warmup 1 > $O/bench_c$c.json 2> $O/bench_c$c.err; done
 timeout 200 python scripts/icp_timing.py > $O/icp_timing.txt 2>&1
 export TMPDIR=/tmp
