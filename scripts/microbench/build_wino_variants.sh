@@ -20,7 +20,7 @@ for n in 3 8; do
   link wperm$n
 done
 if [ "$MODE" = "ab" ]; then   # A/B and profiling builds of the round: phases = cycle stamps in prologue / epilogue, exp = the DIAG instances
-  for v in "phases -DMP_WINO_PHASES" "exp -DMP_CONV_EXPERIMENTS"; do
+  for v in "phases -DMP_WINO_PHASES" "exp -DMP_CONV_EXPERIMENTS" $EXTRA_VARIANTS; do
     set -- $v; n=$1; shift
     mkdir -p $B/$n
     /opt/rocm/bin/hipcc $F "$@" -c $C/conv_wino_bf16.hip -o $B/$n/conv_wino_bf16.o
