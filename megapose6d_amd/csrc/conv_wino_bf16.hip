@@ -15,9 +15,16 @@
 // Why: v_mfma_f32_32x32x16_bf16 retires 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32 -- nine piece products cost 9/16
 // of one fp32 product.  Together with Winograd's 16/36 the matrix time is 0.25 of the direct fp32 convolution's.
 // Per 16-channel step and wave: 16 ds_read_b128 (as before), 24 weight-fragment loads of 1 KB (L2 -> registers, one frequency point
-// ahead), 4 x 36 MFMAs of 32 cycles.  The schedule is hand-placed (sched_barrier fences, one wave per SIMD issues in order): every MFMA
-// is followed by <= 6 instructions of other work -- the split of the NEXT point's fragments (half an element pair per slot), the next
-// step's input-transform planes, patch / weight requests, fragment reads -- so that the matrix pipe never waits for the vector pipe.
+// ahead), 4 x 36 MFMAs of 32 cycles.  The schedule is placed by hand (sched_barrier fences, one wave per SIMD issues in order): the other
+// work of a wave -- the split of the NEXT point's fragments, the next step's input-transform planes, patch / weight requests, fragment
+// reads -- sits in the gaps behind the MFMAs according to slot tables that scripts/gen_wino_schedule.py generates AND checks
+// (conv_wino_bf16_sched.h: at most 5 instructions per gap, 7 in a gap with a ds_write -- what the gap hides, measured).
+// Structure of a launch (round 6): PERSISTENT -- one workgroup per CU walks the 64-tile x 64-channel units; per unit: prologue (transform of
+// step 0, first splits; its requests were issued under the previous unit's epilogue), K loop, a peeled LEAN last step whose free gaps
+// carry the residual requests and the next unit's index arithmetic, epilogue (exchange through LDS with the next unit's patch requests
+// behind the accumulator blocks, store loop with the next unit's accumulator reset behind its passes).
+// Inline asm and hazards: hipcc does not pad hazards whose producer or consumer sits inside an asm statement -- scripts/isa_hazards.py
+// lints the compiled ISA (tests/test_wino_isa_hazards_cpu.py, product + deliberately permuted builds); see the accumulator reset below.
 // Roofline: bf16 MFMA; algorithmic work = 2 * MACs of the direct convolution; executed = 9 x 16/36 of that in bf16 FLOPs.
 #include <atomic>
 #include <cstdlib>
