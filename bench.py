@@ -29,8 +29,11 @@ import tempfile
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+# dmabuf IPC: RCCL across processes needs it on this driver, and the HSA runtime reads it when it starts (first GPU call of the process)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -64,6 +64,7 @@ def init_from_env(backend: Optional[str] = None) -> None:
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC; only effective if the HSA runtime has not started yet
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend, init_method="env://")
 
